@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec of one Wav2Letter TRAINING step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): per GPU a batch of 32 synthetic 10 s @ 16 kHz
+utterances = 1001 frames x 80 mel features (z-normalised synthetic features; the reference
+extracts features offline, preprocessing.py:212-241), 150-character labels, default Wav2Letter
+depth (speech_model.py:275-295), fp32.  One step = batch -> 11-layer conv forward -> CTC loss +
+gradient -> back-prop -> (gradient all-reduce) -> global-norm clip -> TF-Adam, inputs resident in
+HBM.  Weak scaling: every rank processes its own 32 utterances; value = N*32 / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, HIP
+event timing) and `cpu_baseline` (the numpy oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from speecht_amd.data_parallel import GradientAllReducer  # noqa: E402
+from speecht_amd.engine import Wav2LetterEngine  # noqa: E402
+from tests import workloads as WL  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops(engine, batch):
+  """Algorithmic FLOPs per launch of layer i forward: 2*B*T_out*W*Cin*Cout (unpadded dims)."""
+  out = []
+  for l, (t_in, t_out, pl, pr) in zip(engine.layers, engine.geo):
+    out.append(2.0 * batch * t_out * l.width * l.cin * l.cout)
+  return out
+
+
+def train_step(eng, x_dev, reducer, lr, global_batch):
+  eng.X[0].interior().copy_(x_dev)
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / global_batch)
+  eng.backward(reducer.on_layer_done if reducer else None)
+  if reducer:
+    reducer.finish()
+  eng.apply_update(lr)
+
+
+def measure_dominant_kernel(eng, batch, reps=5):
+  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0> (forward of the
+  wide layers L8, L9: 83 % of forward MACs) on the stream it is launched on."""
+  import ctypes
+  from speecht_amd._lib import call
+  flops = conv_flops(eng, batch)
+  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0 and
+          -(-(batch * eng.geo[i][1]) // 128) * (l.n_pad // 128) >= 512]
+  tot_ms, tot_flops, tot_bytes, launches = 0.0, 0.0, 0.0, 0
+  s = eng.stream_ptr
+  for i in wide:
+    l = eng.layers[i]
+    pf, pb = eng._slice(eng.params, i)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+      call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
+           eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
+    ev1.record()
+    ev1.synchronize()
+    tot_ms += ev0.elapsed_time(ev1) / reps
+    tot_flops += flops[i]
+    t_in, t_out = eng.geo[i][0], eng.geo[i][1]
+    tot_bytes += 4.0 * (batch * t_in * l.cin + l.width * l.cin * l.cout + batch * t_out * l.cout)
+    launches += 1
+  if not launches:
+    return None
+  avg_ms = tot_ms / launches
+  achieved = tot_flops / launches / (avg_ms * 1e-3) / 1e12
+  return dict(bound='mfma', kernel='gemm_nn_kernel<128,128,2,2,0> (conv forward L8,L9)', achieved=round(achieved, 2),
+              peak=PEAK_F32_TFLOPS, unit='TFLOP/s', frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None,
+              avg_launch_ms=round(avg_ms, 4), launches_per_step=launches,
+              algorithmic_gflop_per_launch=round(tot_flops / launches / 1e9, 2),
+              algorithmic_mb_per_launch=round(tot_bytes / launches / 1e6, 2),
+              hbm_frac_of_peak=round(tot_bytes / launches / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+
+
+def cpu_baseline(n_mels, frames, utts=2, steps=2):
+  """The numpy oracle (CPU restatement of the reference path; TF1 cannot be installed) timed on
+  the host cores: `utts` utterances of the same 10 s workload, fp32, full-width network."""
+  from oracle import w2l_oracle as O
+  layers = WL.w2l_layers(n_mels)
+  params = WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32)
+  x, sl, labels = WL.make_batch([frames] * utts, n_mels, seed=0)
+  x = x.astype(np.float32)
+  st = O.zero_opt_state(params)
+  O.train_step(x[:1, :201], [201], [labels[0][:20]], params, layers, st, lr=1e-4)     # warm-up (BLAS threads)
+  t0 = time.time()
+  for _ in range(steps):
+    O.train_step(x, sl, labels, params, layers, st, lr=1e-4)
+  dt = (time.time() - t0) / steps
+  return dict(value=round(utts / dt, 4), unit='utterances/s', cores=os.cpu_count(), kind='port',
+              sample='{} x 10 s utterances, {} full training steps of oracle/w2l_oracle.py (numpy fp32, '
+                     'BLAS threads = host cores)'.format(utts, steps))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+  ap.add_argument('--seconds', type=float, default=10.0)
+  ap.add_argument('--mels', type=int, default=80)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+  assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus)
+  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(dev)
+
+  frames = 1 + int(args.seconds * 16000) // 160
+  layers = WL.w2l_layers(args.mels)
+  eng = Wav2LetterEngine(layers, device=dev)
+  eng.set_weights(WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32))   # same replica everywhere
+  x, seq_lens, labels = WL.make_batch([frames] * args.batch, args.mels, seed=100 + rank)
+  eng.load_batch(x, seq_lens)
+  eng.set_labels(labels)
+  x_dev = torch.as_tensor(x, dtype=torch.float32).to(dev)
+  reducer = GradientAllReducer(eng.grads, eng.layer_ranges) if world > 1 else None
+  global_batch = args.batch * world
+  lr = 1e-4
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    train_step(eng, x_dev, reducer, lr, global_batch)
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    train_step(eng, x_dev, reducer, lr, global_batch)
+  sync()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+  eng.check_ctc_status()
+  loss = float(eng.loss.mean())
+
+  if rank == 0:
+    ms = elapsed / args.steps * 1e3
+    fl = conv_flops(eng, args.batch)
+    step_gflop = (3.0 * sum(fl) - fl[0]) / 1e9     # fwd + bwd-data (not for L0) + bwd-filter
+    out = {
+        'metric': 'utterances/sec (training step, 10 s@16 kHz, batch 32)',
+        'value': round(global_batch / (elapsed / args.steps), 2), 'unit': 'utterances/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: 1xMI355X training step, batch {} of {:g} s synthetic clips, {}-mel, '
+                               'default Wav2Letter depth, fp32'.format(args.batch, args.seconds, args.mels),
+                   'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world},
+        'final_avg_loss': round(loss, 4),
+        'step_tflops_algorithmic': round(step_gflop / ms, 2),
+    }
+    out['roofline'] = measure_dominant_kernel(eng, args.batch)
+    traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if out['roofline'] and os.path.exists(traffic_file):
+      out['roofline']['traffic'] = json.load(open(traffic_file)).get('gemm_nn_fwd_bytes_per_launch')
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(args.mels, frames)
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,134 @@
+/* speecht_hip.h -- C ABI of libspeecht_hip.so: the MI355X (gfx950) kernels behind the
+ * speechT Wav2Letter training / inference step.
+ *
+ * The reference (louiskirsch/speechT) has no FFI of its own: its hot path is a list of
+ * TensorFlow-1 / librosa op call sites.  Each entry point below replaces one of those call
+ * sites (file:line relative to the reference root) and is what a reference-side ctypes
+ * binding would bind (INTEGRATION.md shows the stub).  Conventions:
+ *   - plain `extern "C"`, pointers + sizes only, no torch / C++ types;
+ *   - every pointer is a caller-owned DEVICE pointer unless the name says `host_`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue
+ *     work, they never synchronise and never allocate;
+ *   - return 0 on success, a negative ST_E* code otherwise; st_last_error() gives the text
+ *     (thread-local);
+ *   - workspaces are explicit: query the size, pass the buffer.
+ *
+ * Activation layout ("padded NWC"): the reference's (batch, time, channel) tensors
+ * (speech_model.py:44) are stored with zero halo rows around every utterance and the channel
+ * pitch rounded up to 16 floats, so that tf.nn.conv1d's SAME padding (speech_model.py:155)
+ * becomes plain in-bounds reads and every im2col row is one contiguous, 64-byte aligned span.
+ */
+#ifndef SPEECHT_HIP_H
+#define SPEECHT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_OK 0
+#define ST_EINVAL (-1)   /* bad argument / layout precondition violated */
+#define ST_ELAUNCH (-2)  /* HIP launch error */
+#define ST_EWORKSPACE (-3)
+
+/* element (b, t, c) lives at base[((int64)b * t_pitch + halo + t) * c_pitch + c];
+ * rows outside [0, frames) and channels in [channels, c_pitch) must hold zeros. */
+typedef struct st_tensor3 {
+  float* base;
+  int32_t batch;
+  int32_t frames;
+  int32_t channels;
+  int32_t halo;     /* zero rows in front of frame 0 */
+  int32_t t_pitch;  /* rows per utterance, halo + frames + trailing zero rows */
+  int32_t c_pitch;  /* floats per row, multiple of 16 */
+} st_tensor3;
+
+int st_version(void);
+const char* st_last_error(void);
+
+/* ---- filter packing -------------------------------------------------------------------
+ * Reference filters are [W, Cin, Cout] (speech_model.py:148-151; the `export --weights`
+ * layout, exporting.py:30-40).  The kernels use the row-major GEMM operand
+ * packed[k_pad][n_pad], k = w * cin_pitch + c, zero in all padding. */
+int st_packed_dims(int width, int cin_pitch, int cout, int* k_valid, int* k_pad, int* n_pad);
+int st_pack_filters_f32(const float* filters, int width, int cin, int cout, int cin_pitch,
+                        float* packed, void* stream);
+int st_unpack_filters_f32(const float* packed, int width, int cin, int cout, int cin_pitch,
+                          float* filters, void* stream);
+/* packedT[(w' * cout_pitch + o)][c] = packed[((W-1-w') * cin_pitch + c)][o]: the operand that
+ * turns back-prop to the layer input into the same implicit-GEMM convolution. */
+int st_filters_flip_transpose_f32(const float* packed, int width, int cin, int cout,
+                                  int cin_pitch, int cout_pitch, float* packed_t, void* stream);
+
+/* ---- K5-K7: tf.nn.conv1d('SAME') + bias_add + relu (speech_model.py:155,173,177) -------
+ * y[b,t,o] = act(bias[o] + sum_{w,c} x[b, t*stride + w - pad_left, c] * F[w,c,o]).
+ * Requires x->halo >= pad_left and enough trailing halo; bias has n_pad floats. */
+int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
+                          int stride, int pad_left, int relu, const st_tensor3* y, void* stream);
+
+/* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
+ * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),
+ *   mask = (act[b,t,c] > 0) when act != NULL (tf.nn.relu's gradient of the producing layer).
+ *   packed_t comes from st_filters_flip_transpose_f32; dz->halo >= width-1-pad_left.
+ * bwd_filter: dF[w,c,o] = sum_{b,t} x[b, t*stride + w - pad_left, c] * dz[b,t,o] in packed
+ *   layout [k_pad][n_pad]; dbias[o] = sum_{b,t} dz[b,t,o].  Workspace: st_conv1d_bwd_filter_ws. */
+int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int width,
+                               int pad_left, const st_tensor3* act, const st_tensor3* dx,
+                               void* stream);
+size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width);
+int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int width, int stride,
+                                 int pad_left, float* dpacked, float* dbias, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* ---- K9-K10: tf.nn.ctc_loss + reduce_mean gradient (speech_model.py:74-75) --------------
+ * logits: [B, T', C] padded NWC (halo 0), blank = C-1 (C <= 32).  labels CSR: label_offsets
+ * [B+1], label_ids [label_offsets[B]].  seq_lens[b] = frames to use (reference passes
+ * sequence_lengths // 2).  Outputs: loss[b] = -log p(l|x); grad = grad_scale * dloss/dlogits
+ * (0 for t >= seq_lens[b]); status[b] != 0 when the label does not fit ("Not enough time for
+ * target transition sequence") -- then loss = +inf and grad = 0. */
+size_t st_ctc_ws(int batch, int frames, int max_label_len);
+int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids,
+                         const int32_t* label_offsets, const int32_t* seq_lens, int max_label_len,
+                         float grad_scale, float* loss, const st_tensor3* grad, int32_t* status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K14: tf.nn.ctc_greedy_decoder(merge_repeated) (speech_model.py:113-115) ------------
+ * ids [B][max_out] int32 (max_out >= frames), out_lens [B], neg_sum_logits [B]. */
+int st_ctc_greedy_decode(const st_tensor3* logits, const int32_t* seq_lens, int merge_repeated,
+                         int32_t* ids, int max_out, int32_t* out_lens, float* neg_sum_logits,
+                         void* stream);
+
+/* ---- K12-K13: clip_by_global_norm + AdamOptimizer(epsilon outside) (speech_model.py:77-82)
+ * Flat fp32 buffers of n floats.  stats (device, 2 floats) receives {global_norm, scale}.
+ * lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller (host, double).
+ * p -= lr_t * m / (sqrt(v) + eps) after m,v updates with g * scale. */
+size_t st_global_norm_ws(size_t n);
+int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, float* v, size_t n,
+                                 float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                                 float* stats, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+/* norm only (stats[0] = ||g||, stats[1] = clip/max(norm,clip)); used for reporting */
+int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* stats,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K1-K3: calc_power_spectrogram (preprocessing.py:36-58) -----------------------------
+ * audio: concatenated float samples, sample_offsets [n_utts+1].  For every utterance:
+ * reflect-pad, Hann-512 STFT with hop, |.|^2, mel_basis [n_mels][n_fft/2+1], power_to_db with
+ * ref = max, top_db 80, then (x-mean)/std over the whole matrix, written transposed as
+ * out[frame_offsets[u] + t][n_mels] (frames = 1 + len/hop).  max_samples = longest utterance
+ * (each must exceed n_fft/2 samples, numpy reflect padding); total_frames = frame_offsets[n_utts]. */
+size_t st_melspec_ws(int n_utts, int64_t total_frames, int n_mels);
+int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
+                   const float* mel_basis, int n_mels, int n_fft, int hop,
+                   const int64_t* frame_offsets, int64_t total_frames, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- helpers -------------------------------------------------------------------------- */
+int st_fill_f32(float* dst, float value, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECHT_HIP_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libspeecht_hip.so (include/speecht_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+from .build import LIB_PATH
+
+
+class Tensor3(ctypes.Structure):
+  """st_tensor3: padded NWC activation view."""
+  _fields_ = [('base', c_void_p), ('batch', c_int32), ('frames', c_int32), ('channels', c_int32),
+              ('halo', c_int32), ('t_pitch', c_int32), ('c_pitch', c_int32)]
+
+
+class SpeechtHipError(RuntimeError):
+  pass
+
+
+_T3P = POINTER(Tensor3)
+_SIGNATURES = {
+    'st_version': (c_int, []),
+    'st_last_error': (c_char_p, []),
+    'st_packed_dims': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    'st_pack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'st_unpack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'st_filters_flip_transpose_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'st_conv1d_nwc_fwd_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p]),
+    'st_conv1d_nwc_bwd_data_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p]),
+    'st_conv1d_bwd_filter_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_conv1d_nwc_bwd_filter_f32': (c_int, [_T3P, _T3P, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_size_t, c_void_p]),
+    'st_ctc_ws': (c_size_t, [c_int, c_int, c_int]),
+    'st_ctc_loss_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, _T3P,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_ctc_greedy_decode': (c_int, [_T3P, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'st_global_norm_ws': (c_size_t, [c_size_t]),
+    'st_global_norm_clip_adam_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
+                                             c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_global_norm_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_melspec_ws': (c_size_t, [c_int, c_int64, c_int]),
+    'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
+                               c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_fill_f32': (c_int, [c_void_p, c_float, c_size_t, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+  """Load the shared library (once).  Raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise SpeechtHipError('{} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback)'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+      fn = getattr(lib, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+  return _lib
+
+
+def check(code, what):
+  if code != 0:
+    raise SpeechtHipError('{} failed ({}): {}'.format(what, code, load().st_last_error().decode()))
+
+
+def call(name, *args):
+  """Invoke an int-returning entry point and raise on a non-zero status."""
+  check(getattr(load(), name)(*args), name)

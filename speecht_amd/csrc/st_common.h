@@ -1,0 +1,51 @@
+// Internal helpers shared by the gfx950 kernels of libspeecht_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "speecht_hip.h"
+
+namespace st {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return ST_ELAUNCH;
+  }
+  return ST_OK;
+}
+
+#define ST_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      st::set_error(__VA_ARGS__);  \
+      return ST_EINVAL;            \
+    }                              \
+  } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// float offset of row (b, t) of a padded NWC tensor
+inline long row_offset(const st_tensor3& x, int b, int t) {
+  return ((long)b * x.t_pitch + x.halo + t) * (long)x.c_pitch;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace st

@@ -1,0 +1,282 @@
+"""Device-side execution of the Wav2Letter step: buffers in HBM + the launch sequence.
+
+torch is used for device memory, streams and (in data_parallel.py) torch.distributed only; every
+arithmetic op of the path is a call into libspeecht_hip.so through ``_lib`` (no fallback).
+
+HBM layout (DESIGN.md "Data layout"):
+  * activations X[i] / gradients dZ[i]: padded NWC ``st_tensor3`` buffers, zero halos sized for
+    the consuming convolution, channel pitch rounded to 16 floats;
+  * parameters, gradients, Adam m/v: four flat fp32 buffers with identical layout
+    [F0 | b0 | F1 | b1 | ...], filters in the packed GEMM layout [k_pad][n_pad] -- so the
+    gradient all-reduce and clip+Adam each see one contiguous buffer.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Tensor3, call
+
+
+def _round_up(a, b):
+  return (a + b - 1) // b * b
+
+
+def same_padding(t_in, width, stride):
+  """tf.nn.conv1d 'SAME' (speech_model.py:155): extra zero goes to the right."""
+  t_out = -(-t_in // stride)
+  pad_total = max((t_out - 1) * stride + width - t_in, 0)
+  return t_out, pad_total // 2, pad_total - pad_total // 2
+
+
+class DevTensor3:
+  """A zero-initialised padded NWC buffer plus its st_tensor3 descriptor."""
+
+  def __init__(self, batch, frames, channels, halo_l, halo_r, device):
+    self.batch, self.frames, self.channels = batch, frames, channels
+    self.halo = halo_l
+    self.c_pitch = _round_up(channels, 16)
+    self.t_pitch = halo_l + frames + halo_r
+    self.buf = torch.zeros(batch * self.t_pitch * self.c_pitch, dtype=torch.float32, device=device)
+    self.desc = Tensor3(self.buf.data_ptr(), batch, frames, channels, halo_l, self.t_pitch, self.c_pitch)
+
+  @property
+  def ref(self):
+    return ctypes.byref(self.desc)
+
+  def interior(self):
+    """[B, T, C] strided view of the valid region."""
+    v = self.buf.view(self.batch, self.t_pitch, self.c_pitch)
+    return v[:, self.halo:self.halo + self.frames, :self.channels]
+
+
+class LayerSpec:
+  def __init__(self, width, stride, cin, cout, relu):
+    self.width, self.stride, self.cin, self.cout, self.relu = width, stride, cin, cout, relu
+    self.cin_pitch = _round_up(cin, 16)
+    self.cout_pitch = _round_up(cout, 16)
+    kv, kp, npad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    call('st_packed_dims', width, self.cin_pitch, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+    self.k_valid, self.k_pad, self.n_pad = kv.value, kp.value, npad.value
+    # transposed operand for back-prop to the input: [ru32(W*cout_pitch)][n_pad(cin)]
+    call('st_packed_dims', width, self.cout_pitch, cin, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+    self.kt_pad, self.nt_pad = kp.value, npad.value
+
+
+class Wav2LetterEngine:
+  """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
+
+  def __init__(self, layers, device='cuda:0', stream=None):
+    _lib.load()
+    self.device = torch.device(device)
+    if self.device.type != 'cuda':
+      raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
+    self.layers = [LayerSpec(*l) for l in layers]
+    self.num_classes = self.layers[-1].cout
+    self._stream = stream
+    # flat parameter layout
+    self.offsets = []
+    off = 0
+    for l in self.layers:
+      self.offsets.append((off, off + l.k_pad * l.n_pad))
+      off += l.k_pad * l.n_pad + l.n_pad
+    self.n_flat = off
+    z = lambda: torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+    self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()
+    self.packed_t = [None] + [torch.zeros(l.kt_pad * l.nt_pad, dtype=torch.float32, device=self.device)
+                              for l in self.layers[1:]]
+    self._packed_t_fresh = False
+    self.stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+    self.norm_ws = torch.zeros(_lib.load().st_global_norm_ws(self.n_flat) // 4, dtype=torch.float32,
+                               device=self.device)
+    self.step_count = 0
+    self._shape = None
+
+  # ---- plumbing --------------------------------------------------------------------------
+  @property
+  def stream_ptr(self):
+    s = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    return ctypes.c_void_p(s.cuda_stream)
+
+  def _slice(self, flat, i):
+    fo, bo = self.offsets[i]
+    l = self.layers[i]
+    return flat[fo:bo], flat[bo:bo + l.n_pad]
+
+  @property
+  def layer_ranges(self):
+    """(start, end) of each layer's filters+bias inside the flat buffers."""
+    return [(fo, bo + l.n_pad) for (fo, bo), l in zip(self.offsets, self.layers)]
+
+  def _ptr(self, t):
+    return ctypes.c_void_p(t.data_ptr())
+
+  # ---- weights in the reference's layout (exporting.py:30-40: [W, Cin, Cout] + [Cout]) ----------
+  def set_weights(self, params):
+    """params: list of (filters [W,Cin,Cout], bias [Cout]) numpy arrays."""
+    self.params.zero_()
+    for i, ((F, b), l) in enumerate(zip(params, self.layers)):
+      assert F.shape == (l.width, l.cin, l.cout) and b.shape == (l.cout,), (i, F.shape, b.shape)
+      Fd = torch.as_tensor(np.ascontiguousarray(F), dtype=torch.float32).to(self.device).contiguous()
+      pf, pb = self._slice(self.params, i)
+      call('st_pack_filters_f32', self._ptr(Fd), l.width, l.cin, l.cout, l.cin_pitch, self._ptr(pf), self.stream_ptr)
+      pb[:l.cout] = torch.as_tensor(np.asarray(b), dtype=torch.float32).to(self.device)
+    torch.cuda.synchronize(self.device)
+    self._packed_t_fresh = False
+
+  def _unpack(self, flat):
+    out = []
+    for i, l in enumerate(self.layers):
+      pf, pb = self._slice(flat, i)
+      Fd = torch.empty(l.width * l.cin * l.cout, dtype=torch.float32, device=self.device)
+      call('st_unpack_filters_f32', self._ptr(pf), l.width, l.cin, l.cout, l.cin_pitch, self._ptr(Fd), self.stream_ptr)
+      out.append((Fd.view(l.width, l.cin, l.cout).cpu().numpy(), pb[:l.cout].cpu().numpy()))
+    return out
+
+  def get_weights(self):
+    return self._unpack(self.params)
+
+  def get_grads(self):
+    return self._unpack(self.grads)
+
+  def init_xavier(self, seed=None):
+    """tf.contrib.layers.xavier_initializer + zero biases (speech_model.py:150-152)."""
+    rng = np.random.default_rng(seed)
+    params = []
+    for l in self.layers:
+      limit = math.sqrt(6.0 / (l.width * l.cin + l.width * l.cout))
+      params.append((rng.uniform(-limit, limit, (l.width, l.cin, l.cout)).astype(np.float32),
+                     np.zeros(l.cout, np.float32)))
+    self.set_weights(params)
+
+  # ---- activation buffers ------------------------------------------------------------------
+  def _ensure_shape(self, batch, frames):
+    if self._shape == (batch, frames):
+      return
+    dev = self.device
+    self.X, self.dZ = [], []
+    t = frames
+    geo = []
+    for l in self.layers:
+      t_out, pl, pr = same_padding(t, l.width, l.stride)
+      geo.append((t, t_out, pl, pr))
+      t = t_out
+    self.geo = geo
+    for i, l in enumerate(self.layers):
+      t_in, t_out, pl, pr = geo[i]
+      halo_r = max(pr, (t_out - 1) * l.stride + l.width - pl - t_in)
+      self.X.append(DevTensor3(batch, t_in, l.cin, pl, halo_r, dev))
+      # gradient wrt this layer's pre-activation output; halo for its own back-prop-to-input conv
+      self.dZ.append(DevTensor3(batch, t_out, l.cout, l.width - 1 - pl, pl, dev))
+    last = self.layers[-1]
+    self.X.append(DevTensor3(batch, geo[-1][1], last.cout, 0, 0, dev))     # logits [B, T', C]
+    assert self.X[-1].c_pitch >= 32 or last.cout > 32
+    self.t_out = geo[-1][1]
+    lib = _lib.load()
+    ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
+    self.wgrad_ws = torch.zeros(ws // 4 + 64, dtype=torch.float32, device=dev)
+    self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
+    self.ctc_status = torch.zeros(batch, dtype=torch.int32, device=dev)
+    self.ctc_ws = None
+    self._ctc_lmax = -1
+    self.dec_ids = torch.zeros(batch * self.t_out, dtype=torch.int32, device=dev)
+    self.dec_lens = torch.zeros(batch, dtype=torch.int32, device=dev)
+    self.dec_score = torch.zeros(batch, dtype=torch.float32, device=dev)
+    self._shape = (batch, frames)
+
+  # ---- the path ----------------------------------------------------------------------------
+  def load_batch(self, inputs, seq_lens):
+    """inputs: [B, T, input_size] (numpy or torch, any float dtype); seq_lens: [B] unpadded frames."""
+    x = torch.as_tensor(inputs)
+    B, T, C = x.shape
+    assert C == self.layers[0].cin, 'input_size mismatch'
+    self._ensure_shape(B, T)
+    self.X[0].interior().copy_(x.to(torch.float32), non_blocking=True)
+    self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
+    # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
+    self.ctc_lens = torch.as_tensor((self.seq_lens_host // 2).astype(np.int32)).to(self.device, non_blocking=True)
+
+  def forward(self):
+    s = self.stream_ptr
+    for i, l in enumerate(self.layers):
+      pf, pb = self._slice(self.params, i)
+      call('st_conv1d_nwc_fwd_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
+           self.geo[i][2], int(l.relu), self.X[i + 1].ref, s)
+
+  def logits_time_major(self):
+    """[T', B, C] like tf.transpose(outputs, (1, 0, 2)) (speech_model.py:295)."""
+    return self.X[-1].interior().permute(1, 0, 2)
+
+  def set_labels(self, label_list):
+    ids = np.fromiter((v for l in label_list for v in l), dtype=np.int32)
+    offs = np.zeros(len(label_list) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(l) for l in label_list])
+    self.max_label_len = int(max([len(l) for l in label_list] + [0]))
+    self.label_ids = torch.as_tensor(np.concatenate([ids, np.zeros(1, np.int32)])).to(self.device, non_blocking=True)
+    self.label_offs = torch.as_tensor(offs).to(self.device, non_blocking=True)
+
+  def ctc_loss_grad(self, grad_scale):
+    B, T = self.X[-1].batch, self.X[-1].frames
+    lib = _lib.load()
+    need = lib.st_ctc_ws(B, T, self.max_label_len)
+    if need == 0:
+      raise ValueError('label of length {} is too long for the CTC kernel (max 511)'.format(self.max_label_len))
+    if self.ctc_ws is None or self.ctc_ws.numel() * 4 < need:
+      self.ctc_ws = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
+    call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
+         self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
+         self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
+
+  def refresh_packed_t(self):
+    s = self.stream_ptr
+    for i, l in enumerate(self.layers):
+      if i == 0:
+        continue
+      pf, _ = self._slice(self.params, i)
+      call('st_filters_flip_transpose_f32', self._ptr(pf), l.width, l.cin, l.cout, l.cin_pitch, l.cout_pitch,
+           self._ptr(self.packed_t[i]), s)
+    self._packed_t_fresh = True
+
+  def backward(self, on_layer_done=None):
+    """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
+    called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce)."""
+    s = self.stream_ptr
+    if not self._packed_t_fresh:
+      self.refresh_packed_t()
+    for i in reversed(range(len(self.layers))):
+      l = self.layers[i]
+      gf, gb = self._slice(self.grads, i)
+      call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
+           self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+      if on_layer_done is not None:
+        on_layer_done(i)
+      if i > 0:
+        # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
+        act = self.X[i].ref if self.layers[i - 1].relu else None
+        call('st_conv1d_nwc_bwd_data_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
+             act, self.dZ[i - 1].ref, s)
+
+  def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
+    """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""
+    self.step_count += 1
+    t = self.step_count
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    call('st_global_norm_clip_adam_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
+         self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), float(lr_t), beta1, beta2, eps,
+         self._ptr(self.stats), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
+    self._packed_t_fresh = False
+
+  def greedy_decode(self, merge_repeated=True):
+    """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""
+    call('st_ctc_greedy_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(merge_repeated),
+         self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score), self.stream_ptr)
+    lens = self.dec_lens.cpu().numpy()
+    ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
+    return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
+
+  def check_ctc_status(self):
+    st = self.ctc_status.cpu().numpy()
+    if st.any():
+      raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))

@@ -1,0 +1,278 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (fp32 path vs float64 oracle; BASELINE.json north_star): logits |err| <= 1e-4
+absolute, CTC loss <= 1e-4 relative, gradients <= 2e-4 of the tensor's max magnitude, greedy
+decode strings bit-identical.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  return 'cuda:0'
+
+
+def make_engine(layers, dev):
+  from speecht_amd.engine import Wav2LetterEngine
+  return Wav2LetterEngine(layers, device=dev)
+
+
+def rel_err(a, b):
+  return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+CONV_CASES = [
+    # B, T, W, s, cin, cout, relu
+    (3, 41, 48, 2, 16, 24, True),      # L0-like, odd T -> pad (23,24)
+    (2, 40, 48, 2, 80, 250, True),     # L0 real channels, even T -> pad (23,23)
+    (2, 37, 7, 1, 250, 250, True),     # L1-7 real channels (250 -> pitch 256)
+    (2, 45, 32, 1, 24, 40, True),      # L8-like asymmetric pad (15,16)
+    (1, 33, 32, 1, 250, 2000, True),   # L8 real channels, n_pad 2048 > pitch 2000
+    (2, 29, 1, 1, 2000, 2000, True),   # L9 real, K=2000 -> k_pad 2016
+    (3, 21, 1, 1, 2000, 29, False),    # L10 real, n_pad 32
+    (5, 131, 7, 1, 40, 40, True),      # several 128-row tiles, n_pad 64
+    (1, 3, 7, 1, 16, 16, True),        # fewer frames than the filter width
+]
+
+
+@pytest.mark.parametrize('B,T,W,s,cin,cout,relu', CONV_CASES)
+def test_conv_fwd_bwd(dev, B, T, W, s, cin, cout, relu):
+  rng = np.random.default_rng(B * 1000 + T)
+  x = rng.standard_normal((B, T, cin))
+  F = rng.standard_normal((W, cin, cout)) * (1.0 / math.sqrt(W * cin))
+  b = rng.standard_normal(cout) * 0.1
+  eng = make_engine([(W, s, cin, cout, relu)], dev)
+  eng.set_weights([(F, b)])
+  eng.load_batch(x, [T] * B)
+  eng.forward()
+  y = eng.X[1].interior().cpu().numpy()
+  yref = O.conv1d_same_fwd(x, F, b, s, relu)
+  assert y.shape == yref.shape
+  assert np.max(np.abs(y - yref)) < 2e-5 * max(1.0, np.max(np.abs(yref)))
+  # halos and pad channels must stay zero
+  full = eng.X[1].buf.view(B, eng.X[1].t_pitch, eng.X[1].c_pitch).cpu().numpy()
+  assert np.all(full[:, :, cout:] == 0)
+  # backward: feed dz (gradient wrt the pre-activation) directly
+  dy = rng.standard_normal(yref.shape)
+  dz = dy * (yref > 0) if relu else dy
+  eng.dZ[0].interior().copy_(torch.as_tensor(dz, dtype=torch.float32))
+  eng.backward()
+  (gF, gb), = eng.get_grads()
+  _, dF, db = O.conv1d_same_bwd(x, F, yref, dy, s, relu, need_dx=False)
+  assert rel_err(gF, dF) < 2e-5
+  assert rel_err(gb, db) < 2e-5
+  # padded part of the flat gradient must be exactly zero (it enters the global norm)
+  gsum = float(eng.grads.double().pow(2).sum())
+  assert gsum == pytest.approx(float((gF.astype(np.float64) ** 2).sum() + (gb.astype(np.float64) ** 2).sum()), rel=1e-6)
+
+
+def test_conv_bwd_data_with_relu_mask(dev):
+  rng = np.random.default_rng(3)
+  layers = [(7, 1, 16, 250, True), (32, 1, 250, 40, True), (1, 1, 40, 29, False)]
+  params = WL.xavier_params(layers, seed=5)
+  B, T = 2, 57
+  x = rng.standard_normal((B, T, 16))
+  eng = make_engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, [T] * B)
+  eng.forward()
+  logits, acts = O.wav2letter_forward(x, params, layers, keep=True)
+  assert np.max(np.abs(eng.logits_time_major().cpu().numpy() - logits)) < 1e-5
+  dl = rng.standard_normal(logits.shape)
+  eng.dZ[-1].interior().copy_(torch.as_tensor(np.transpose(dl, (1, 0, 2)), dtype=torch.float32))
+  eng.backward()
+  ref = O.wav2letter_backward(acts, params, layers, dl)
+  for (gF, gb), (rF, rb) in zip(eng.get_grads(), ref):
+    assert rel_err(gF, rF) < 2e-5 and rel_err(gb, rb) < 2e-5
+
+
+def _ctc_case(rng, B, T, C, lengths, lens=None):
+  logits = rng.standard_normal((T, B, C)) * 2.0
+  labels = [rng.integers(0, C - 1, L).tolist() for L in lengths]
+  lens = np.full(B, T) if lens is None else np.asarray(lens)
+  return logits, labels, lens
+
+
+def run_ctc(dev, logits_tm, labels, lens, scale=1.0):
+  T, B, C = logits_tm.shape
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits_tm, (1, 0, 2)), dtype=torch.float32))
+  eng.ctc_lens = torch.as_tensor(np.asarray(lens, dtype=np.int32)).to(dev)
+  eng.set_labels(labels)
+  eng.ctc_loss_grad(scale)
+  torch.cuda.synchronize()
+  grad = np.transpose(eng.dZ[-1].interior().cpu().numpy(), (1, 0, 2))
+  return eng, eng.loss.cpu().numpy(), grad
+
+
+@pytest.mark.parametrize('T,lengths', [
+    (50, [0, 1, 7, 20]),             # KPL 1 (U <= 64): empty label, single label
+    (120, [31, 32, 45, 3]),          # KPL 1/2 boundary (U = 63, 65)
+    (300, [150, 95, 140]),           # KPL 5: the bench shape (L = 150 -> U = 301)
+    (260, [130, 127, 128]),          # exact lane boundaries
+    (700, [330, 200]),               # KPL 12
+])
+def test_ctc_loss_grad(dev, T, lengths):
+  rng = np.random.default_rng(T)
+  B = len(lengths)
+  lens = [T - 3 * i for i in range(B)]           # ragged
+  logits, labels, lens = _ctc_case(rng, B, T, 29, lengths, lens)
+  if lengths[0] >= 5:
+    labels[0][1] = labels[0][0]                  # force repeats
+    labels[0][3] = labels[0][2]
+  ref_loss, ref_grad = O.ctc_loss_and_grad(logits, labels, lens)
+  eng, loss, grad = run_ctc(dev, logits, labels, lens, scale=0.5)
+  assert not eng.ctc_status.cpu().numpy().any()
+  np.testing.assert_allclose(loss, ref_loss, rtol=1e-4)
+  assert np.max(np.abs(grad - 0.5 * ref_grad)) < 2e-4
+  for b in range(B):
+    assert np.all(grad[lens[b]:, b] == 0)
+
+
+def test_ctc_closed_forms_and_errors(dev):
+  C = 29
+  T = 7
+  _, loss, grad = run_ctc(dev, np.zeros((T, 1, C)), [[]], [T])
+  assert loss[0] == pytest.approx(T * math.log(C), rel=1e-5)
+  _, loss, _ = run_ctc(dev, np.zeros((6, 1, C)), [[2]], [6])
+  assert loss[0] == pytest.approx(-math.log(6 * 7 / 2 / C ** 6), rel=1e-5)
+  _, loss, _ = run_ctc(dev, np.zeros((3, 1, C)), [[1, 1]], [3])
+  assert loss[0] == pytest.approx(3 * math.log(C), rel=1e-5)
+  # "aa" cannot be emitted in 2 frames: TF raises InvalidArgument; we flag + raise in the host layer
+  eng, loss, grad = run_ctc(dev, np.zeros((2, 2, C)), [[1, 1], [3]], [2, 2])
+  assert eng.ctc_status.cpu().numpy().tolist() == [1, 0]
+  assert math.isinf(loss[0]) and np.all(grad[:, 0] == 0) and np.isfinite(loss[1])
+  with pytest.raises(ValueError):
+    eng.check_ctc_status()
+
+
+def test_greedy_decode_bit_identical(dev):
+  rng = np.random.default_rng(9)
+  T, B, C = 301, 6, 29
+  logits = rng.standard_normal((T, B, C)).astype(np.float32)
+  logits[:, 0, :] = np.round(logits[:, 0, :])          # many exact ties -> lowest index must win
+  logits[:, 1, 28] += 3.0                              # mostly blanks
+  logits[:, 2, :] = 0.0                                # all ties: 'a' every frame -> one 'a'
+  logits[10:200, 3, 5] = 9.0                           # long run merges
+  lens = np.array([301, 300, 17, 250, 1, 150])
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits, (1, 0, 2))))
+  eng.ctc_lens = torch.as_tensor(lens.astype(np.int32)).to(dev)
+  for merge in (True, False):
+    ids, score = eng.greedy_decode(merge)
+    ref_ids, ref_score = O.ctc_greedy_decode(logits.astype(np.float64), lens, merge)
+    assert ids == ref_ids
+    np.testing.assert_allclose(score, ref_score, rtol=1e-5)
+
+
+@pytest.mark.parametrize('n,clip', [(1000, 5.0), (1 << 20, 5.0), (4099, 0.01)])
+def test_clip_adam(dev, n, clip):
+  from speecht_amd import _lib
+  import ctypes
+  rng = np.random.default_rng(n)
+  p = rng.standard_normal(n); g = rng.standard_normal(n) * (0.001 if clip == 5.0 and n == 1000 else 1.0)
+  m = rng.standard_normal(n) * 0.1; v = rng.random(n) * 0.01
+  t = [torch.as_tensor(a, dtype=torch.float32).to(dev) for a in (p, g, m, v)]
+  stats = torch.zeros(2, device=dev)
+  ws = torch.zeros(2048, device=dev)
+  step, lr = 3, 1e-3
+  lr_t = lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+  P = lambda x: ctypes.c_void_p(x.data_ptr())
+  _lib.call('st_global_norm_clip_adam_f32', P(t[0]), P(t[1]), P(t[2]), P(t[3]), n, clip, lr_t, 0.9, 0.999, 1e-3,
+            P(stats), P(ws), ws.numel() * 4, None)
+  torch.cuda.synchronize()
+  g32, p32, m32, v32 = (a.astype(np.float32).astype(np.float64) for a in (g, p, m, v))
+  clipped, gn = O.clip_by_global_norm([g32], clip)
+  pr, mr, vr = O.adam_tf_step(p32, clipped[0], m32, v32, step, lr)
+  assert float(stats[0]) == pytest.approx(gn, rel=1e-5)
+  assert float(stats[1]) == pytest.approx(clip / max(gn, clip), rel=1e-5)
+  np.testing.assert_allclose(t[0].cpu().numpy(), pr, rtol=2e-5, atol=1e-6)
+  np.testing.assert_allclose(t[2].cpu().numpy(), mr, rtol=2e-5, atol=1e-7)
+  np.testing.assert_allclose(t[3].cpu().numpy(), vr, rtol=2e-5, atol=1e-9)
+
+
+def test_small_train_step_vs_oracle_and_golden(dev, golden_dir):
+  import os
+  case = WL.small_train_case()
+  gold = np.load(os.path.join(golden_dir, 'w2l_small_golden.npz'))
+  eng = make_engine(case['layers'], dev)
+  eng.set_weights(case['params'])
+  eng.load_batch(case['x'], case['seq_lens'])
+  eng.set_labels(case['labels'])
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / 3)
+  eng.backward()
+  grads = eng.get_grads()
+  eng.apply_update(lr=1e-4)
+  dec, score = eng.greedy_decode()
+  torch.cuda.synchronize()
+  ref = O.train_step(case['x'], case['seq_lens'], case['labels'], case['params'], case['layers'],
+                     O.zero_opt_state(case['params']), lr=1e-4)
+  logits = eng.logits_time_major().cpu().numpy()
+  assert np.max(np.abs(logits - ref['logits'])) < 1e-4
+  assert np.max(np.abs(logits - gold['logits'])) < 1e-4
+  loss = eng.loss.cpu().numpy()
+  np.testing.assert_allclose(loss, ref['loss'], rtol=1e-4)
+  assert float(loss.mean()) == pytest.approx(float(gold['avg_loss']), rel=1e-4)
+  assert float(eng.stats[0]) == pytest.approx(ref['grad_norm'], rel=1e-4)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(grads, ref['grads'])):
+    assert rel_err(gF, rF) < 2e-4, i
+    assert rel_err(gb, rb) < 2e-4, i
+    np.testing.assert_allclose(gb, gold['gb%d' % i], atol=2e-4 * np.max(np.abs(gold['gb%d' % i])))
+  for (pF, pb), (rF, rb) in zip(eng.get_weights(), ref['params']):
+    assert np.max(np.abs(pF - rF)) < 2e-6 and np.max(np.abs(pb - rb)) < 2e-6
+  ref_dec, _ = O.ctc_greedy_decode(ref['logits'], case['seq_lens'] // 2)
+  assert dec == ref_dec
+  gold_dec = [[int(v) for v in row if v >= 0] for row in gold['decoded']]
+  assert dec == gold_dec
+
+
+def test_full_width_forward_logits(dev):
+  """Real Wav2Letter widths (80-mel, 250/2000 channels), B=2 ragged, ~2 s clips."""
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42)
+  x, seq_lens, labels = WL.make_batch([201, 160], 80, seed=2)
+  eng = make_engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, seq_lens)
+  eng.forward()
+  logits = eng.logits_time_major().cpu().numpy()
+  ref = O.wav2letter_forward(x, params, layers)
+  assert logits.shape == ref.shape == (101, 2, 29)
+  assert np.max(np.abs(logits - ref)) < 1e-4
+  ids, _ = eng.greedy_decode()
+  ref_ids, _ = O.ctc_greedy_decode(ref, seq_lens // 2)
+  assert ids == ref_ids
+
+
+@pytest.mark.parametrize('n_mels,sr', [(80, 16000), (128, 22050)])
+def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
+  """calc_power_spectrogram (preprocessing.py:36-58): ragged batch, odd lengths; the features are
+  z-normalised dB values (std 1), tolerance 1e-3 absolute (fp32 FFT + log10 vs float64)."""
+  import os
+  from speecht_amd.preprocessing import calc_power_spectrogram, calc_power_spectrogram_batch
+  audio = [O.synthetic_audio(7, 16000 + 77), O.synthetic_audio(8, 32000), O.synthetic_audio(9, 5003),
+           np.sin(2 * np.pi * 440.0 * np.arange(12345) / sr).astype(np.float32)]
+  feats = calc_power_spectrogram_batch(audio, sr, n_mels=n_mels)
+  for a, f in zip(audio, feats):
+    ref = O.calc_power_spectrogram(a, sr, n_mels=n_mels)
+    assert f.shape == ref.shape == (1 + len(a) // 160, n_mels)
+    assert np.max(np.abs(f - ref)) < 1e-3
+  single = calc_power_spectrogram(audio[0], sr, n_mels=n_mels)
+  np.testing.assert_array_equal(single, feats[0])
+  if n_mels == 80 and sr == 16000:
+    gold = np.load(os.path.join(golden_dir, 'w2l_small_golden.npz'))['mel80']
+    assert np.max(np.abs(feats[0] - gold)) < 1e-3

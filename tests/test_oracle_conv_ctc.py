@@ -1,0 +1,193 @@
+"""Pins the numpy oracle against an independent torch-CPU formulation and analytical cases.
+
+The reference's own tests hold no numeric vector for this path, so these are the
+oracle's pins: F.conv1d + autograd, F.ctc_loss, closed-form CTC values.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import w2l_oracle as O
+
+
+def torch_conv_same(x, filt, bias, stride, relu):
+  # x [B,T,Cin] -> NCW, filters [W,Cin,Cout] -> [Cout,Cin,W]
+  t_out, pl, pr = O.same_padding(x.shape[1], filt.shape[0], stride)
+  xt = F.pad(x.permute(0, 2, 1), (pl, pr))
+  y = F.conv1d(xt, filt.permute(2, 1, 0), bias, stride=stride).permute(0, 2, 1)
+  return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize('T,W,s,cin,cout,relu', [
+    (21, 48, 2, 5, 7, True), (20, 48, 2, 5, 7, True), (17, 7, 1, 6, 6, True),
+    (33, 32, 1, 4, 9, True), (9, 1, 1, 8, 3, False), (50, 5, 3, 3, 4, True)])
+def test_conv_fwd_bwd_vs_torch(T, W, s, cin, cout, relu):
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((3, T, cin))
+  filt = rng.standard_normal((W, cin, cout)) * 0.2
+  bias = rng.standard_normal(cout) * 0.1
+  y = O.conv1d_same_fwd(x, filt, bias, s, relu)
+  xt = torch.tensor(x, requires_grad=True)
+  ft = torch.tensor(filt, requires_grad=True)
+  bt = torch.tensor(bias, requires_grad=True)
+  yt = torch_conv_same(xt, ft, bt, s, relu)
+  assert y.shape == tuple(yt.shape)
+  np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-12, atol=1e-12)
+  dy = rng.standard_normal(y.shape)
+  yt.backward(torch.tensor(dy))
+  dx, dF, db = O.conv1d_same_bwd(x, filt, y, dy, s, relu)
+  np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-11, atol=1e-11)
+  np.testing.assert_allclose(dF, ft.grad.numpy(), rtol=1e-11, atol=1e-11)
+  np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-11, atol=1e-11)
+
+
+def test_same_padding_asymmetry():
+  # Appendix A1: L0 pads (23,23) for even T and (23,24) for odd T; L8 (15,16); W7 (3,3)
+  assert O.same_padding(1000, 48, 2) == (500, 23, 23)
+  assert O.same_padding(1001, 48, 2) == (501, 23, 24)
+  assert O.same_padding(501, 32, 1) == (501, 15, 16)
+  assert O.same_padding(501, 7, 1) == (501, 3, 3)
+  # delta filter exposes which tap lines up with the output frame
+  x = np.arange(1.0, 11.0).reshape(1, 10, 1)
+  for W, s in [(4, 1), (48, 2), (32, 1)]:
+    t_out, pl, _ = O.same_padding(10, W, s)
+    filt = np.zeros((W, 1, 1))
+    filt[pl, 0, 0] = 1.0
+    y = O.conv1d_same_fwd(x, filt, np.zeros(1), s, relu=False)
+    np.testing.assert_allclose(y[0, :, 0], x[0, ::s, 0])
+
+
+def _rand_ctc_case(rng, T, B, C, Lmax):
+  logits = rng.standard_normal((T, B, C)) * 2.0
+  lens = rng.integers(max(2, T // 2), T + 1, B)
+  labels = []
+  for b in range(B):
+    L = int(rng.integers(0, min(Lmax, lens[b] // 2) + 1))
+    labels.append(rng.integers(0, C - 1, L).tolist())
+  return logits, labels, lens
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_ctc_vs_torch(seed):
+  rng = np.random.default_rng(seed)
+  T, B, C = 40, 5, 29
+  logits, labels, lens = _rand_ctc_case(rng, T, B, C, 12)
+  if seed == 0:
+    labels[0] = [3, 3, 3, 7, 7]          # repeats need separating blanks
+    labels[1] = []                       # empty label (U = 1)
+  loss, grad = O.ctc_loss_and_grad(logits, labels, lens)
+  lt = torch.tensor(logits, requires_grad=True)
+  lp = torch.log_softmax(lt, dim=-1)
+  flat = torch.tensor([v for l in labels for v in l], dtype=torch.long)
+  tl = F.ctc_loss(lp, flat, torch.tensor(lens), torch.tensor([len(l) for l in labels]),
+                  blank=C - 1, reduction='none', zero_infinity=False)
+  np.testing.assert_allclose(loss, tl.detach().numpy(), rtol=1e-10, atol=1e-10)
+  tl.sum().backward()
+  np.testing.assert_allclose(grad, lt.grad.numpy(), rtol=1e-8, atol=1e-10)
+  for b in range(B):                     # no gradient beyond the utterance length
+    assert np.all(grad[lens[b]:, b] == 0)
+
+
+def test_ctc_closed_forms():
+  C = 29
+  # uniform logits, empty label: only the all-blank path, p = 29^-T
+  T = 7
+  loss, grad = O.ctc_loss_and_grad(np.zeros((T, 1, C)), [[]], [T])
+  assert loss[0] == pytest.approx(T * math.log(C), rel=1e-12)
+  # T = 1, L = 1: p = y(label)
+  lg = np.random.default_rng(1).standard_normal((1, 1, C))
+  loss, grad = O.ctc_loss_and_grad(lg, [[4]], [1])
+  y = np.exp(O.log_softmax(lg[0, 0]))
+  assert loss[0] == pytest.approx(-math.log(y[4]), rel=1e-12)
+  expect = y.copy()
+  expect[4] -= 1.0
+  np.testing.assert_allclose(grad[0, 0], expect, atol=1e-12)
+  # uniform logits, one label, T frames: #paths = T(T+1)/2 (choose start and end of the run)
+  T = 6
+  loss, _ = O.ctc_loss_and_grad(np.zeros((T, 1, C)), [[2]], [T])
+  assert loss[0] == pytest.approx(-math.log(T * (T + 1) / 2 / C ** T), rel=1e-12)
+  # a repeated label needs a blank in between: "aa" in 2 frames is impossible
+  with pytest.raises(ValueError):
+    O.ctc_loss_and_grad(np.zeros((2, 1, C)), [[1, 1]], [2])
+  # ... and in 3 frames exactly one path a,blank,a
+  loss, _ = O.ctc_loss_and_grad(np.zeros((3, 1, C)), [[1, 1]], [3])
+  assert loss[0] == pytest.approx(3 * math.log(C), rel=1e-12)
+
+
+def test_ctc_grad_finite_difference():
+  rng = np.random.default_rng(5)
+  logits, labels, lens = _rand_ctc_case(rng, 12, 2, 6, 4)
+  loss, grad = O.ctc_loss_and_grad(logits, labels, lens)
+  eps = 1e-6
+  for (t, b, c) in [(0, 0, 1), (3, 1, 5), (7, 0, 2), (11, 1, 0)]:
+    lp = logits.copy(); lp[t, b, c] += eps
+    lm = logits.copy(); lm[t, b, c] -= eps
+    fd = (O.ctc_loss_and_grad(lp, labels, lens)[0][b] - O.ctc_loss_and_grad(lm, labels, lens)[0][b]) / (2 * eps)
+    assert grad[t, b, c] == pytest.approx(fd, abs=1e-6)
+
+
+def test_greedy_decode_semantics():
+  C = 29
+  blank = C - 1
+  seq = [0, blank, 0, 0, 5, blank, blank, 5, 7]   # "a, blank, a" keeps both a's; "a a" merges
+  logits = np.full((len(seq), 1, C), -1.0)
+  for t, k in enumerate(seq):
+    logits[t, 0, k] = 2.0
+  ids, score = O.ctc_greedy_decode(logits, [len(seq)])
+  assert ids == [[0, 0, 5, 5, 7]]
+  assert score[0, 0] == pytest.approx(-2.0 * len(seq))
+  ids, _ = O.ctc_greedy_decode(logits, [4])       # length cuts the tail
+  assert ids == [[0, 0]]
+  tie = np.zeros((1, 1, C))                       # ties -> lowest index
+  assert O.ctc_greedy_decode(tie, [1])[0] == [[0]]
+  ids, _ = O.ctc_greedy_decode(logits, [len(seq)], merge_repeated=False)
+  assert ids == [[0, 0, 0, 5, 5, 7]]
+
+
+def test_adam_tf_vs_torch_adam_differs_and_closed_form():
+  p = np.array([1.0, -2.0]); g = np.array([0.5, -0.25])
+  p1, m1, v1 = O.adam_tf_step(p, g, np.zeros(2), np.zeros(2), 1, lr=1e-3)
+  m = 0.1 * g; v = 0.001 * g * g
+  lr_t = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)
+  np.testing.assert_allclose(p1, p - lr_t * m / (np.sqrt(v) + 1e-3), rtol=1e-15)
+  clipped, gn = O.clip_by_global_norm([np.array([3.0, 4.0]), np.array([12.0])], 5.0)
+  assert gn == pytest.approx(13.0)
+  np.testing.assert_allclose(clipped[0], np.array([3.0, 4.0]) * 5 / 13)
+  same, gn = O.clip_by_global_norm([np.array([0.3, 0.4])], 5.0)
+  np.testing.assert_allclose(same[0], [0.3, 0.4])
+
+
+def test_train_step_grads_vs_torch_autograd():
+  """Whole-path gradient (11 layers + CTC mean) against torch autograd on a tiny batch."""
+  rng = np.random.default_rng(11)
+  layers = [(48, 2, 6, 10, True), (7, 1, 10, 10, True), (32, 1, 10, 16, True),
+            (1, 1, 16, 16, True), (1, 1, 16, 29, False)]
+  params = O.xavier_init(layers, seed=3, bias_range=0.05)
+  B, T = 3, 41
+  x = rng.standard_normal((B, T, 6))
+  x[1, 30:] = 0; x[2, 25:] = 0
+  seq = np.array([41, 30, 25])
+  labels = [[1, 2, 2, 3], [5], [7, 8, 9]]
+  out = O.train_step(x, seq, labels, params, layers, O.zero_opt_state(params), update=False)
+  tp = [(torch.tensor(F_, requires_grad=True), torch.tensor(b_, requires_grad=True)) for F_, b_ in params]
+  h = torch.tensor(x)
+  for (F_, b_), (W, s, cin, cout, relu) in zip(tp, layers):
+    h = torch_conv_same(h, F_, b_, s, relu)
+  lp = torch.log_softmax(h.permute(1, 0, 2), dim=-1)
+  flat = torch.tensor([v for l in labels for v in l])
+  tl = F.ctc_loss(lp, flat, torch.tensor(seq // 2), torch.tensor([len(l) for l in labels]),
+                  blank=28, reduction='none').mean()
+  assert out['avg_loss'] == pytest.approx(float(tl), rel=1e-10)
+  tl.backward()
+  for (gF, gb), (F_, b_) in zip(out['grads'], tp):
+    np.testing.assert_allclose(gF, F_.grad.numpy(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gb, b_.grad.numpy(), rtol=1e-7, atol=1e-10)
+
+
+def test_levenshtein():
+  assert O.levenshtein('kitten', 'sitting') == 3
+  assert O.levenshtein('', 'abc') == 3
+  assert O.levenshtein('a b c'.split(), 'a c'.split()) == 1

@@ -54,6 +54,13 @@ def load():
   """Load the shared library (once).  Raises if it has not been built."""
   global _lib
   if _lib is None:
+    # The process must run ONE HIP runtime.  torch bundles its own libamdhip64.so (soname without
+    # version), hipcc links ours against /opt/rocm's libamdhip64.so.7: make torch's runtime globally
+    # visible first so that our HIP calls bind to the runtime that owns torch's streams and memory.
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(bundled):
+      ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     if not os.path.exists(LIB_PATH):
       raise SpeechtHipError('{} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                             '(there is no CPU fallback)'.format(LIB_PATH))

@@ -34,17 +34,44 @@ struct RowMap2 {   // (b, t) -> float offset
   }
 };
 
-__device__ __forceinline__ float lse2(float a, float b) {
+// ---- base-2 log-domain helpers: v_exp_f32 / v_log_f32 are 2^x / log2(x) natively -------------
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float lse2_b2(float a, float b) {
   float m = fmaxf(a, b);
-  if (m == NEG_INF) return NEG_INF;
-  return m + __logf(__expf(a - m) + __expf(b - m));
+  float ms = m == NEG_INF ? 0.f : m;
+  return ms + lg2(ex2(a - ms) + ex2(b - ms));
 }
-__device__ __forceinline__ float lse3(float a, float b, float c) {
+__device__ __forceinline__ float lse3_b2(float a, float b, float c) {   // branch free; all -inf -> -inf
   float m = fmaxf(fmaxf(a, b), c);
-  if (m == NEG_INF) return NEG_INF;
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+  float ms = m == NEG_INF ? 0.f : m;
+  return ms + lg2(ex2(a - ms) + ex2(b - ms) + ex2(c - ms));
 }
 
+// cross-lane moves on the VALU (DPP), no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                               __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float from_lane_below(float v) { return dpp_move<0x138>(v, NEG_INF); }   // wave_shr:1
+__device__ __forceinline__ float from_lane_above(float v) { return dpp_move<0x130>(v, NEG_INF); }   // wave_shl:1
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v, v));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_move<0x4E>(v, v));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_move<0x141>(v, v));    // row_half_mirror
+  v = fmaxf(v, dpp_move<0x140>(v, v));    // row_mirror: every lane of a 16-row holds the row max
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int NORM_EVERY = 4;   // re-centre the lattice column every 4 frames
+
+// log2-softmax of every (b, t) row into the scratch [B*T][32]
 __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __restrict__ logits, RowMap2 map,
                                                              int B, int T, int C, float* __restrict__ logy) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,18 +96,23 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __rest
   for (int q = 0; q < CP / 4; ++q) {
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (4 * q + e < C) ? v[4 * q + e] - lz : 0.f;
+    for (int e = 0; e < 4; ++e) o[e] = (4 * q + e < C) ? (v[4 * q + e] - lz) * LOG2E : 0.f;
     *reinterpret_cast<f32x4*>(out + 4 * q) = o;
   }
 }
 
 // One wave per (utterance, direction).  blockIdx.y: 0 = alpha, 1 = beta.
+// Lattice columns are kept RE-CENTRED: stored value = log2 alpha_t(u) - off[t], where off (double,
+// one per frame) accumulates the wave maximum subtracted every NORM_EVERY frames.  The f32 state
+// therefore stays O(10) instead of O(-1000) and keeps ~1e-6 absolute precision over 500+ frames.
+// Storage is lane-major: value of state u = lane*KPL + j at frame t sits at ((t*KPL + j)*64 + lane).
 template <int KPL>
 __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logy, int T, int C,
                                                             const int* __restrict__ label_ids,
                                                             const int* __restrict__ label_off,
                                                             const int* __restrict__ seq_lens,
                                                             float* __restrict__ alpha, float* __restrict__ beta,
+                                                            double* __restrict__ aoff, double* __restrict__ boff,
                                                             int* __restrict__ status) {
   constexpr int UP = KPL * 64;
   __shared__ __attribute__((aligned(16))) float E[2][TC * CP];
@@ -104,7 +136,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
   }
   if (!is_beta && lane == 0) status[b] = 0;
 
-  int cls[KPL];
+  int coff[KPL];          // class column of each state (LDS float offset inside an emission row)
   bool valid[KPL], skip[KPL];
 #pragma unroll
   for (int j = 0; j < KPL; ++j) {
@@ -112,13 +144,14 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     valid[j] = u < U;
     const bool odd = (u & 1) && valid[j];
     const int li = (u - 1) >> 1;
-    cls[j] = odd ? lab[li] : blank;
+    coff[j] = odd ? lab[li] : blank;
     if (!is_beta) skip[j] = odd && u >= 3 && lab[li] != lab[li - 1];          // may arrive from u-2
     else skip[j] = odd && u + 2 < U && lab[li + 1] != lab[li];                  // may leave to u+2
   }
 
   const float* ly = logy + (long)b * T * CP;
-  float* dst = (is_beta ? beta : alpha) + (long)b * T * UP + lane * KPL;
+  float* dst = (is_beta ? beta : alpha) + (long)b * T * UP + lane;
+  double* doff = (is_beta ? boff : aoff) + (long)b * T;
 
   // stage one 64-frame chunk of emissions [chunk*TC, +TC) into E[buf]; rows past T read row T-1
   f32x4 stage[TC * CP / 4 / 64];
@@ -135,8 +168,20 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     for (int i = 0; i < TC * CP / 4 / 64; ++i)
       *reinterpret_cast<f32x4*>(&E[buf][(lane + 64 * i) * 4]) = stage[i];
   };
+  auto recentre = [&](float (&s)[KPL], double& off) {
+    float m = NEG_INF;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) m = fmaxf(m, s[j]);
+    m = wave_max_dpp(m);
+    if (m != NEG_INF) {
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) s[j] -= m;
+      off += (double)m;
+    }
+  };
 
-  float s[KPL];   // alpha_t(u) resp. beta_t(u)
+  float s[KPL];   // re-centred log2 alpha_t(u) resp. log2 beta_t(u)
+  double off = 0.0;
   if (!is_beta) {
     // ---- alpha: t ascending ------------------------------------------------------------
     chunk_load(0);
@@ -144,10 +189,11 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
       const int u = lane * KPL + j;
-      s[j] = (u < 2 && valid[j]) ? E[0][cls[j]] : NEG_INF;
+      s[j] = (u < 2 && valid[j]) ? E[0][coff[j]] : NEG_INF;
     }
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) dst[j] = s[j];
+    for (int j = 0; j < KPL; ++j) dst[j * 64] = s[j];
+    if (lane == 0) doff[0] = 0.0;
     const int nchunks = (Tb + TC - 1) / TC;
     for (int ch = 0; ch < nchunks; ++ch) {
       const int buf = ch & 1;
@@ -155,21 +201,26 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       const int t_lo = max(1, ch * TC), t_hi = min(Tb, (ch + 1) * TC);
       for (int t = t_lo; t < t_hi; ++t) {
         const float* e = &E[buf][(t - ch * TC) * CP];
-        float up1 = __shfl_up(s[KPL - 1], 1, 64);
-        float up2 = KPL >= 2 ? __shfl_up(s[KPL >= 2 ? KPL - 2 : 0], 1, 64) : __shfl_up(s[0], 2, 64);
-        if (lane == 0) { up1 = NEG_INF; up2 = NEG_INF; }
-        if (KPL == 1 && lane == 1) up2 = NEG_INF;
+        float ev[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) ev[j] = e[coff[j]];
+        const float up1 = from_lane_below(s[KPL - 1]);
+        const float up2 = KPL >= 2 ? from_lane_below(s[KPL >= 2 ? KPL - 2 : 0]) : from_lane_below(up1);
         float n[KPL];
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
           const float p1 = j >= 1 ? s[j >= 1 ? j - 1 : 0] : up1;
           const float p2 = j >= 2 ? s[j >= 2 ? j - 2 : 0] : (j == 1 ? up1 : up2);
-          const float v = e[cls[j]] + lse3(s[j], p1, skip[j] ? p2 : NEG_INF);
+          const float v = ev[j] + lse3_b2(s[j], p1, skip[j] ? p2 : NEG_INF);
           n[j] = valid[j] ? v : NEG_INF;
         }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) s[j] = n[j];
+        if ((t & (NORM_EVERY - 1)) == 0) recentre(s, off);
         float* o = dst + (long)t * UP;
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) { s[j] = n[j]; o[j] = n[j]; }
+        for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
+        if (lane == 0) doff[t] = off;
       }
       if (ch + 1 < nchunks) chunk_store(buf ^ 1);
     }
@@ -186,33 +237,36 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     {
       float* o = dst + (long)(Tb - 1) * UP;
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) o[j] = s[j];
+      for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
+      if (lane == 0) doff[Tb - 1] = 0.0;
     }
     for (int ch = last; ch >= 0; --ch) {
       const int buf = ch & 1;
       if (ch > 0) chunk_load(ch - 1);
-      // frames t+1 in this chunk: t+1 in [max(1, ch*TC), min(Tb-1, ch*TC+TC-1)]
+      // frames f = t+1 of this chunk: f in [max(1, ch*TC), min(Tb-1, ch*TC+TC-1)]
       const int f_hi = min(Tb - 1, ch * TC + TC - 1), f_lo = max(1, ch * TC);
       for (int f = f_hi; f >= f_lo; --f) {
         const float* e = &E[buf][(f - ch * TC) * CP];
         float g[KPL];
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) g[j] = s[j] + e[cls[j]];
-        float dn1 = __shfl_down(g[0], 1, 64);
-        float dn2 = KPL >= 2 ? __shfl_down(g[KPL >= 2 ? 1 : 0], 1, 64) : __shfl_down(g[0], 2, 64);
-        if (lane == 63) { dn1 = NEG_INF; dn2 = NEG_INF; }
-        if (KPL == 1 && lane == 62) dn2 = NEG_INF;
+        for (int j = 0; j < KPL; ++j) g[j] = s[j] + e[coff[j]];
+        const float dn1 = from_lane_above(g[0]);
+        const float dn2 = KPL >= 2 ? from_lane_above(g[KPL >= 2 ? 1 : 0]) : from_lane_above(dn1);
         float n[KPL];
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
           const float p1 = j + 1 < KPL ? g[j + 1 < KPL ? j + 1 : 0] : dn1;
           const float p2 = j + 2 < KPL ? g[j + 2 < KPL ? j + 2 : 0] : (j + 2 == KPL ? dn1 : dn2);
-          const float v = lse3(g[j], p1, skip[j] ? p2 : NEG_INF);
+          const float v = lse3_b2(g[j], p1, skip[j] ? p2 : NEG_INF);
           n[j] = valid[j] ? v : NEG_INF;
         }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) s[j] = n[j];
+        if ((f & (NORM_EVERY - 1)) == 0) recentre(s, off);
         float* o = dst + (long)(f - 1) * UP;
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) { s[j] = n[j]; o[j] = n[j]; }
+        for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
+        if (lane == 0) doff[f - 1] = off;
       }
       if (ch > 0) chunk_store(buf ^ 1);
     }
@@ -222,7 +276,9 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 // grad[b,t,c] = scale * (y_t(c) - sum_{u: l'_u = c} exp(alpha_t(u) + beta_t(u) - log p))
 constexpr int GF = 16;   // frames per block (4 waves x 4)
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logy, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, int T, int C, int UP,
+                                                       const float* __restrict__ beta,
+                                                       const double* __restrict__ aoff,
+                                                       const double* __restrict__ boff, int T, int C, int KPL,
                                                        const int* __restrict__ label_ids,
                                                        const int* __restrict__ label_off,
                                                        const int* __restrict__ seq_lens,
@@ -233,6 +289,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   int* pos_off = smem;                 // [32]
   int* pos_list = smem + 32;           // [lmax]
   float* wbuf = reinterpret_cast<float*>(smem + 32 + lmax);   // [4][lmax]
+  const int UP = KPL * 64;
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int* lab = label_ids + label_off[b];
@@ -241,6 +298,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   const int Tb = seq_lens[b];
   const bool bad = status[b] != 0;
   const int blank = C - 1;
+  auto sidx = [&](int u) { return (u % KPL) * 64 + u / KPL; };     // lane-major state index
 
   if (wave == 0) {
     // per-class position lists in increasing position order (fixed summation order)
@@ -255,12 +313,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   }
   __syncthreads();
 
-  float logp = 0.f;
+  double logp2 = 0.0;   // log2 p(l|x)
   if (!bad) {
     const float* al = alpha + ((long)b * T + (Tb - 1)) * UP;
-    logp = lse2(al[U - 1], U > 1 ? al[U - 2] : NEG_INF);
+    logp2 = aoff[(long)b * T + Tb - 1] + (double)lse2_b2(al[sidx(U - 1)], U > 1 ? al[sidx(U - 2)] : NEG_INF);
   }
-  if (blockIdx.x == 0 && tid == 0) loss[b] = bad ? __builtin_inff() : -logp;
+  if (blockIdx.x == 0 && tid == 0) loss[b] = bad ? __builtin_inff() : (float)(-logp2 * (double)LN2);
 
   float* wb = wbuf + wave * lmax;
   for (int k = 0; k < GF / 4; ++k) {
@@ -270,8 +328,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     if (live) {
       const float* al = alpha + ((long)b * T + t) * UP;
       const float* be = beta + ((long)b * T + t) * UP;
+      const float shift = (float)(aoff[(long)b * T + t] + boff[(long)b * T + t] - logp2);
       for (int u = lane; u < U; u += 64) {
-        float w = __expf(al[u] + be[u] - logp);
+        const int i = sidx(u);
+        float w = ex2(al[i] + be[i] + shift);
         if (u & 1) wb[u >> 1] = w; else blank_sum += w;
       }
       blank_sum = st::wave_sum(blank_sum);
@@ -285,7 +345,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
           occ = 0.f;
           for (int i = pos_off[lane]; i < pos_off[lane + 1]; ++i) occ += wb[pos_list[i]];
         }
-        g = (__expf(logy[((long)b * T + t) * CP + lane]) - occ) * scale;
+        g = (ex2(logy[((long)b * T + t) * CP + lane]) - occ) * scale;
       }
       grad[gmap.off(b, t) + lane] = g;
     }
@@ -363,9 +423,9 @@ RowMap2 make_map2(const st_tensor3& t) {
 
 template <int KPL>
 void launch_ab(int B, hipStream_t s, const float* logy, int T, int C, const int* ids, const int* off,
-               const int* lens, float* alpha, float* beta, int* status) {
+               const int* lens, float* alpha, float* beta, double* aoff, double* boff, int* status) {
   hipLaunchKernelGGL((ctc_alpha_beta_kernel<KPL>), dim3(B, 2), dim3(64), 0, s, logy, T, C, ids, off, lens,
-                     alpha, beta, status);
+                     alpha, beta, aoff, boff, status);
 }
 
 }  // namespace
@@ -376,7 +436,7 @@ size_t st_ctc_ws(int batch, int frames, int max_label_len) {
   int kpl = pick_kpl(std::max(max_label_len, 0));
   if (kpl < 0 || batch <= 0 || frames <= 0) return 0;
   size_t rows = (size_t)batch * frames;
-  return rows * CP * sizeof(float) + 2 * rows * kpl * 64 * sizeof(float) + 512;
+  return rows * CP * sizeof(float) + 2 * rows * kpl * 64 * sizeof(float) + 2 * rows * sizeof(double) + 512;
 }
 
 int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, const int32_t* label_offsets,
@@ -398,18 +458,20 @@ int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, con
   float* logy = reinterpret_cast<float*>(workspace);
   float* alpha = logy + rows * CP;
   float* beta = alpha + rows * kpl * 64;
+  double* aoff = reinterpret_cast<double*>(beta + rows * kpl * 64);   // 8-byte aligned: all counts are even
+  double* boff = aoff + rows;
   hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, logits->base,
                      make_map2(*logits), B, T, C, logy);
   switch (kpl) {
-#define ST_AB(K) case K: launch_ab<K>(B, s, logy, T, C, label_ids, label_offsets, seq_lens, alpha, beta, status); break;
+#define ST_AB(K) case K: launch_ab<K>(B, s, logy, T, C, label_ids, label_offsets, seq_lens, alpha, beta, aoff, boff, status); break;
     ST_AB(1) ST_AB(2) ST_AB(3) ST_AB(4) ST_AB(5) ST_AB(6) ST_AB(8) ST_AB(10) ST_AB(12) ST_AB(16)
 #undef ST_AB
   }
   if (int e = st::check_launch("ctc_alpha_beta")) return e;
   const int lmax = std::max(1, kpl * 32);
   const size_t shm = (32 + (size_t)lmax * 5) * sizeof(int);
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3(st::ceil_div(T, GF), B), dim3(256), shm, s, logy, alpha, beta, T, C,
-                     kpl * 64, label_ids, label_offsets, seq_lens, status, grad_scale, grad->base, make_map2(*grad),
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3(st::ceil_div(T, GF), B), dim3(256), shm, s, logy, alpha, beta, aoff, boff,
+                     T, C, kpl, label_ids, label_offsets, seq_lens, status, grad_scale, grad->base, make_map2(*grad),
                      std::min(grad->c_pitch, CP), loss, lmax);
   return st::check_launch("ctc_grad");
 }

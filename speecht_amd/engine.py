@@ -172,7 +172,6 @@ class Wav2LetterEngine:
       self.dZ.append(DevTensor3(batch, t_out, l.cout, l.width - 1 - pl, pl, dev))
     last = self.layers[-1]
     self.X.append(DevTensor3(batch, geo[-1][1], last.cout, 0, 0, dev))     # logits [B, T', C]
-    assert self.X[-1].c_pitch >= 32 or last.cout > 32
     self.t_out = geo[-1][1]
     lib = _lib.load()
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))

@@ -14,6 +14,7 @@
 // A^T * dz reduced over all (b, t) rows, split over row ranges into slabs that a second
 // kernel sums (deterministic, no atomics).
 #include <algorithm>
+#include <cstdlib>
 
 #include "st_common.h"
 
@@ -46,28 +47,80 @@ struct NNParams {
   const float* bias;                 // EPI 0
   int M, Kvalid, Kp, n_store, relu;
   int tiles_m, tiles_n, chunk;       // XCD-aware tile order
+  int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
+};
+
+// ------------------------------------------------------------------------------------
+// "Interleaved-4" LDS image of a row-major [32 x COLS] stage whose ROWS are the reduction index:
+// element (r, c) lives at ((r>>2)*4 + (c&3)) * PITCH + (c>>2)*4 + (r&3), PITCH = COLS + 16.
+// A lane then fetches 4 consecutive reduction rows of its column with ONE ds_read_b128 (the four
+// k-steps of an MFMA quad), and both the transposing ds_write_b128 (lanes 16 B apart) and the
+// fragment ds_read_b128 (16 lanes -> 16 distinct 16-byte bank slots, PITCH = 16 mod 64 dwords)
+// are bank-conflict free.
+// ------------------------------------------------------------------------------------
+template <int COLS>
+struct Il4 {
+  static constexpr int PITCH = COLS + 16;
+  static constexpr int SIZE = 32 * PITCH;
+  static constexpr int BLOCKS = 8 * (COLS / 4);      // 4x4 blocks per stage
+  // write the 4x4 block (rows 4g..4g+3, cols 4cq..4cq+3) held as 4 row vectors
+  static __device__ __forceinline__ void store_block(float* base, int g, int cq, const f32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = {r[0][i], r[1][i], r[2][i], r[3][i]};
+      *reinterpret_cast<f32x4*>(base + (g * 4 + i) * PITCH + cq * 4) = v;
+    }
+  }
+  // float offset of the fragment base of a lane: column c0 + l31 (c0 % 4 == 0), row group h
+  static __device__ __forceinline__ int frag_base(int c0, int l31, int h) {
+    return (h * 4 + (l31 & 3)) * PITCH + (c0 / 4 + (l31 >> 2)) * 4;
+  }
+  static constexpr int Q_STRIDE = 8 * PITCH;          // next pair of row groups (8 reduction rows)
 };
 
 // ------------------------------------------------------------------------------------
 // C[M, n_store] = epilogue(A[M, Kp] * B[Kp, Np]).  256 threads = WMW x WNW waves, each wave
-// owns a (BM/WMW) x (BN/WNW) block of 32x32 MFMA tiles.  Register-staged double-buffered LDS,
-// one barrier per 32-deep k-tile; the global loads of tile k+1 are in flight under the 16
-// MFMA k-steps of tile k.
+// owns a (BM/WMW) x (BN/WNW) block of 32x32 MFMA tiles.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write instructions, and
+// the copy of k-tile kt+1 is in flight under all 64 MFMAs of tile kt (one barrier per tile, which
+// also drains the DMA).  DMA destinations are lane-linear, so the bank-conflict fix for the
+// im2col operand is an XOR swizzle applied on the SOURCE address: LDS row m, 16-byte slot p holds
+// source slot p ^ ((m>>1)&7); the fragment ds_read_b128 applies the same XOR.  The filter operand
+// stays linear [k][n]; a lane fetches NT adjacent columns with one read, so n-tile nt of a wave
+// covers columns {NT*lane + nt} -- the epilogue stores NT adjacent floats per lane.
+// All LDS lives in ONE array (a second __shared__ object makes hipcc drain the DMA queue before
+// every fragment read).
 // ------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> struct FVec;
+template <> struct FVec<1> { typedef float type; };
+template <> struct FVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct FVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int N> __device__ __forceinline__ float vget(const typename FVec<N>::type& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <int N> __device__ __forceinline__ void vset(typename FVec<N>::type& v, int i, float x) { v[i] = x; }
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
+
 template <int BM, int BN, int WMW, int WNW, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int AL = BM * BK / 4 / NTHREADS;
-  constexpr int BL = (BK * BN / 4 + NTHREADS - 1) / NTHREADS;
-  constexpr int BROW4 = BN / 4;  // float4 per B row
-  static_assert(WMW * WNW == 4 && MT >= 1 && NT >= 1 && AL >= 1, "tile config");
+  constexpr int A_DMA = BM / 32;            // DMA instructions per wave for the [BM][32] A stage
+  constexpr int B_DMA = BN / 32;            // ... for the [32][BN] B stage
+  constexpr int B_LPR = BN / 4;             // lanes per B row
+  constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
+  static_assert(WMW * WNW == 4 && MT >= 1 && (NT == 1 || NT == 2 || NT == 4) && A_DMA >= 1 && B_DMA >= 1, "tile config");
+  typedef typename FVec<NT>::type bvec;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * APITCH];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-  __shared__ long a_off[BM];
-  __shared__ long c_off[BM];
-  __shared__ long m_off[BM];
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ + 6 * BM];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_SZ;
+  long* const a_off = reinterpret_cast<long*>(smem + 2 * A_SZ + 2 * B_SZ);
+  long* const c_off = a_off + BM;
+  long* const m_off = c_off + BM;
 
   // XCD-aware order: block b runs on XCD b%8; give each XCD one contiguous chunk of the
   // panel-major tile list so the CUs sharing an L2 stream the same filter panel together.
@@ -79,7 +132,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WNW, wn = wave % WNW;
 
@@ -93,18 +147,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   }
   __syncthreads();
 
-  const float* arow[AL];
+  // DMA sources.  A: instruction i of this wave covers rows (wave*A_DMA + i)*8 .. +8, lane -> (row,
+  // physical slot); B: instruction i covers 64/B_LPR rows of k.
+  const float* asrc[A_DMA];
+  int aslot4[A_DMA];
 #pragma unroll
-  for (int i = 0; i < AL; ++i) arow[i] = p.A + a_off[(tid >> 3) + 32 * i] + (tid & 7) * 4;
-  const float* bptr[BL];
-  bool bact[BL];
-#pragma unroll
-  for (int i = 0; i < BL; ++i) {
-    int f = tid + NTHREADS * i;
-    bact[i] = f < BK * BROW4;
-    int k = bact[i] ? f / BROW4 : 0, nq = f % BROW4;
-    bptr[i] = p.Bm + (long)k * p.Np + n0 + nq * 4;
+  for (int i = 0; i < A_DMA; ++i) {
+    const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
+    asrc[i] = p.A + a_off[row];
+    aslot4[i] = (((lane & 7) ^ ((row >> 1) & 7))) * 4;
   }
+  const float* bsrc[B_DMA];
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i) {
+    const int krow = (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR;
+    bsrc[i] = p.Bm + (long)krow * p.Np + n0 + (lane % B_LPR) * 4;
+  }
+  const int ktail = p.Kvalid - 4;   // last float4 inside the valid reduction range
+  const long bstep = (long)BK * p.Np;
+
+  auto dma = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+      // reduction tail (Kvalid % 32 == 16): clamp so the read stays inside the row span; the
+      // matching rows of the packed filter operand are zero, so the values do not matter.
+      const float* g = asrc[i] + min(k0 + aslot4[i], ktail);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + i) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + kt * bstep),
+                                       (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
+    }
+  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -114,87 +190,82 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[AL], rb[BL];
+  // fragment addresses: A row = wm*WTM + mt*32 + l31, logical slot 2q+h, XOR-swizzled
+  int a_frag[4];
+  {
+    const int row = wm * WTM + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
+  const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
+
   const int nk = p.Kp / BK;
-  const int kq4 = (tid & 7) * 4;
-
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const bool kin = k0 + kq4 < p.Kvalid;   // Kvalid is a multiple of 16: whole float4 in or out
-#pragma unroll
-    for (int i = 0; i < AL; ++i)
-      ra[i] = kin ? *reinterpret_cast<const f32x4*>(arow[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < BL; ++i)
-      if (bact[i]) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + (long)k0 * p.Np);
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AL; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf][((tid >> 3) + 32 * i) * APITCH + kq4]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      int f = tid + NTHREADS * i;
-      if (bact[i]) *reinterpret_cast<f32x4*>(&Bs[buf][f * 4]) = rb[i];
-    }
-  };
-
-  gload(0);
-  sstore(0);
+  dma(0, 0);
   __syncthreads();
 
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) gload(kt + 1);
-    const float* as = &As[cur][(wm * WTM + l31) * APITCH + 4 * h];
-    const float* bs = &Bs[cur][(4 * h) * BN + wn * WTN + l31];
+    if (kt + 1 < nk && !(p.debug & 1)) dma(kt + 1, cur ^ 1);
+    const float* as = As + cur * A_SZ;
+    const float* bs = Bs + cur * B_SZ + b_frag;
+    // Software-pipelined fragment reads: the reads of k-quad q+1 are issued BEFORE the 16 MFMAs of
+    // quad q (sched_barrier pins the order; hipcc otherwise sinks the reads behind the MFMAs to
+    // save registers and then stalls on LDS latency four times per tile).
+    f32x4 af[4][MT];
+    bvec bf[4][4];
+    auto read_frags = [&](int q) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + a_frag[q] + i * 32 * BK);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+    };
+    read_frags(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 a[MT];
+      if (q < 3) read_frags(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * APITCH + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float b[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = bs[(8 * q + j) * BN + n * 32];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
-      }
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) sstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (!(p.debug & 4)) __syncthreads();     // also drains this wave's DMA (vmcnt) before anyone reads it
+    if (!(p.debug & 1)) cur ^= 1;
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: C/D layout of 32x32 MFMA: tile column = lane&31 (-> output column NT*l31 + nt),
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5); every lane stores NT adjacent floats per row.
+  const int col0 = n0 + wn * WTN + NT * l31;
+  const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
+  bvec bv;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n0 + wn * WTN + n * 32 + l31;
-    const bool col_ok = col < p.n_store;
-    float bv = 0.f;
-    if (EPI == 0 && p.bias && col_ok) bv = p.bias[col];
+  for (int n = 0; n < NT; ++n) vset<NT>(bv, n, (EPI == 0 && p.bias && col_ok) ? p.bias[col0 + n] : 0.f);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long co = c_off[row];
-        if (co >= 0 && col_ok) {
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const long co = c_off[row];
+      if (co >= 0 && col_ok) {
+        bvec out, mk;
+        if (EPI == 1 && p.mask) mk = *reinterpret_cast<const bvec*>(p.mask + m_off[row] + col0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
           float v = acc[i][n][r];
           if (EPI == 0) {
-            v += bv;
+            v += vget<NT>(bv, n);
             if (p.relu) v = fmaxf(v, 0.f);
           } else if (p.mask) {
-            v = p.mask[m_off[row] + col] > 0.f ? v : 0.f;
+            v = vget<NT>(mk, n) > 0.f ? v : 0.f;
           }
-          p.C[co + col] = v;
+          vset<NT>(out, n, v);
         }
+        *reinterpret_cast<bvec*>(p.C + co + col0) = out;
       }
     }
   }
@@ -202,9 +273,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 
 // ------------------------------------------------------------------------------------
 // Filter gradient: out[split][k][n] = sum over the split's rows m of A[m][k] * Z[m][n].
-// Both operands are reduction-major in memory (k resp. n contiguous within a row), which is
-// exactly what the MFMA operand fetch wants: lane i reads element i of LDS row m -- bank
-// conflict free with no padding.  Tile 128(k) x BN(n), 32 rows of m per stage.
+// Both operands are reduction-major in memory (a row of A / Z is one value of the reduction
+// index m), so both use the interleaved-4 LDS image.  Tile 128(k) x BN(n), 32 rows of m per
+// stage, the row range of a split walked incrementally (no per-row division).
 // ------------------------------------------------------------------------------------
 struct TNParams {
   const float* A; RowMap amap;
@@ -213,6 +284,8 @@ struct TNParams {
   int M, Kvalid, Kp, Np, z_cols;   // z_cols = readable floats per Z row (its c_pitch)
   int rows_per_split;    // multiple of 32
   int tiles_k, tiles_n;
+  int amap_batches;      // utterances (rows never advance past the last one)
+  int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
 };
 
 template <int BN, int WKW, int WNW>
@@ -221,12 +294,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNParams p) {
   constexpr int BMR = 32;
   constexpr int WTK = BKO / WKW, WTN = BN / WNW;   // wave tile
   constexpr int MT = WTK / 32, NT = WTN / 32;
-  constexpr int ZL = BMR * BN / 4 / NTHREADS;
-  constexpr int ZROW4 = BN / 4;
-  static_assert(WKW * WNW == 4 && MT >= 1 && NT >= 1 && ZL >= 1, "tile config");
+  using AL = Il4<BKO>;
+  using ZL = Il4<BN>;
+  constexpr bool Z_ALL = ZL::BLOCKS >= NTHREADS;
+  static_assert(WKW * WNW == 4 && MT >= 1 && NT >= 1 && AL::BLOCKS == NTHREADS && ZL::BLOCKS <= NTHREADS, "tile config");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BMR * BKO];
-  __shared__ __attribute__((aligned(16))) float Zs[2][BMR * BN];
+  __shared__ __attribute__((aligned(16))) float As[2][AL::SIZE];
+  __shared__ __attribute__((aligned(16))) float Zs[2][ZL::SIZE];
 
   const int tile = blockIdx.x;
   const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
@@ -248,35 +322,75 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // thread -> (row, float4 column) of the A stage [32][128] and the Z stage [32][BN]
-  const int ar = tid >> 5, ac4 = (tid & 31) * 4;       // rows ar + 8*i, i < 4
-  const bool a_col_ok = k0 + ac4 < p.Kvalid;
-  f32x4 ra[4], rz[ZL];
+  // staging: thread -> 4x4 block: reduction rows 4g..4g+3 of the stage, columns 4cq..4cq+3
+  const int ag = tid >> 5, acq = tid & 31;
+  const bool a_col_ok = k0 + 4 * acq < p.Kvalid;
+  const bool z_act = Z_ALL || tid < ZL::BLOCKS;
+  const int zg = z_act ? tid / (BN / 4) : 0, zcq = tid % (BN / 4);
+  const bool z_col_ok = z_act && n0 + 4 * zcq < p.z_cols;
+  // (b, t) of this thread's first A row and first Z row, advanced by 32 rows per stage
+  int ab = 0, at = 0, zb = 0, zt = 0;
+  if (m_begin < p.M) {
+    int m = min(m_begin + 4 * ag, p.M - 1);
+    ab = m / p.amap.frames; at = m - ab * p.amap.frames;
+    m = min(m_begin + 4 * zg, p.M - 1);
+    zb = m / p.zmap.frames; zt = m - zb * p.zmap.frames;
+  }
+  f32x4 ra[4], rz[4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  // Loads never branch and never wait: addresses are clamped to valid rows/columns and the
+  // zeroing of out-of-range rows (split tail) / columns happens on the registers at store time.
+  const int acol = a_col_ok ? k0 + 4 * acq : 0;
+  const int zcol = z_col_ok ? n0 + 4 * zcq : 0;
+  int a_rows = 0, z_rows = 0;      // valid rows (0..4) of the block held in ra / rz
+  // walk 4 consecutive (b, t) rows starting at (b, t): branch-free wrap into the next utterance
+  auto row_ptrs = [&](const float* base, const RowMap& map, int b, int t, int m_first, int col,
+                      const float* (&ptr)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ptr[r] = base + (long)b * map.batch_stride + map.row0 + (long)t * map.row_stride + col;
+      const bool adv = m_first + r + 1 < p.M;          // never step past the last row of the tensor
+      const int t1 = t + (adv ? 1 : 0);
+      const bool wrap = t1 >= map.frames;
+      t = wrap ? 0 : t1;
+      b += wrap ? 1 : 0;
+    }
+  };
+  auto advance = [&](int& b, int& t, const RowMap& map) {   // += 32 rows, clamped to the last row
+    t += p.adv_t;
+    b += p.adv_b;
+    const bool wrap = t >= map.frames;
+    t -= wrap ? map.frames : 0;
+    b += wrap ? 1 : 0;
+    const bool past = b >= p.amap_batches;
+    b = past ? p.amap_batches - 1 : b;
+    t = past ? map.frames - 1 : t;
+  };
   auto gload = [&](int mb) {
+    const float* pa[4];
+    const float* pz[4];
+    row_ptrs(p.A, p.amap, ab, at, mb + 4 * ag, acol, pa);
+    if (z_act) row_ptrs(p.Z, p.zmap, zb, zt, mb + 4 * zg, zcol, pz);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = mb + ar + 8 * i;
-      ra[i] = (m < m_end && a_col_ok)
-                  ? *reinterpret_cast<const f32x4*>(p.A + p.amap.off(m) + k0 + ac4)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int r = 0; r < 4; ++r) ra[r] = *reinterpret_cast<const f32x4*>(pa[r]);
+    if (z_act) {
 #pragma unroll
-    for (int i = 0; i < ZL; ++i) {
-      int f = tid + NTHREADS * i;
-      int r = f / ZROW4, c4 = (f % ZROW4) * 4;
-      int m = mb + r;
-      rz[i] = (m < m_end && n0 + c4 < p.z_cols)
-                  ? *reinterpret_cast<const f32x4*>(p.Z + p.zmap.off(m) + n0 + c4)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) rz[r] = *reinterpret_cast<const f32x4*>(pz[r]);
     }
+    a_rows = a_col_ok ? max(0, min(4, m_end - (mb + 4 * ag))) : 0;
+    z_rows = z_col_ok ? max(0, min(4, m_end - (mb + 4 * zg))) : 0;
+    advance(ab, at, p.amap);
+    advance(zb, zt, p.zmap);
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf][(ar + 8 * i) * BKO + ac4]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < ZL; ++i) *reinterpret_cast<f32x4*>(&Zs[buf][(tid + NTHREADS * i) * 4]) = rz[i];
+    for (int r = 0; r < 4; ++r) {
+      if (r >= a_rows) ra[r] = zero4;
+      if (r >= z_rows) rz[r] = zero4;
+    }
+    AL::store_block(&As[buf][0], ag, acq, ra);
+    if (z_act) ZL::store_block(&Zs[buf][0], zg, zcq, rz);
   };
 
   if (m_begin < m_end) {
@@ -284,26 +398,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNParams p) {
     sstore(0);
   }
   __syncthreads();
+  const int a_frag = AL::frag_base(wk * WTK, l31, h);
+  const int z_frag = ZL::frag_base(wn * WTN, l31, h);
   int cur = 0;
   for (int mb = m_begin; mb < m_end; mb += BMR) {
     const bool more = mb + BMR < m_end;
     if (more) gload(mb + BMR);
-    const float* as = &As[cur][h * BKO + wk * WTK + l31];
-    const float* zs = &Zs[cur][h * BN + wn * WTN + l31];
+    const float* as = &As[cur][a_frag];
+    const float* zs = &Zs[cur][z_frag];
+    f32x4 af[4][MT], zf[4][NT];
 #pragma unroll
-    for (int s = 0; s < BMR / 2; ++s) {
-      float a[MT], z[NT];
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = as[(2 * s) * BKO + i * 32];
+      for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + q * AL::Q_STRIDE + i * 32);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) z[n] = zs[(2 * s) * BN + n * 32];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], z[n], acc[i][n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) zf[q][n] = *reinterpret_cast<const f32x4*>(zs + q * ZL::Q_STRIDE + n * 32);
     }
-    if (more) sstore(cur ^ 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == 2 && more) sstore(cur ^ 1);     // mid-stream staging store (see gemm_nn_kernel)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], zf[q][n][j], acc[i][n], 0, 0, 0);
+    }
     __syncthreads();
     cur ^= 1;
   }
@@ -418,15 +539,20 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.tiles_n = p.Np / BN;
   const int total = p.tiles_m * p.tiles_n;
   p.chunk = st::ceil_div(total, 8);
+  if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
   dim3 grid(p.chunk * 8), block(NTHREADS);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1>), grid, block, 0, s, p);
 }
 
 int run_nn(NNParams& p, int epi, hipStream_t s) {
+  static const int force = getenv("ST_GEMM_TILE") ? atoi(getenv("ST_GEMM_TILE")) : 0;   // perf experiments
   if (p.Np % 128 == 0) {
     long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128);
-    if (tiles128 >= 512) launch_nn<128, 128, 2, 2>(p, epi, s);
+    if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
+    else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
+    else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
+    else if (tiles128 >= 512) launch_nn<128, 128, 2, 2>(p, epi, s);
     else launch_nn<64, 128, 2, 2>(p, epi, s);
   } else if (p.Np == 64) {
     launch_nn<128, 64, 2, 2>(p, epi, s);
@@ -597,6 +723,9 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   float* slabs = reinterpret_cast<float*>(workspace);
   p.out = used > 1 ? slabs : dpacked;
   p.tiles_k = st::ceil_div(p.Kp, 128);
+  p.amap_batches = dz->batch;
+  p.adv_b = 32 / dz->frames;
+  p.adv_t = 32 % dz->frames;
   if (p.Np % 128 == 0) {
     p.tiles_n = p.Np / 128;
     hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(NTHREADS), 0, s, p);

@@ -163,3 +163,54 @@ class SpeechCorpusReader:
       if not loop_infinitely:
         break
       random.shuffle(files)
+
+
+def load_audio(path):
+  """Decode an audio file to (float32 mono samples in [-1, 1], samplerate).
+
+  Bundled decoders: 16-bit PCM ``.wav`` (stdlib ``wave``) and raw ``.npy`` arrays (assumed 16 kHz).
+  FLAC decoding and librosa's implicit 22 050 Hz ``kaiser_best`` resampling (preprocessing.py:169)
+  are real-audio ingest, outside the hot path: convert LibriSpeech to wav first.
+  """
+  ext = os.path.splitext(path)[1].lower()
+  if ext == '.npy':
+    return np.load(path).astype(np.float32), 16000
+  if ext == '.wav':
+    import wave
+    with wave.open(path, 'rb') as w:
+      if w.getsampwidth() != 2:
+        raise ValueError('{}: only 16-bit PCM wav is supported'.format(path))
+      data = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
+      if w.getnchannels() > 1:
+        data = data.reshape(-1, w.getnchannels()).mean(axis=1)
+      return data, w.getframerate()
+  raise RuntimeError('{}: no decoder bundled for {} files'.format(path, ext or 'extension-less'))
+
+
+class Preprocessing:
+  """`speecht-cli preprocess` (preprocessing.py:282-311).  Corpus download (corpus.py) is network
+  I/O and out of scope: the audio must already be under <data_dir>/{train,test,dev}."""
+
+  AUDIO_PATTERNS = ('*.wav', '*.npy')
+
+  def __init__(self, flags):
+    self.flags = flags
+
+  def run(self):
+    corpus_reader = SpeechCorpusReader(self.flags.data_dir)
+    if self.flags.feature_type == 'power':
+      preprocess_fnc = calc_power_spectrogram
+    elif self.flags.feature_type == 'mfcc':
+      raise NotImplementedError('MFCC features (preprocessing.py:61-84) are not on the accelerated path; use --power')
+    else:
+      raise ValueError('Feature type must be mfcc or power.')
+    preprocess_all = not (self.flags.train_only or self.flags.test_only or self.flags.dev_only)
+    for split, only, title in (('train', self.flags.train_only, 'training'), ('test', self.flags.test_only, 'test'),
+                               ('dev', self.flags.dev_only, 'development')):
+      if only or preprocess_all:
+        if not os.path.isdir(os.path.join(self.flags.data_dir, split)):
+          print('Skipping {} data: {}/{} does not exist'.format(title, self.flags.data_dir, split))
+          continue
+        print('Preprocessing {} data'.format(title))
+        for pattern in self.AUDIO_PATTERNS:
+          corpus_reader.store_samples(split, preprocess_fnc, audio_loader=load_audio, pattern=pattern)

@@ -1,0 +1,187 @@
+"""Batch assembly and the input pipeline (mirror of speecht/speech_input.py).
+
+The reference builds TF placeholders + a FIFOQueue(capacity=100) fed by Python threads
+(speech_input.py:130-218).  Here the queue is a plain ``queue.Queue`` of host batches; the padded
+batch layout and the sparse label layout -- the data formats either side of the hot path -- are kept
+exactly (speech_input.py:27-69): inputs zero-padded to [B, max_T, input_size], sequence_lengths =
+unpadded frame counts, labels as (indices [N,2], values [N], dense_shape [B, max_T]).
+"""
+import collections
+import queue
+import threading
+
+import numpy as np
+
+SparseTensorValue = collections.namedtuple('SparseTensorValue', ['indices', 'values', 'dense_shape'])
+
+
+class OutOfRangeError(Exception):
+  """End-of-data signal, the role tf.errors.OutOfRangeError plays in training.py:92 / evaluation.py:109."""
+
+
+class Coordinator:
+  """The subset of tf.train.Coordinator the executors use (execution.py:54-58)."""
+
+  def __init__(self):
+    self._stop = threading.Event()
+    self._threads = []
+
+  def should_stop(self):
+    return self._stop.is_set()
+
+  def request_stop(self):
+    self._stop.set()
+
+  def register_thread(self, thread):
+    self._threads.append(thread)
+
+  def join(self, timeout=5.0):
+    for t in self._threads:
+      t.join(timeout)
+
+
+class Placeholder:
+  """Names an input slot; ``get_inputs()`` returns these, values arrive through ``dequeue()``/feed."""
+
+  def __init__(self, name):
+    self.name = name
+
+  def __repr__(self):
+    return '<Placeholder {}>'.format(self.name)
+
+
+class BaseInputLoader:
+
+  def __init__(self, input_size):
+    self.input_size = input_size
+
+  def _get_inputs_feed_item(self, input_list):
+    """list of [time, input_size] arrays -> (input_tensor [B, max_T, C], sequence_lengths, max_time)."""
+    sequence_lengths = np.fromiter((item.shape[0] for item in input_list), dtype=np.int64, count=len(input_list))
+    max_time = int(sequence_lengths.max())
+    input_tensor = np.zeros((len(input_list), max_time, self.input_size), dtype=np.float32)
+    for row, item in zip(input_tensor, input_list):
+      row[:item.shape[0]] = item
+    return input_tensor, sequence_lengths, max_time
+
+  @staticmethod
+  def _get_labels_feed_item(label_list, max_time):
+    """list of id sequences -> SparseTensorValue with dense_shape [B, max_time] (the reference
+    uses the INPUT max_time here, speech_input.py:58)."""
+    counts = [len(label) for label in label_list]
+    total = sum(counts)
+    indices = np.empty((total, 2), dtype=np.int64)
+    indices[:, 0] = np.repeat(np.arange(len(label_list)), counts)
+    indices[:, 1] = np.concatenate([np.arange(c) for c in counts]) if total else np.empty(0, np.int64)
+    values = np.fromiter((v for label in label_list for v in label), dtype=np.int64, count=total)
+    return SparseTensorValue(indices, values, np.array([len(label_list), max_time], dtype=np.int64))
+
+  def get_inputs(self):
+    raise NotImplementedError()
+
+  def get_feed_dict(self):
+    return None
+
+  def dequeue(self):
+    """Next (inputs, sequence_lengths, labels|None) for one model step."""
+    raise NotImplementedError()
+
+
+def sparse_to_label_lists(labels):
+  """SparseTensorValue -> list of per-utterance id lists (row-major indices)."""
+  out = [[] for _ in range(int(labels.dense_shape[0]))]
+  for (b, _), v in zip(labels.indices, labels.values):
+    out[int(b)].append(int(v))
+  return out
+
+
+class SingleInputLoader(BaseInputLoader):
+  """Feeds one utterance per step (speech_input.py:79-127), used for live / ad-hoc inference."""
+
+  def __init__(self, input_size):
+    super().__init__(input_size)
+    self.speech_input = None
+    self.inputs = Placeholder('inputs')
+    self.sequence_lengths = Placeholder('sequence_lengths')
+
+  def get_inputs(self):
+    return self.inputs, self.sequence_lengths, None
+
+  def get_feed_dict(self):
+    if self.speech_input is None:
+      raise ValueError('Speech input must be provided using `set_input` first!')
+    input_tensor, sequence_lengths, _ = self._get_inputs_feed_item([self.speech_input])
+    self.speech_input = None
+    return {self.inputs: input_tensor, self.sequence_lengths: sequence_lengths}
+
+  def set_input(self, speech_input):
+    self.speech_input = speech_input
+
+  def dequeue(self):
+    feed = self.get_feed_dict()
+    return feed[self.inputs], feed[self.sequence_lengths], None
+
+
+class InputBatchLoader(BaseInputLoader):
+  """Background threads assemble padded batches into a bounded queue (capacity 100 like the
+  reference's FIFOQueue); the final partial batch is dropped (``zip(*[iter]*B)``,
+  speech_input.py:169-179) and ``max_steps`` caps the batches produced."""
+
+  CAPACITY = 100
+
+  def __init__(self, input_size, batch_size, data_generator_creator, max_steps=None):
+    super().__init__(input_size)
+    self.batch_size = batch_size
+    self.data_generator_creator = data_generator_creator
+    self.steps_left = max_steps
+    self.inputs = Placeholder('inputs')
+    self.sequence_lengths = Placeholder('sequence_lengths')
+    self.labels = Placeholder('labels')
+    self._queue = queue.Queue(maxsize=self.CAPACITY)
+    self._closed = threading.Event()
+    self._lock = threading.Lock()
+
+  def get_inputs(self):
+    return self.inputs, self.sequence_lengths, self.labels
+
+  def _batch(self, iterable):
+    return zip(*([iter(iterable)] * self.batch_size))
+
+  def _enqueue(self, sess, coord):
+    try:
+      for sample_batch in self._batch(self.data_generator_creator()):
+        input_list, label_list = zip(*sample_batch)
+        input_tensor, sequence_lengths, max_time = self._get_inputs_feed_item(input_list)
+        item = (input_tensor, sequence_lengths, self._get_labels_feed_item(label_list, max_time))
+        while not (self._closed.is_set() or coord.should_stop()):
+          try:
+            self._queue.put(item, timeout=0.1)
+            break
+          except queue.Full:
+            continue
+        with self._lock:
+          if self.steps_left is not None:
+            self.steps_left -= 1
+            if self.steps_left == 0:
+              break
+        if coord.should_stop() or self._closed.is_set():
+          break
+    finally:
+      self._closed.set()      # like sess.run(queue.close()): the first finished feeder closes the queue
+
+  def start_threads(self, sess, coord, n_threads=1):
+    threads = []
+    for _ in range(n_threads):
+      t = threading.Thread(target=self._enqueue, args=(sess, coord), daemon=True)
+      t.start()
+      coord.register_thread(t)
+      threads.append(t)
+    return threads
+
+  def dequeue(self):
+    while True:
+      try:
+        return self._queue.get(timeout=0.05)
+      except queue.Empty:
+        if self._closed.is_set() and self._queue.empty():
+          raise OutOfRangeError('input queue is closed and has insufficient elements')

@@ -1,0 +1,322 @@
+"""Wav2Letter acoustic model with the reference's Python surface (mirror of speecht/speech_model.py).
+
+``SpeechModel`` keeps the call protocol of the TF1 graph class -- ``add_training_ops``,
+``add_decoding_ops``, ``finalize``, ``init_session``, ``step`` (same fetch order), ``restore`` /
+``restore_or_create``, ``global_step`` / ``learning_rate`` handles with ``.eval()``, ``saver.save`` --
+but nothing is traced or compiled: ``_create_network`` records the layer list and ``step`` runs the
+hand-written HIP kernels through ``engine.Wav2LetterEngine``.  ``sess`` is an opaque ``Session``
+(device + stream) instead of a tf.Session.
+"""
+import json
+import math
+import os
+import time
+
+import numpy as np
+
+from . import vocabulary
+from .speech_input import BaseInputLoader, SparseTensorValue, sparse_to_label_lists
+
+
+class Session:
+  """Execution context handed to ``step`` (the reference passes a tf.Session, training.py:46)."""
+
+  def __init__(self, device='cuda:0'):
+    self.device = device
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    return False
+
+  def run(self, op, feed_dict=None):
+    """Runs host-side ops such as ``learning_rate_decay_op`` (training.py:84)."""
+    if isinstance(op, (list, tuple)):
+      return [self.run(o) for o in op]
+    return op()
+
+
+class _Scalar:
+  """A host-side variable with the ``.eval()`` / ``.assign()`` protocol callers use."""
+
+  def __init__(self, value, dtype=float):
+    self._dtype = dtype
+    self.value = dtype(value)
+
+  def eval(self, session=None):
+    return self.value
+
+  def assign(self, value):
+    def op():
+      self.value = self._dtype(value() if callable(value) else value)
+      return self.value
+    return op
+
+
+class _SummaryWriter:
+  """TensorBoard diagnostics (tf.summary.*, speech_model.py:50-51,158-170) are out of scope; scalar
+  summaries are appended as JSON lines to <log_dir>/<run_name>_<run_type>/scalars.jsonl."""
+
+  def __init__(self, directory):
+    self.directory = directory
+
+  def add_graph(self, graph=None):
+    pass
+
+  def add_summary(self, summary, global_step=None):
+    if not summary:
+      return
+    os.makedirs(self.directory, exist_ok=True)
+    with open(os.path.join(self.directory, 'scalars.jsonl'), 'a') as f:
+      f.write(json.dumps(dict(summary, step=int(global_step) if global_step is not None else None)) + '\n')
+
+
+class _Saver:
+  """Checkpoints: ``<path>-<global_step>.npz`` + a ``checkpoint`` index file naming the latest,
+  holding what tf.train.Saver(tf.global_variables()) holds (speech_model.py:122): weights, Adam
+  m/v, global_step, learning_rate."""
+
+  def __init__(self, model):
+    self.model = model
+
+  def save(self, sess, save_path, global_step=None):
+    step = global_step.eval() if hasattr(global_step, 'eval') else global_step
+    path = '{}-{}'.format(save_path, step) if step is not None else save_path
+    eng = self.model.engine
+    np.savez(path + '.npz', params=eng.params.cpu().numpy(), adam_m=eng.adam_m.cpu().numpy(),
+             adam_v=eng.adam_v.cpu().numpy(), global_step=self.model.global_step.eval(),
+             learning_rate=self.model.learning_rate.eval() if hasattr(self.model, 'learning_rate') else 0.0,
+             layers=np.array([(l.width, l.stride, l.cin, l.cout, int(l.relu)) for l in eng.layers]))
+    with open(os.path.join(os.path.dirname(path) or '.', 'checkpoint'), 'w') as f:
+      json.dump({'model_checkpoint_path': path + '.npz'}, f)
+    return path
+
+  def restore(self, sess, path):
+    import torch
+    eng = self.model.engine
+    with np.load(path) as ck:
+      if ck['params'].shape[0] != eng.n_flat:
+        raise ValueError('checkpoint {} does not match the model layout'.format(path))
+      dev = eng.device
+      eng.params.copy_(torch.as_tensor(ck['params']).to(dev))
+      eng.adam_m.copy_(torch.as_tensor(ck['adam_m']).to(dev))
+      eng.adam_v.copy_(torch.as_tensor(ck['adam_v']).to(dev))
+      eng.step_count = int(ck['global_step'])
+      eng._packed_t_fresh = False
+      self.model.global_step.value = int(ck['global_step'])
+      if hasattr(self.model, 'learning_rate'):
+        self.model.learning_rate.value = float(ck['learning_rate'])
+
+
+def latest_checkpoint(checkpoint_directory):
+  index = os.path.join(checkpoint_directory, 'checkpoint')
+  if not os.path.exists(index):
+    return None
+  path = json.load(open(index)).get('model_checkpoint_path')
+  return path if path and os.path.exists(path) else None
+
+
+class SpeechModel:
+
+  def __init__(self, input_loader: BaseInputLoader, input_size: int, num_classes: int):
+    """input_loader provides the batches, input_size = values per time step, num_classes =
+    vocabulary size + 1 for the CTC blank (speech_model.py:29-51)."""
+    self.input_loader = input_loader
+    self.input_size = input_size
+    self.num_classes = num_classes
+    self.convolution_count = 0
+    self._layer_specs = []
+    self.global_step = _Scalar(0, int)
+    self.inputs, self.sequence_lengths, self.labels = input_loader.get_inputs()
+    self.logits = self._create_network(num_classes)
+    self.engine = None
+    self._training = False
+    self._decoding = False
+    self._reducer = None
+    self._world = 1
+
+  # ---- graph-building protocol ---------------------------------------------------------------
+  def _convolution(self, value, filter_width, stride, input_channels, out_channels, apply_non_linearity=True):
+    """Registers conv1d(SAME) + bias (+ ReLU) as layer ``convolution_layer_<id>`` (speech_model.py:128-181);
+    returns (symbolic output, out_channels) like the reference."""
+    layer_id = self.convolution_count
+    self.convolution_count += 1
+    self._layer_specs.append((filter_width, stride, input_channels, out_channels, bool(apply_non_linearity)))
+    return ('convolution_layer_{}'.format(layer_id), out_channels), out_channels
+
+  def _create_network(self, num_classes):
+    raise NotImplementedError()
+
+  def add_training_ops(self, learning_rate=1e-3, learning_rate_decay_factor=0, max_gradient_norm=5.0, momentum=0.9):
+    """CTC loss -> mean -> clip_by_global_norm -> Adam(epsilon=1e-3) (speech_model.py:53-82).
+    ``momentum`` is accepted and unused, exactly as in the reference."""
+    self.learning_rate = _Scalar(learning_rate, float)
+    self.learning_rate_decay_op = self.learning_rate.assign(
+        lambda: self.learning_rate.value * learning_rate_decay_factor)
+    self.max_gradient_norm = max_gradient_norm
+    self._training = self.labels is not None
+
+  def add_decoding_ops(self, language_model=None, lm_weight=0.8, word_count_weight=0.0, valid_word_count_weight=2.3):
+    """Greedy CTC decoding (speech_model.py:112-115).  The LM beam search needs the reference's
+    custom tensorflow-with-kenlm fork (speech_model.py:101-111) and is not part of this path."""
+    if language_model:
+      raise NotImplementedError('KenLM beam-search decoding depends on a TensorFlow fork that is not vendored')
+    self.lm_weight, self.word_count_weight = lm_weight, word_count_weight
+    self.valid_word_count_weight = valid_word_count_weight
+    self._decoding = True
+
+  def finalize(self, log_dir: str, run_name: str, run_type: str):
+    self.saver = _Saver(self)
+    self.summary_writer = _SummaryWriter('{}/{}_{}'.format(log_dir, run_name, run_type))
+
+  # ---- session protocol ------------------------------------------------------------------------
+  def _ensure_engine(self, sess):
+    if self.engine is None:
+      from .engine import Wav2LetterEngine
+      self.engine = Wav2LetterEngine(self._layer_specs, device=sess.device)
+    return self.engine
+
+  def init_session(self, sess, init_variables=True):
+    eng = self._ensure_engine(sess)
+    if init_variables:
+      eng.init_xavier()        # xavier_initializer filters, zero biases (speech_model.py:150-152)
+      eng.adam_m.zero_(); eng.adam_v.zero_()
+      eng.step_count = 0
+      self.global_step.value = 0
+    self.summary_writer.add_graph(None)
+
+  def enable_data_parallel(self, group=None):
+    """Shard-by-utterance data parallelism: see data_parallel.py.  Call after init_session."""
+    import torch.distributed as dist
+    from .data_parallel import GradientAllReducer
+    self._world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self._reducer = GradientAllReducer(self.engine.grads, self.engine.layer_ranges, group) if self._world > 1 else None
+
+  def step(self, sess, loss=True, update=True, decode=False, return_label=False, summary=False, feed_dict=None):
+    """One evaluation of the path.  Returns, in this order and only when requested:
+    avg_loss, decoded, label, update (None), summary  (speech_model.py:197-235)."""
+    eng = self._ensure_engine(sess)
+    inputs, seq_lens, labels = self.input_loader.dequeue()
+    if feed_dict:
+      inputs = feed_dict.get(self.inputs, inputs)
+      seq_lens = feed_dict.get(self.sequence_lengths, seq_lens)
+      labels = feed_dict.get(self.labels, labels) if self.labels is not None else labels
+    if (loss or update) and labels is None:
+      raise ValueError('loss/update requested but the input loader provides no labels')
+    eng.load_batch(inputs, seq_lens)
+    eng.forward()
+    out = []
+    avg_loss = None
+    if loss or update:
+      eng.set_labels(sparse_to_label_lists(labels))
+      # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
+      eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
+      if update:
+        if not self._training:
+          raise RuntimeError('add_training_ops() was not called with labelled inputs')
+        eng.backward(self._reducer.on_layer_done if self._reducer else None)
+        if self._reducer:
+          self._reducer.finish()
+        eng.apply_update(self.learning_rate.value, self.max_gradient_norm)
+        self.global_step.value += 1
+      eng.check_ctc_status()
+      avg_loss = np.float32(eng.loss.mean().item())
+      if self._world > 1:
+        from .data_parallel import all_reduce_mean_scalar
+        avg_loss = np.float32(all_reduce_mean_scalar(float(avg_loss), eng.device))
+    if loss:
+      out.append(avg_loss)
+    if decode:
+      if not self._decoding:
+        raise RuntimeError('add_decoding_ops() was not called')
+      ids, _ = eng.greedy_decode()
+      idx = [[b, p] for b, seq in enumerate(ids) for p in range(len(seq))]
+      out.append([SparseTensorValue(np.array(idx, dtype=np.int64).reshape(-1, 2),
+                                    np.array([v for seq in ids for v in seq], dtype=np.int64),
+                                    np.array([len(ids), max([len(s) for s in ids] + [0])], dtype=np.int64))])
+    if return_label:
+      out.append(labels)
+    if update:
+      out.append(None)
+    if summary:
+      scalars = {}
+      if avg_loss is not None:
+        scalars['loss'] = float(avg_loss)
+      if hasattr(self, 'learning_rate'):
+        scalars['learning_rate'] = self.learning_rate.value
+      out.append(scalars)
+    return out
+
+  def restore(self, session, checkpoint_directory: str, reset_learning_rate: float = None):
+    path = latest_checkpoint(checkpoint_directory)
+    if not path:
+      raise FileNotFoundError('No checkpoint for evaluation found')
+    print('Reading model parameters from {}'.format(path))
+    self._ensure_engine(session)
+    self.saver.restore(session, path)
+    self.init_session(session, init_variables=False)
+    if reset_learning_rate:
+      self.learning_rate.value = float(reset_learning_rate)
+
+  def restore_or_create(self, session, checkpoint_directory: str, reset_learning_rate: float = None):
+    try:
+      self.restore(session, checkpoint_directory, reset_learning_rate)
+    except FileNotFoundError:
+      print('Created model with fresh parameters.')
+      self.init_session(session, init_variables=True)
+
+  # ---- weight interchange: the `export --weights` layout (exporting.py:30-40) -------------------
+  def export_weights(self, directory):
+    """<dir>/convolution_layer_<i>/filters:0.npy [W,Cin,Cout] and .../bias:0.npy [Cout]."""
+    for i, (F, b) in enumerate(self.engine.get_weights()):
+      layer_dir = os.path.join(directory, 'convolution_layer_{}'.format(i))
+      os.makedirs(layer_dir, exist_ok=True)
+      np.save(os.path.join(layer_dir, 'filters:0.npy'), F)
+      np.save(os.path.join(layer_dir, 'bias:0.npy'), b)
+
+  def load_weights(self, session, directory):
+    eng = self._ensure_engine(session)
+    params = []
+    for i in range(len(self._layer_specs)):
+      layer_dir = os.path.join(directory, 'convolution_layer_{}'.format(i))
+      params.append((np.load(os.path.join(layer_dir, 'filters:0.npy')), np.load(os.path.join(layer_dir, 'bias:0.npy'))))
+    eng.set_weights(params)
+
+
+class Wav2LetterModel(SpeechModel):
+  """11 convolutions: 48/2 -> 7x (7/1) -> 32/1 (x8 channels) -> 1x1 -> 1x1 to classes (speech_model.py:275-295)."""
+
+  def __init__(self, input_loader: BaseInputLoader, input_size: int, num_classes: int):
+    super().__init__(input_loader, input_size, num_classes)
+
+  def _create_network(self, num_classes):
+    outputs, channels = self._convolution(self.inputs, 48, 2, self.input_size, 250)
+    for _ in range(7):
+      outputs, channels = self._convolution(outputs, 7, 1, channels, channels)
+    outputs, channels = self._convolution(outputs, 32, 1, channels, channels * 8)
+    outputs, channels = self._convolution(outputs, 1, 1, channels, channels)
+    outputs, channels = self._convolution(outputs, 1, 1, channels, num_classes, False)
+    # time-major [max_time / 2, batch_size, num_classes] like tf.transpose(outputs, (1, 0, 2))
+    return ('logits_time_major', outputs)
+
+
+def create_default_model(flags, input_size: int, speech_input: BaseInputLoader) -> SpeechModel:
+  """speech_model.py:298-324: training ops are always added so that checkpoints restore fully."""
+  model = Wav2LetterModel(input_loader=speech_input, input_size=input_size, num_classes=vocabulary.SIZE + 1)
+  if flags.command == 'train':
+    model.add_training_ops(learning_rate=flags.learning_rate,
+                           learning_rate_decay_factor=flags.learning_rate_decay_factor,
+                           max_gradient_norm=flags.max_gradient_norm, momentum=flags.momentum)
+    model.add_decoding_ops()
+  elif flags.command == 'export':
+    model.add_training_ops()
+    model.add_decoding_ops()
+  else:
+    model.add_training_ops()
+    model.add_decoding_ops(language_model=getattr(flags, 'language_model', None),
+                           lm_weight=getattr(flags, 'lm_weight', 0.8),
+                           word_count_weight=getattr(flags, 'word_count_weight', 0.0),
+                           valid_word_count_weight=getattr(flags, 'valid_word_count_weight', 2.3))
+  model.finalize(log_dir=flags.log_dir, run_name=flags.run_name, run_type=flags.run_type)
+  return model

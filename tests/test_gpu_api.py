@@ -1,0 +1,167 @@
+"""GPU tests of the reference-shaped Python API and the CLI plumbing (BASELINE configs[0])."""
+import os
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  return 'cuda:0'
+
+
+class Flags:
+  command = 'train'
+  learning_rate = 1e-3
+  learning_rate_decay_factor = 0
+  max_gradient_norm = 5.0
+  momentum = 0.9
+  log_dir = 'log'
+  run_name = 'unit'
+  run_type = 'train'
+
+
+def make_loader(n_feat, batch, frames, seed=0):
+  from speecht_amd.speech_input import Coordinator, InputBatchLoader
+  x, seq, labels = WL.make_batch(frames, n_feat, seed=seed)
+
+  def gen():
+    while True:
+      for i in range(len(frames)):
+        yield x[i, :seq[i]], labels[i]
+  loader = InputBatchLoader(n_feat, batch, gen)
+  coord = Coordinator()
+  loader.start_threads(None, coord)
+  return loader, coord, (x, seq, labels)
+
+
+def test_model_step_protocol_and_training_reduces_loss(dev, tmp_path):
+  from speecht_amd.speech_model import Session, create_default_model
+  flags = Flags()
+  flags.log_dir = str(tmp_path / 'log')
+  loader, coord, (x, seq, labels) = make_loader(16, 4, [121, 100, 90, 121])
+  model = create_default_model(flags, 16, loader)
+  assert model.convolution_count == 11 and model.num_classes == 29
+  with Session(dev) as sess:
+    model.init_session(sess)
+    # fetch order: avg_loss, decoded, label, update, summary (speech_model.py:214-235)
+    res = model.step(sess, loss=True, update=True, decode=True, return_label=True, summary=True)
+    assert len(res) == 5 and res[3] is None and set(res[4]) == {'loss', 'learning_rate'}
+    first = float(res[0])
+    assert np.isfinite(first) and res[1][0].indices.shape[1] == 2 and res[2].dense_shape.tolist() == [4, 121]
+    assert model.global_step.eval() == 1
+    # the same loss as the oracle on the same weights and batch
+    params = model.engine.get_weights()
+    only_loss = model.step(sess, update=False)
+    assert len(only_loss) == 1
+    ref = O.train_step(x.astype(np.float32).astype(np.float64), seq, labels,
+                       [(F.astype(np.float64), b.astype(np.float64)) for F, b in params],
+                       WL.w2l_layers(16), None, update=False)
+    assert float(only_loss[0]) == pytest.approx(ref['avg_loss'], rel=1e-4)
+    for _ in range(40):
+      last = float(model.step(sess)[0])
+    assert last < 0.7 * first
+    # checkpoint round trip (saver.save / restore, speech_model.py:251-267)
+    ck = str(tmp_path / 'run')
+    os.makedirs(ck)
+    model.saver.save(sess, os.path.join(ck, 'speechT.ckpt'), global_step=model.global_step)
+    w_before = model.engine.params.clone()
+    step_before = model.global_step.eval()
+    model.init_session(sess, init_variables=True)
+    assert model.global_step.eval() == 0
+    model.restore(sess, ck)
+    assert model.global_step.eval() == step_before and torch.equal(model.engine.params, w_before)
+    with pytest.raises(FileNotFoundError):
+      model.restore(sess, str(tmp_path / 'nothing'))
+    # export --weights layout round trip (exporting.py:30-40)
+    wdir = str(tmp_path / 'weights')
+    model.export_weights(wdir)
+    assert np.load(os.path.join(wdir, 'convolution_layer_8', 'filters:0.npy')).shape == (32, 250, 2000)
+    assert np.load(os.path.join(wdir, 'convolution_layer_10', 'bias:0.npy')).shape == (29,)
+    model.engine.params.zero_()
+    model.load_weights(sess, wdir)
+    assert torch.equal(model.engine.params, w_before)
+  coord.request_stop()
+
+
+def test_single_input_inference_matches_batch_padding_semantics(dev, tmp_path):
+  """F7: nothing is masked, so logits depend on the padded batch length; a single utterance fed
+  through SingleInputLoader must equal the oracle on that [1, T, C] tensor."""
+  from speecht_amd.speech_input import SingleInputLoader
+  from speecht_amd.speech_model import Session, Wav2LetterModel
+  loader = SingleInputLoader(16)
+  model = Wav2LetterModel(loader, 16, 29)
+  model.add_training_ops()
+  model.add_decoding_ops()
+  model.finalize(str(tmp_path), 'r', 'record')
+  feats = WL.synthetic_features(5, 77, 16)
+  with Session(dev) as sess:
+    model.init_session(sess)
+    loader.set_input(feats)
+    decoded, = model.step(sess, loss=False, update=False, decode=True)
+    params = [(F.astype(np.float64), b.astype(np.float64)) for F, b in model.engine.get_weights()]
+    ref = O.wav2letter_forward(feats.astype(np.float32)[None].astype(np.float64), params, WL.w2l_layers(16))
+    got = model.engine.logits_time_major().cpu().numpy()
+    assert np.max(np.abs(got - ref)) < 1e-4
+    ref_ids, _ = O.ctc_greedy_decode(ref, [77 // 2])
+    assert decoded[0].values.tolist() == ref_ids[0]
+    with pytest.raises(ValueError):
+      model.step(sess, loss=False, update=False, decode=True)          # input consumed
+    with pytest.raises(NotImplementedError):
+      model.add_decoding_ops(language_model='kenlm-dir')
+
+
+def write_wav(path, samples, rate=16000):
+  with wave.open(path, 'wb') as w:
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate)
+    w.writeframes((np.clip(samples, -1, 1) * 32767).astype('<i2').tobytes())
+
+
+def test_cli_preprocess_train_evaluate(dev, tmp_path):
+  """BASELINE configs[0]: `speecht-cli evaluate --step-count 1`, batch 4 of 2 s synthetic 16 kHz
+  clips, greedy decode -- through preprocess -> train (few steps, checkpoint) -> evaluate."""
+  data = tmp_path / 'data'
+  for split in ('train', 'test'):
+    (data / split).mkdir(parents=True)
+    lines = []
+    for i in range(4):
+      uid = 'spk-{}-{:04d}'.format(split, i)
+      write_wav(str(data / split / (uid + '.wav')), O.synthetic_audio(i, 32000))
+      lines.append('{} {}'.format(uid, "HELLO WORLD IT'S {}".format('ABCD'[i])))
+    (data / split / 'x.trans.txt').write_text('\n'.join(lines) + '\n')
+  cli = [sys.executable, os.path.join(ROOT, 'speecht-cli')]
+  common = ['--data-dir', str(data), '--train-dir', str(tmp_path / 'train'), '--log-dir', str(tmp_path / 'log'),
+            '--run-name', 'ci', '--batch-size', '4']
+  run = lambda args: subprocess.run(cli + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+  r = run(['preprocess'] + common)
+  assert r.returncode == 0, r.stdout + r.stderr
+  feats = np.load(str(data / 'preprocessed-power' / 'train' / 'spk-train-0000.npz'))
+  assert feats['audio_fragments'].shape == (201, 128)            # default n_mels = 128 (speecht-cli:53)
+  from speecht_amd.preprocessing import load_audio
+  samples, rate = load_audio(str(data / 'train' / 'spk-train-0000.wav'))         # host-side decode only
+  ref = O.calc_power_spectrogram(samples.astype(np.float64), rate, n_mels=128)
+  assert rate == 16000 and np.max(np.abs(feats['audio_fragments'] - ref)) < 1e-3
+  assert feats['transcript'].tolist() == O.sentence_to_ids("hello world it's a")
+  r = run(['train'] + common + ['--steps-per-checkpoint', '3', '--max-steps', '6', '--learning-rate', '1e-3'])
+  assert r.returncode == 0, r.stdout + r.stderr
+  assert 'global step 3 learning rate' in r.stdout and r.stdout.count('Model saved') == 2
+  r = run(['evaluate', '--step-count', '1', '--no-save'] + common)
+  assert r.returncode == 0, r.stdout + r.stderr
+  out = r.stdout
+  assert 'validation average loss' in out and out.count('expected: ') == 4 and 'Global statistics' in out
+  assert "expected: hello world it's" in out and 'LED: ' in out and 'WER: ' in out
+  r = run(['evaluate', '--step-count', '1', '--run-name', 'missing', '--data-dir', str(data),
+           '--train-dir', str(tmp_path / 'train'), '--log-dir', str(tmp_path / 'log'), '--batch-size', '4'])
+  assert r.returncode != 0 and 'No checkpoint for evaluation found' in r.stderr

@@ -1,0 +1,195 @@
+"""CPU tests of the host-side mirror of the reference API: batch/label layout, input pipeline,
+evaluation statistics, CLI flags, corpus cache format, and the data-parallel all-reduce (gloo)."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batch_and_label_layout_matches_oracle():
+  from speecht_amd.speech_input import BaseInputLoader, sparse_to_label_lists
+  rng = np.random.default_rng(0)
+  items = [rng.standard_normal((t, 5)) for t in (7, 3, 9, 1)]
+  labels = [[1, 2, 3], [], [27, 26], [4]]
+  loader = BaseInputLoader(5)
+  x, lens, max_t = loader._get_inputs_feed_item(items)
+  xr, lr, mr = O.pad_batch(items, 5)
+  np.testing.assert_allclose(x, xr.astype(np.float32))
+  assert x.dtype == np.float32 and lens.tolist() == lr.tolist() and max_t == mr == 9
+  sp = loader._get_labels_feed_item(labels, max_t)
+  idx, vals, shape = O.sparse_labels(labels, max_t)
+  np.testing.assert_array_equal(sp.indices, idx)
+  np.testing.assert_array_equal(sp.values, vals)
+  np.testing.assert_array_equal(sp.dense_shape, shape)       # dense_shape uses the INPUT max_time
+  assert sparse_to_label_lists(sp) == labels
+
+
+def test_input_batch_loader_drops_partial_batch_and_signals_end():
+  from speecht_amd.speech_input import Coordinator, InputBatchLoader, OutOfRangeError
+
+  def gen():
+    for i in range(7):                                           # 7 samples, batch 3 -> 2 batches
+      yield np.full((4 + i, 2), float(i)), [i % 28]
+  loader = InputBatchLoader(2, 3, gen)
+  coord = Coordinator()
+  loader.start_threads(None, coord)
+  seen = []
+  with pytest.raises(OutOfRangeError):
+    while True:
+      x, lens, labels = loader.dequeue()
+      seen.append((x.shape, lens.tolist(), labels.values.tolist()))
+  assert seen == [((3, 6, 2), [4, 5, 6], [0, 1, 2]), ((3, 9, 2), [7, 8, 9], [3, 4, 5])]
+  coord.request_stop(); coord.join()
+  # max_steps caps the number of batches
+  loader = InputBatchLoader(2, 1, gen, max_steps=2)
+  loader.start_threads(None, Coordinator())
+  assert loader.dequeue()[1].tolist() == [4] and loader.dequeue()[1].tolist() == [5]
+  with pytest.raises(OutOfRangeError):
+    loader.dequeue()
+
+
+def test_single_input_loader_protocol():
+  from speecht_amd.speech_input import SingleInputLoader
+  loader = SingleInputLoader(3)
+  with pytest.raises(ValueError):
+    loader.get_feed_dict()
+  loader.set_input(np.ones((5, 3)))
+  x, lens, labels = loader.dequeue()
+  assert x.shape == (1, 5, 3) and lens.tolist() == [5] and labels is None
+  assert loader.speech_input is None                            # consumed, like the reference
+
+
+def test_editdistance_and_eval_statistics():
+  from speecht_amd import editdistance
+  from speecht_amd.evaluation import EvalStatistics, Evaluation
+  from speecht_amd.speech_input import SparseTensorValue
+  rng = np.random.default_rng(1)
+  for _ in range(50):
+    a = ''.join(rng.choice(list('abc '), rng.integers(0, 12)))
+    b = ''.join(rng.choice(list('abc '), rng.integers(0, 12)))
+    assert editdistance.eval(a, b) == O.levenshtein(a, b)
+    assert editdistance.eval(a.split(), b.split()) == O.levenshtein(a.split(), b.split())
+  stats = EvalStatistics()
+  stats.track_decoding('the cat sat', 'the cat sat on')
+  assert (stats.letter_edit_distance, stats.word_edit_distance) == (3, 1)
+  assert stats.letter_error_rate == pytest.approx(3 / 14) and stats.word_error_rate == pytest.approx(0.25)
+  stats.track_decoding('x', 'y z')
+  assert stats.global_letter_edit_distance == pytest.approx((3 + 3) / 2)
+  assert stats.global_word_error_rate == pytest.approx((0.25 + 1.0) / 2)
+  # extract_decoded_ids: faithful to the reference, including the empty-row quirk
+  sp = SparseTensorValue(np.array([[0, 0], [0, 1], [2, 0]]), np.array([5, 6, 7]), np.array([3, 2]))
+  assert [list(x) for x in Evaluation.extract_decoded_ids(sp)] == [[5, 6], [7]]   # row 1 (empty) vanishes
+
+
+def test_cli_flags_and_derived_values():
+  import importlib.machinery
+  import importlib.util
+  loader = importlib.machinery.SourceFileLoader('speecht_cli', os.path.join(ROOT, 'speecht-cli'))
+  cli = importlib.util.module_from_spec(importlib.util.spec_from_loader('speecht_cli', loader))
+  loader.exec_module(cli)
+  _, f = cli.parse(['train'])
+  assert (f.feature_type, f.batch_size, f.run_name, f.learning_rate, f.max_gradient_norm,
+          f.steps_per_checkpoint, f.run_type, f.run_train_dir) == ('power', 64, 'noname', 1e-4, 5.0, 1000, 'train',
+                                                                     'train/noname')
+  _, f = cli.parse(['evaluate', '--dev', '--step-count', '1', '--run-name', 'x', '--train-dir', 't', '--no-save'])
+  assert (f.dataset, f.run_type, f.step_count, f.should_save, f.run_train_dir) == ('dev', 'dev', 1, False, 't/x')
+  _, f = cli.parse(['evaluate'])
+  assert f.dataset == 'test' and f.run_type == 'test' and f.should_save is True
+  _, f = cli.parse(['preprocess', '--train-only', '--mfcc'])
+  assert f.train_only and f.feature_type == 'mfcc' and f.run_type == 'other'
+
+
+def test_corpus_reader_transcripts_and_npz_cache(tmp_path, golden_dir):
+  """Same assertions as the reference's test__get_transcript_entries / test_load_samples
+  (speecht/tests/test_speechCorpusReader.py:25-35,62-73) on its own transcript fixture."""
+  from speecht_amd.preprocessing import SpeechCorpusReader
+  from speecht_amd import vocabulary
+  data = tmp_path / 'data'
+  (data / 'train').mkdir(parents=True)
+  src = open(os.path.join(golden_dir, '1089-134686.trans.txt')).read()
+  (data / 'train' / '1089-134686.trans.txt').write_text(src)
+  reader = SpeechCorpusReader(str(data))
+  entries = list(reader._get_transcript_entries(str(data / 'train')))
+  assert entries[0][0] == '1089-134686-0000' and entries[0][1].startswith('HE HOPED THERE WOULD BE STEW FOR DINNER')
+  assert entries[-1][0] == '1089-134686-0037' and len(entries) == 38
+  feats = np.random.default_rng(0).standard_normal((33, 13)).astype(np.float32)
+  out = data / 'preprocessed' / 'train'
+  out.mkdir(parents=True)
+  np.savez(str(out / '1089-134686-0037'), audio_fragments=feats, transcript=reader._transcript_dict['1089-134686-0037'])
+  samples = list(reader.load_samples('train', feature_type='mfcc'))
+  assert len(samples) == 1
+  np.testing.assert_array_equal(samples[0][0], feats)
+  assert vocabulary.ids_to_sentence(samples[0][1]) == entries[-1][1].lower()
+  with pytest.raises(ValueError):
+    list(reader.load_samples('dev', feature_type='power'))
+
+
+def test_shard_range_and_buckets():
+  from speecht_amd.data_parallel import default_buckets, shard_range
+  assert [shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+  with pytest.raises(ValueError):
+    shard_range(10, 0, 4)
+  offs = [(0, 10), (10, 20), (20, 120), (120, 140), (140, 145)]
+  assert default_buckets([e - s for s, e in offs], offs) == [(3, 120, 145), (2, 20, 120), (0, 0, 20)]
+
+
+DP_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ST_ROOT"])
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+from speecht_amd.data_parallel import GradientAllReducer, shard_range, all_reduce_mean_scalar
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+layers = [(7, 2, 6, 8, True), (5, 1, 8, 8, True), (1, 1, 8, 29, False)]
+params = WL.xavier_params(layers, seed=3)
+x, seq, labels = WL.make_batch([40, 33, 28, 40], 6, seed=4)      # global batch 4
+lo, hi = shard_range(len(labels), rank, world)
+
+def flat_grads(xs, ss, ls, scale_batch):
+  logits, acts = O.wav2letter_forward(xs, params, layers, keep=True)
+  loss, g = O.ctc_loss_and_grad(logits, ls, np.asarray(ss) // 2)
+  grads = O.wav2letter_backward(acts, params, layers, g / scale_batch)     # 1 / GLOBAL batch
+  return np.concatenate([np.concatenate([gF.ravel(), gb.ravel()]) for gF, gb in grads]), loss
+
+local, loss = flat_grads(x[lo:hi], seq[lo:hi], labels[lo:hi], len(labels))
+sizes = [F.size + b.size for F, b in params]
+offs = np.concatenate([[0], np.cumsum(sizes)])
+ranges = [(int(offs[i]), int(offs[i + 1])) for i in range(len(sizes))]
+flat = torch.tensor(local)
+red = GradientAllReducer(flat, ranges)
+for i in reversed(range(len(layers))):
+  red.on_layer_done(i)
+red.finish()
+full, full_loss = flat_grads(x, seq, labels, len(labels))
+assert np.allclose(flat.numpy(), full, rtol=1e-9, atol=1e-12), np.abs(flat.numpy() - full).max()
+mean_loss = all_reduce_mean_scalar(float(np.mean(loss)), "cpu")
+assert abs(mean_loss - float(np.mean(full_loss))) < 1e-9
+# identical replicas: every rank ends with the same buffer
+gathered = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+assert all(torch.equal(gathered[0], g) for g in gathered)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_data_parallel_allreduce_equals_single_rank_gloo(tmp_path):
+  """world_size 2 on CPU (gloo): bucketed SUM all-reduce of per-rank gradients scaled by
+  1/global_batch == gradient of the concatenated batch; replicas end bit-identical."""
+  script = tmp_path / 'dp_worker.py'
+  script.write_text(DP_WORKER)
+  env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', WORLD_SIZE='2')
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT) for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o)

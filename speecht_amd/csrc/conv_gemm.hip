@@ -46,6 +46,7 @@ struct NNParams {
   const float* mask; RowMap mmap;    // EPI 1: relu mask source (may be null)
   const float* bias;                 // EPI 0
   int M, Kvalid, Kp, n_store, relu;
+  int taps, cp;                      // filter width and channel pitch of A (k = tap * cp + channel)
   int tiles_m, tiles_n, chunk;       // XCD-aware tile order
   int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
 };
@@ -160,26 +161,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const float* bsrc[B_DMA];
 #pragma unroll
   for (int i = 0; i < B_DMA; ++i) {
-    const int krow = (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR;
-    bsrc[i] = p.Bm + (long)krow * p.Np + n0 + (lane % B_LPR) * 4;
+    bsrc[i] = p.Bm + n0 + (lane % B_LPR) * 4;
   }
   const int ktail = p.Kvalid - 4;   // last float4 inside the valid reduction range
-  const long bstep = (long)BK * p.Np;
 
-  auto dma = [&](int kt, int buf) {
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < A_DMA; ++i) {
-      // reduction tail (Kvalid % 32 == 16): clamp so the read stays inside the row span; the
-      // matching rows of the packed filter operand are zero, so the values do not matter.
-      const float* g = asrc[i] + min(k0 + aslot4[i], ktail);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + i) * 256), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_DMA; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + kt * bstep),
+  const int kplast = p.Kp - 1;
+  constexpr int N_DMA = A_DMA + B_DMA;
+  // DMA piece `pc` (compile-time) of the tile starting at reduction index k0: pieces [0, A_DMA) are
+  // 8-row groups of the im2col operand, the rest 1-KiB groups of filter rows.
+  auto dma_piece = [&](int pc, int k0, int buf) {
+    if (pc < A_DMA) {
+      // reduction tail: clamp so the read stays inside the row span (values there are unused)
+      const float* g = asrc[pc < A_DMA ? pc : 0] + min(k0 + aslot4[pc < A_DMA ? pc : 0], ktail);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + pc) * 256), 16, 0, 0);
+    } else {
+      const int i = pc - A_DMA;
+      const int krow = min(k0 + (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR, kplast);
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
                                        (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
     }
+  };
+  auto dma = [&](int k0, int buf) {
+#pragma unroll
+    for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, k0, buf);
   };
 
   f32x16 acc[MT][NT];
@@ -200,13 +204,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   }
   const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
 
-  const int nk = p.Kp / BK;
-  dma(0, 0);
+  // Reduction order.  k = tap * cp + channel.  With more than one tap the k-tiles are walked
+  // channel-chunk OUTER, tap INNER: consecutive tiles then read the same 32-channel column of input
+  // rows shifted by one frame, so 127 of the 128 staged rows were fetched by the previous tile and
+  // the DMA hits L1/L2 instead of re-streaming the receptive window from HBM/MALL for every tap.
+  // A chunk (or the flat tail tile) holding only 16 valid channels runs half the MFMA quads.
+  const bool tap_inner = p.taps > 1;
+  const int chunks = (p.cp + BK - 1) / BK;
+  const int nk = tap_inner ? chunks * p.taps : p.Kp / BK;
+  int tap = 0, chunk = 0;                       // position of the tile being COMPUTED
+  auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
+  auto tile_nq = [&](int t, int c) {
+    const int valid = tap_inner ? p.cp - c * BK : p.Kvalid - c * BK;
+    return valid >= BK ? 4 : 2;
+  };
+  dma(tile_k0(0, 0), 0);
   __syncthreads();
 
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && !(p.debug & 1)) dma(kt + 1, cur ^ 1);
+    const int nq = tile_nq(tap, chunk);
+    // next tile
+    int ntap = tap, nchunk = chunk;
+    if (tap_inner) { if (++ntap == p.taps) { ntap = 0; ++nchunk; } } else { ++nchunk; }
+    const bool more = kt + 1 < nk && !(p.debug & 1);
+    const int nk0 = tile_k0(ntap, nchunk);
+    tap = ntap; chunk = nchunk;
     const float* as = As + cur * A_SZ;
     const float* bs = Bs + cur * B_SZ + b_frag;
     // Software-pipelined fragment reads: the reads of k-quad q+1 are issued BEFORE the 16 MFMAs of
@@ -223,15 +246,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     read_frags(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      // The DMA of the next tile is issued in slices between the MFMA quads: a burst of 8 DMA
+      // instructions stalls the wave's issue long enough to drain the matrix pipe, two (~60 cycles
+      // each) hide in the shadow of the MFMAs in flight.  (One per 4 MFMAs with more sched_barriers
+      // measured slower: the pinning then also blocks hipcc's own ds_read/MFMA interleave.)
+      if (more) {
+#pragma unroll
+        for (int pc = q; pc < N_DMA; pc += 4) dma_piece(pc, nk0, cur ^ 1);
+      }
       if (q < 3) read_frags(q + 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (q < nq) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!(p.debug & 4)) __syncthreads();     // also drains this wave's DMA (vmcnt) before anyone reads it
@@ -650,6 +683,8 @@ int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float*
   p.Kp = (int)st::round_up(p.Kvalid, BK);
   p.n_store = std::min(y->c_pitch, p.Np);
   p.relu = relu;
+  p.taps = width;
+  p.cp = x->c_pitch;
   return run_nn(p, 0, st::as_stream(stream));
 }
 
@@ -678,6 +713,8 @@ int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int 
   p.Kvalid = width * dz->c_pitch;
   p.Kp = (int)st::round_up(p.Kvalid, BK);
   p.n_store = std::min(dx->c_pitch, p.Np);
+  p.taps = width;
+  p.cp = dz->c_pitch;
   return run_nn(p, 1, st::as_stream(stream));
 }
 

@@ -96,6 +96,19 @@ struct Il4 {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA with scalar base + 32-bit per-lane byte offset (no VALU address math per piece).
+// hipcc does not model the M0 write or the outstanding load: the issuing wave drains with
+// dma_wait_all() before the barrier that publishes the data.
+__device__ __forceinline__ void dma16_sv(unsigned lds_byte_addr, const void* sbase, unsigned voff_bytes) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
+}
+
 template <int N> struct FVec;
 template <> struct FVec<1> { typedef float type; };
 template <> struct FVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -169,6 +182,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   constexpr int N_DMA = A_DMA + B_DMA;
   // DMA piece `pc` (compile-time) of the tile starting at reduction index k0: pieces [0, A_DMA) are
   // 8-row groups of the im2col operand, the rest 1-KiB groups of filter rows.
+  // (The scalar-base inline-asm DMA of the filter-gradient kernel measured SLOWER here, 123 vs 128
+  // TF/s: the per-piece address math is already only a min + 64-bit add, and the asm statements
+  // block hipcc's own interleave.)
   auto dma_piece = [&](int pc, int k0, int buf) {
     if (pc < A_DMA) {
       // reduction tail: clamp so the read stays inside the row span (values there are unused)
@@ -319,31 +335,58 @@ struct TNParams {
   int tiles_k, tiles_n;
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
+  int debug;
 };
 
+__device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
+
+constexpr int TN_THREADS = NTHREADS;
+
 template <int BN, int WKW, int WNW>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNParams p) {
+__global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   constexpr int BKO = 128;
   constexpr int BMR = 32;
   constexpr int WTK = BKO / WKW, WTN = BN / WNW;   // wave tile
   constexpr int MT = WTK / 32, NT = WTN / 32;
-  using AL = Il4<BKO>;
-  using ZL = Il4<BN>;
-  constexpr bool Z_ALL = ZL::BLOCKS >= NTHREADS;
-  static_assert(WKW * WNW == 4 && MT >= 1 && NT >= 1 && AL::BLOCKS == NTHREADS && ZL::BLOCKS <= NTHREADS, "tile config");
+  constexpr int A_DMA = BKO / 32, Z_DMA = BN / 32; // DMA instructions per wave and stage
+  constexpr int A_LPR = BKO / 4, Z_LPR = BN / 4;   // lanes per stage row
+  constexpr int A_SZ = BMR * BKO, Z_SZ = BMR * BN;
+  constexpr int N_DMA = A_DMA + Z_DMA;
+  static_assert(WKW * WNW == 4 && (MT == 1 || MT == 2 || MT == 4) && (NT == 1 || NT == 2 || NT == 4), "tile config");
+  typedef typename FVec<MT>::type avec;
+  typedef typename FVec<NT>::type zvec;
 
-  __shared__ __attribute__((aligned(16))) float As[2][AL::SIZE];
-  __shared__ __attribute__((aligned(16))) float Zs[2][ZL::SIZE];
+  // LDS-DMA staged, linear [m][cols] images (one array: see gemm_nn_kernel).  A lane fetches MT
+  // (resp. NT) adjacent columns of reduction row m with one read, so MFMA tile i of a wave covers
+  // output rows {MT*lane + i}: a permutation the epilogue undoes with MT-strided row addresses.
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * Z_SZ];
+  float* const As = smem;
+  float* const Zs = smem + 2 * A_SZ;
 
-  const int tile = blockIdx.x;
-  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  // XCD-aware order (see gemm_nn_kernel): 8x8 super-tiles so the CUs behind one L2 share operands
+  int tile_k, tile_n;
+  {
+    const int bid = blockIdx.x;
+    const int total = p.tiles_k * p.tiles_n;
+    if ((p.tiles_k & 7) == 0 && (p.tiles_n & 7) == 0) {
+      const int idx = (bid & 7) * (total >> 3) + (bid >> 3);
+      const int sb = idx >> 6, within = idx & 63;
+      const int sbn = p.tiles_n >> 3;
+      tile_k = (sb / sbn) * 8 + (within >> 3);
+      tile_n = (sb % sbn) * 8 + (within & 7);
+    } else {
+      tile_n = bid % p.tiles_n;
+      tile_k = bid / p.tiles_n;
+    }
+  }
   const int k0 = tile_k * BKO, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wk = wave / WNW, wn = wave % WNW;
 
@@ -355,125 +398,125 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: thread -> 4x4 block: reduction rows 4g..4g+3 of the stage, columns 4cq..4cq+3
-  const int ag = tid >> 5, acq = tid & 31;
-  const bool a_col_ok = k0 + 4 * acq < p.Kvalid;
-  const bool z_act = Z_ALL || tid < ZL::BLOCKS;
-  const int zg = z_act ? tid / (BN / 4) : 0, zcq = tid % (BN / 4);
-  const bool z_col_ok = z_act && n0 + 4 * zcq < p.z_cols;
-  // (b, t) of this thread's first A row and first Z row, advanced by 32 rows per stage
-  int ab = 0, at = 0, zb = 0, zt = 0;
-  if (m_begin < p.M) {
-    int m = min(m_begin + 4 * ag, p.M - 1);
-    ab = m / p.amap.frames; at = m - ab * p.amap.frames;
-    m = min(m_begin + 4 * zg, p.M - 1);
-    zb = m / p.zmap.frames; zt = m - zb * p.zmap.frames;
-  }
-  f32x4 ra[4], rz[4];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int nstages = (m_end - m_begin + BMR - 1) / BMR;
 
-  // Loads never branch and never wait: addresses are clamped to valid rows/columns and the
-  // zeroing of out-of-range rows (split tail) / columns happens on the registers at store time.
-  const int acol = a_col_ok ? k0 + 4 * acq : 0;
-  const int zcol = z_col_ok ? n0 + 4 * zcq : 0;
-  int a_rows = 0, z_rows = 0;      // valid rows (0..4) of the block held in ra / rz
-  // walk 4 consecutive (b, t) rows starting at (b, t): branch-free wrap into the next utterance
-  auto row_ptrs = [&](const float* base, const RowMap& map, int b, int t, int m_first, int col,
-                      const float* (&ptr)[4]) {
+  // ---- staging: every wave issues 1/4 of the stage's DMA pieces, in slices between MFMA quads ----
+  // A piece = 64/A_LPR rows of the A stage (1 KiB), likewise for Z.  In a PLAIN stage (all 32 rows
+  // inside one utterance and inside the split -- all but ~1 in 15) a piece is addressed by a scalar
+  // base + a constant per-lane byte offset: no VALU between the DMA instructions, which matters
+  // because any VALU burst in an MFMA-bound wave drains the matrix pipe.  Boundary / last stages
+  // take the general per-lane path.
+  constexpr int A_PIECES = BMR * A_LPR / 64, Z_PIECES = BMR * Z_LPR / 64;
+  constexpr int A_PW = (A_PIECES + 3) / 4, Z_PW = (Z_PIECES + 3) / 4;       // pieces per wave
+  const int acol = min(k0 + (lane % A_LPR) * 4, p.Kvalid - 4);   // clamped into the row; masked at the store
+  const int zcol = min(n0 + (lane % Z_LPR) * 4, p.z_cols - 4);
+  const int arow = lane / A_LPR, zrow = lane / Z_LPR;
+  const long a_jump = p.amap.batch_stride - (long)p.amap.frames * p.amap.row_stride;
+  const long z_jump = p.zmap.batch_stride - (long)p.zmap.frames * p.zmap.row_stride;
+  const bool tiny = p.amap.frames < BMR;          // more than one utterance boundary per stage possible
+  const unsigned a_voff = (unsigned)((arow * p.amap.row_stride + acol) * 4);
+  const unsigned z_voff = (unsigned)((zrow * p.zmap.row_stride + zcol) * 4);
+  const unsigned lds_a = lds_addr(As), lds_z = lds_addr(Zs);
+  const long a_step = (long)(64 / A_LPR) * p.amap.row_stride * 4, z_step = (long)(64 / Z_LPR) * p.zmap.row_stride * 4;
+  int sb = min(m_begin, p.M - 1) / p.amap.frames;  // (utterance, frame) of the first row of the stage being STAGED
+  int stt = min(m_begin, p.M - 1) - sb * p.amap.frames;
+
+  // slice `sl` (0..3) of the stage starting at row mb -> LDS buffer buf
+  auto issue_slice = [&](int sl, int mb, int buf) {
+    const bool plain = !tiny && stt + BMR <= p.amap.frames && mb + BMR <= m_end;
+    if (plain) {
+      const char* sa = reinterpret_cast<const char*>(p.A + ((long)sb * p.amap.batch_stride + p.amap.row0 + (long)stt * p.amap.row_stride));
+      const char* sz = reinterpret_cast<const char*>(p.Z + ((long)sb * p.zmap.batch_stride + p.zmap.row0 + (long)stt * p.zmap.row_stride));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ptr[r] = base + (long)b * map.batch_stride + map.row0 + (long)t * map.row_stride + col;
-      const bool adv = m_first + r + 1 < p.M;          // never step past the last row of the tensor
-      const int t1 = t + (adv ? 1 : 0);
-      const bool wrap = t1 >= map.frames;
-      t = wrap ? 0 : t1;
-      b += wrap ? 1 : 0;
+      for (int i = sl; i < A_PW; i += 4) {
+        const int pc = wave * A_PW + i;
+        if (pc < A_PIECES) dma16_sv(lds_a + (buf * A_SZ + pc * 256) * 4, sa + pc * a_step, a_voff);
+      }
+#pragma unroll
+      for (int i = sl; i < Z_PW; i += 4) {
+        const int pc = wave * Z_PW + i;
+        if (pc < Z_PIECES) dma16_sv(lds_z + (buf * Z_SZ + pc * 256) * 4, sz + pc * z_step, z_voff);
+      }
+    } else {
+#pragma unroll
+      for (int i = sl; i < A_PW + Z_PW; i += 4) {
+        const bool isA = i < A_PW;
+        const int pc = isA ? wave * A_PW + i : wave * Z_PW + (i - A_PW);
+        if (pc >= (isA ? A_PIECES : Z_PIECES)) continue;
+        const int r = isA ? pc * (64 / A_LPR) + arow : pc * (64 / Z_LPR) + zrow;
+        const int m = min(mb + r, p.M - 1);
+        const float* g = isA ? p.A + p.amap.off(m) + acol : p.Z + p.zmap.off(m) + zcol;
+        if (mb + r >= m_end) g = g_zero_row;            // rows past the split end contribute zero
+        float* dst = isA ? As + buf * A_SZ + pc * 256 : Zs + buf * Z_SZ + pc * 256;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
+      }
     }
   };
-  auto advance = [&](int& b, int& t, const RowMap& map) {   // += 32 rows, clamped to the last row
-    t += p.adv_t;
-    b += p.adv_b;
-    const bool wrap = t >= map.frames;
-    t -= wrap ? map.frames : 0;
-    b += wrap ? 1 : 0;
-    const bool past = b >= p.amap_batches;
-    b = past ? p.amap_batches - 1 : b;
-    t = past ? map.frames - 1 : t;
-  };
-  auto gload = [&](int mb) {
-    const float* pa[4];
-    const float* pz[4];
-    row_ptrs(p.A, p.amap, ab, at, mb + 4 * ag, acol, pa);
-    if (z_act) row_ptrs(p.Z, p.zmap, zb, zt, mb + 4 * zg, zcol, pz);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ra[r] = *reinterpret_cast<const f32x4*>(pa[r]);
-    if (z_act) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rz[r] = *reinterpret_cast<const f32x4*>(pz[r]);
-    }
-    a_rows = a_col_ok ? max(0, min(4, m_end - (mb + 4 * ag))) : 0;
-    z_rows = z_col_ok ? max(0, min(4, m_end - (mb + 4 * zg))) : 0;
-    advance(ab, at, p.amap);
-    advance(zb, zt, p.zmap);
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (r >= a_rows) ra[r] = zero4;
-      if (r >= z_rows) rz[r] = zero4;
-    }
-    AL::store_block(&As[buf][0], ag, acq, ra);
-    if (z_act) ZL::store_block(&Zs[buf][0], zg, zcq, rz);
+  auto stage_advance = [&]() {
+    stt += p.adv_t; sb += p.adv_b;
+    if (stt >= p.amap.frames) { stt -= p.amap.frames; ++sb; }
   };
 
-  if (m_begin < m_end) {
-    gload(m_begin);
-    sstore(0);
+  if (nstages > 0) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) issue_slice(sl, m_begin, 0);
+    stage_advance();
   }
+  dma_wait_all();
   __syncthreads();
-  const int a_frag = AL::frag_base(wk * WTK, l31, h);
-  const int z_frag = ZL::frag_base(wn * WTN, l31, h);
-  int cur = 0;
-  for (int mb = m_begin; mb < m_end; mb += BMR) {
-    const bool more = mb + BMR < m_end;
-    if (more) gload(mb + BMR);
-    const float* as = &As[cur][a_frag];
-    const float* zs = &Zs[cur][z_frag];
-    f32x4 af[4][MT], zf[4][NT];
+
+  const int a_frag = (4 * h) * BKO + wk * WTK + MT * l31;
+  const int z_frag = (4 * h) * BN + wn * WTN + NT * l31;
+  for (int st = 0; st < nstages; ++st) {
+    const int cur = (p.debug & 1) ? 0 : (st & 1);
+    const bool more = st + 1 < nstages && !(p.debug & 1);
+    const int mb_next = m_begin + (st + 1) * BMR;
+    const float* as = As + cur * A_SZ + a_frag;
+    const float* zs = Zs + cur * Z_SZ + z_frag;
+    avec af[4][4];
+    zvec zf[4][4];
+    auto read_frags = [&](int q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        af[q][j] = *reinterpret_cast<const avec*>(as + (8 * q + j) * BKO);
+        zf[q][j] = *reinterpret_cast<const zvec*>(zs + (8 * q + j) * BN);
+      }
+    };
+    read_frags(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + q * AL::Q_STRIDE + i * 32);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) zf[q][n] = *reinterpret_cast<const f32x4*>(zs + q * ZL::Q_STRIDE + n * 32);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q == 2 && more) sstore(cur ^ 1);     // mid-stream staging store (see gemm_nn_kernel)
+      if (more) issue_slice(q, mb_next, cur ^ 1);
+      if (q < 3) read_frags(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], zf[q][n][j], acc[i][n], 0, 0, 0);
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<MT>(af[q][j], i), vget<NT>(zf[q][j], n), acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    cur ^= 1;
+    if (more) stage_advance();
+    dma_wait_all();
+    if (!(p.debug & 4)) __syncthreads();
   }
 
   float* out = p.out + (long)split * p.Kp * p.Np;
+  const int col0 = n0 + wn * WTN + NT * l31;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n0 + wn * WTN + n * 32 + l31;
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + wk * WTK + MT * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+      if (k < p.Kp && col0 < p.Np) {
+        zvec o;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wk * WTK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (k < p.Kp && col < p.Np) out[(long)k * p.Np + col] = (k < p.Kvalid && col < p.z_cols) ? acc[i][n][r] : 0.f;
+        for (int n = 0; n < NT; ++n)
+          vset<NT>(o, n, (k < p.Kvalid && col0 + n < p.z_cols) ? acc[i][n][r] : 0.f);
+        *reinterpret_cast<zvec*>(out + (long)k * p.Np + col0) = o;
       }
-  }
+    }
 }
 
 // dst[i] = sum_s slabs[s][i]
@@ -763,15 +806,16 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   p.amap_batches = dz->batch;
   p.adv_b = 32 / dz->frames;
   p.adv_t = 32 % dz->frames;
+  if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
   if (p.Np % 128 == 0) {
     p.tiles_n = p.Np / 128;
-    hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);
   } else if (p.Np == 64) {
     p.tiles_n = 1;
-    hipLaunchKernelGGL((gemm_tn_kernel<64, 2, 2>), dim3(p.tiles_k, used), dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<64, 2, 2>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
   } else if (p.Np == 32) {
     p.tiles_n = 1;
-    hipLaunchKernelGGL((gemm_tn_kernel<32, 4, 1>), dim3(p.tiles_k, used), dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<32, 4, 1>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
   } else {
     st::set_error("conv bwd_filter: unsupported n_pad=%d", p.Np);
     return ST_EINVAL;

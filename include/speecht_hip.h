@@ -71,12 +71,14 @@ int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float*
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),
  *   mask = (act[b,t,c] > 0) when act != NULL (tf.nn.relu's gradient of the producing layer).
- *   packed_t comes from st_filters_flip_transpose_f32; dz->halo >= width-1-pad_left.
+ *   packed_t comes from st_filters_flip_transpose_f32; dz->halo >= width-1-pad_left.  The workspace
+ *   (st_conv1d_bwd_data_ws bytes, may be 0 / NULL) enables split-K for long reductions.
  * bwd_filter: dF[w,c,o] = sum_{b,t} x[b, t*stride + w - pad_left, c] * dz[b,t,o] in packed
  *   layout [k_pad][n_pad]; dbias[o] = sum_{b,t} dz[b,t,o].  Workspace: st_conv1d_bwd_filter_ws. */
+size_t st_conv1d_bwd_data_ws(const st_tensor3* dz, const st_tensor3* dx, int width);
 int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int width,
                                int pad_left, const st_tensor3* act, const st_tensor3* dx,
-                               void* stream);
+                               void* workspace, size_t workspace_bytes, void* stream);
 size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width);
 int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int width, int stride,
                                  int pad_left, float* dpacked, float* dbias, void* workspace,

@@ -59,7 +59,7 @@ def main():
     d = 0.0
     if i > 0 and args.only in ('', 'data'):
       d = timeit(lambda: call('st_conv1d_nwc_bwd_data_f32', eng.dZ[i].ref, eng._ptr(eng.packed_t[i]), l.width, pl,
-                              eng.X[i].ref, eng.dZ[i - 1].ref, s), args.reps)
+                              eng.X[i].ref, eng.dZ[i - 1].ref, eng._ptr(eng.wgrad_ws), eng.wgrad_ws.numel() * 4, s), args.reps)
     mult = 7 if i == 1 else 1
     tot['fwd'] += f * mult; tot['bwd_data'] += d * mult; tot['bwd_filter'] += w * mult
     tf = lambda ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

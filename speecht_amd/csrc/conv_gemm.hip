@@ -49,6 +49,8 @@ struct NNParams {
   int taps, cp;                      // filter width and channel pitch of A (k = tap * cp + channel)
   int tiles_m, tiles_n, chunk;       // XCD-aware tile order
   int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
+  int splits, steps_per_split;       // split-K over blockIdx.y: raw partial tiles go to `slab`
+  float* slab;                       // [splits][M][Np]
 };
 
 // ------------------------------------------------------------------------------------
@@ -227,14 +229,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // A chunk (or the flat tail tile) holding only 16 valid channels runs half the MFMA quads.
   const bool tap_inner = p.taps > 1;
   const int chunks = (p.cp + BK - 1) / BK;
-  const int nk = tap_inner ? chunks * p.taps : p.Kp / BK;
-  int tap = 0, chunk = 0;                       // position of the tile being COMPUTED
+  const int nk_total = tap_inner ? chunks * p.taps : p.Kp / BK;
+  // split-K: this workgroup reduces k-tiles [s0, s0 + nk) and writes a raw partial tile
+  const int s0 = p.splits > 1 ? blockIdx.y * p.steps_per_split : 0;
+  const int nk = p.splits > 1 ? min(p.steps_per_split, nk_total - s0) : nk_total;
+  int tap = tap_inner ? s0 % p.taps : 0;          // position of the tile being COMPUTED
+  int chunk = tap_inner ? s0 / p.taps : s0;
   auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
   auto tile_nq = [&](int t, int c) {
     const int valid = tap_inner ? p.cp - c * BK : p.Kvalid - c * BK;
     return valid >= BK ? 4 : 2;
   };
-  dma(tile_k0(0, 0), 0);
+  dma(tile_k0(tap, chunk), 0);
   __syncthreads();
 
   int cur = 0;
@@ -290,6 +296,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // epilogue: C/D layout of 32x32 MFMA: tile column = lane&31 (-> output column NT*l31 + nt),
   // row = (r&3) + 8*(r>>2) + 4*(lane>>5); every lane stores NT adjacent floats per row.
   const int col0 = n0 + wn * WTN + NT * l31;
+  if (p.splits > 1) {                            // raw partial tile; splitk_epilogue_kernel finishes
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.Np;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M) {
+          bvec out;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
+          *reinterpret_cast<bvec*>(slab + (long)m * p.Np + col0) = out;
+        }
+      }
+    return;
+  }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
   bvec bv;
 #pragma unroll
@@ -531,23 +553,31 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   }
 }
 
-// column sums of dz: partial[chunk][c] over row chunks, then summed in order by a second pass.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ Z, RowMap zmap,
-                                                             int M, int cols, int rows_per_chunk,
+// column sums of dz (the bias gradient): partial[(b, chunk)][c] over 256-frame chunks of every
+// utterance, then summed in fixed order by a second pass.  HBM-bound streaming read: a block covers
+// 128 columns with 16-byte loads, 8 rows in flight per pass.
+constexpr int COLSUM_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ Z, long batch_stride, long row0,
+                                                             int row_stride, int frames, int cols, int c_pitch,
                                                              float* __restrict__ partial, int np) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sub = threadIdx.x >> 6;     // 4 row phases
-  const int m_begin = blockIdx.y * rows_per_chunk;
-  const int m_end = min(M, m_begin + rows_per_chunk);
-  float s = 0.f;
-  if (c < cols)
-    for (int m = m_begin + sub; m < m_end; m += 4) s += Z[zmap.off(m) + c];
-  __shared__ float red[4][64];
-  red[sub][threadIdx.x & 63] = s;
+  const int c4 = blockIdx.x * 128 + (threadIdx.x & 31) * 4;
+  const int rl = threadIdx.x >> 5;
+  const int chunks = gridDim.y;
+  const int t_lo = blockIdx.y * COLSUM_ROWS, t_hi = min(frames, t_lo + COLSUM_ROWS);
+  const float* base = Z + (long)blockIdx.z * batch_stride + row0 + c4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < c_pitch)
+    for (int t = t_lo + rl; t < t_hi; t += 8) acc += *reinterpret_cast<const f32x4*>(base + (long)t * row_stride);
+  __shared__ f32x4 red[8][32];
+  red[rl][threadIdx.x & 31] = acc;
   __syncthreads();
-  if (sub == 0 && c < np) {
-    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    partial[(long)blockIdx.y * np + c] = c < cols ? t : 0.f;
+  if (rl == 0 && c4 < np) {
+    f32x4 s = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][threadIdx.x];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (c4 + e >= cols) s[e] = 0.f;
+    *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.z * chunks + blockIdx.y) * np + c4) = s;
   }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int np,
@@ -573,22 +603,27 @@ __global__ void pack_filters_kernel(const float* __restrict__ f, int W, int cin,
   else packed[pi] = f[i];
 }
 
-// out[(w' * cop + o) * NpT + c] = in[((W-1-w') * cip + c) * Np + o]   (32x32 LDS transpose)
+// out[(w' * cop + o) * NpT + c] = in[((W-1-w') * cip + c) * Np + o]   (32x32 LDS transpose).
+// The grid covers the WHOLE padded output [kt_pad][NpT] and writes zeros into every padding
+// element, so no separate clear pass is needed per step.
 __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ in, int W, int cin,
                                                              int cout, int cip, int Np, int cop, int NpT,
-                                                             float* __restrict__ out) {
+                                                             int kt_pad, float* __restrict__ out) {
   __shared__ float tile[32][33];
-  const int w = blockIdx.z;
+  const int w = blockIdx.z;                 // taps 0..W-1, and W = the k-padding rows past W*cop
   const int c0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    int c = c0 + r, o = o0 + tx;
-    tile[r][tx] = (c < cin && o < cout) ? in[((long)(W - 1 - w) * cip + c) * Np + o] : 0.f;
+  if (w < W) {
+    for (int r = ty; r < 32; r += 8) {
+      int c = c0 + r, o = o0 + tx;
+      tile[r][tx] = (c < cin && o < cout) ? in[((long)(W - 1 - w) * cip + c) * Np + o] : 0.f;
+    }
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
-    int o = o0 + r, c = c0 + tx;
-    if (o < cout && c < cin) out[((long)w * cop + o) * NpT + c] = tile[tx][r];
+    const int o = o0 + r, c = c0 + tx;
+    const long krow = (long)w * cop + o;
+    if (c < NpT && krow < kt_pad && (w == W || o < cop)) out[krow * NpT + c] = (w < W) ? tile[tx][r] : 0.f;
   }
 }
 
@@ -609,6 +644,41 @@ RowMap make_map(const st_tensor3& t, int first_row, int frame_stride, int frames
   return m;
 }
 
+// C[m, :] = epilogue(sum_s slab[s][m][:]) for split-K launches (fixed summation order).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(NNParams p, int epi) {
+  const int cols4 = p.n_store / 4;
+  const int rows_per_block = 256 / cols4 > 0 ? 256 / cols4 : 1;
+  const int c4 = (threadIdx.x % cols4) * 4;
+  const int m = blockIdx.x * rows_per_block + threadIdx.x / cols4;
+  if (m >= p.M || threadIdx.x >= rows_per_block * cols4) return;
+  const float* src = p.slab + (long)m * p.Np + c4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(src);
+  for (int sidx = 1; sidx < p.splits; ++sidx) v += *reinterpret_cast<const f32x4*>(src + (long)sidx * p.M * p.Np);
+  if (epi == 0) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  } else if (p.mask) {
+    f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + p.mmap.off(m) + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(p.C + p.cmap.off(m) + c4) = v;
+}
+
+// split-K policy.  Measured on MI355X (L8 back-prop to the input: M 16032, K 64000, N 256 -> 252
+// tiles of 128x128): no split 4.31 ms, 2 splits 4.32 ms, 4 splits 4.39 ms, 64x128 tiles 4.62 ms.
+// One 128x128 workgroup per CU already keeps the matrix pipe as busy as two, so splitting K buys
+// nothing; the machinery stays for shapes with far fewer tiles than CUs (ST_GEMM_SPLITS forces it).
+int nn_splits(int M, int Np, int Kp) {
+  static const int forced = getenv("ST_GEMM_SPLITS") ? atoi(getenv("ST_GEMM_SPLITS")) : 0;
+  if (Np % 128) return 1;
+  const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
+  const int nk = Kp / BK;
+  int splits = forced ? forced : (tiles128 < 64 && nk >= 256 ? (int)std::min<long>(8, 256 / tiles128) : 1);
+  while (splits > 1 && nk / splits < 64) --splits;
+  return splits;
+}
+
 template <int BM, int BN, int WMW, int WNW>
 void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.tiles_m = st::ceil_div(p.M, BM);
@@ -616,9 +686,13 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   const int total = p.tiles_m * p.tiles_n;
   p.chunk = st::ceil_div(total, 8);
   if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
-  dim3 grid(p.chunk * 8), block(NTHREADS);
+  dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1>), grid, block, 0, s, p);
+  if (p.splits > 1) {
+    const int rows_per_block = std::max(1, 256 / (p.n_store / 4));
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(st::ceil_div(p.M, rows_per_block)), dim3(256), 0, s, p, epi);
+  }
 }
 
 int run_nn(NNParams& p, int epi, hipStream_t s) {
@@ -628,7 +702,7 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
-    else if (tiles128 >= 512) launch_nn<128, 128, 2, 2>(p, epi, s);
+    else if (tiles128 >= 192 || p.splits > 1) launch_nn<128, 128, 2, 2>(p, epi, s);   // >= 3/4 of the CUs busy
     else launch_nn<64, 128, 2, 2>(p, epi, s);
   } else if (p.Np == 64) {
     launch_nn<128, 64, 2, 2>(p, epi, s);
@@ -698,10 +772,10 @@ int st_filters_flip_transpose_f32(const float* packed, int width, int cin, int c
   int np = npad_of(cout);
   int kvt, kpt, npt;
   if (int e = st_packed_dims(width, cout_pitch, cin, &kvt, &kpt, &npt)) return e;
-  if (int e = st_fill_f32(packed_t, 0.f, (size_t)kpt * npt, stream)) return e;
-  dim3 grid(st::ceil_div(cout, 32), st::ceil_div(cin, 32), width);
+  const int pad_rows = kpt - width * cout_pitch;          // < 32 rows of k-padding
+  dim3 grid(st::ceil_div(std::max(cout_pitch, pad_rows), 32), st::ceil_div(npt, 32), width + (pad_rows > 0 ? 1 : 0));
   hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(256), 0, st::as_stream(stream), packed, width,
-                     cin, cout, cin_pitch, np, cout_pitch, npt, packed_t);
+                     cin, cout, cin_pitch, np, cout_pitch, npt, kpt, packed_t);
   return st::check_launch("flip_transpose");
 }
 
@@ -731,8 +805,17 @@ int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float*
   return run_nn(p, 0, st::as_stream(stream));
 }
 
+size_t st_conv1d_bwd_data_ws(const st_tensor3* dz, const st_tensor3* dx, int width) {
+  if (!dz || !dx) return 0;
+  const int np = npad_of(dx->channels), kp = (int)st::round_up((size_t)width * dz->c_pitch, BK);
+  const int M = dx->batch * dx->frames;
+  const int splits = nn_splits(M, np, kp);
+  return splits > 1 ? (size_t)splits * M * np * sizeof(float) : 0;
+}
+
 int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
-                               const st_tensor3* act, const st_tensor3* dx, void* stream) {
+                               const st_tensor3* act, const st_tensor3* dx, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && packed_t, "conv bwd_data: bad tensor descriptor");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames, "conv bwd_data: stride-1 layers only");
   const int lead = width - 1 - pad_left;   // zero rows needed in front of dz frame 0
@@ -758,6 +841,15 @@ int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int 
   p.n_store = std::min(dx->c_pitch, p.Np);
   p.taps = width;
   p.cp = dz->c_pitch;
+  // long reductions on few output tiles (L8: K = 64000, N = 256) are split over K; needs the workspace
+  const int splits = nn_splits(p.M, p.Np, p.Kp);
+  if (splits > 1 && workspace && workspace_bytes >= st_conv1d_bwd_data_ws(dz, dx, width)) {
+    const int nk = p.taps > 1 ? st::ceil_div(p.cp, BK) * p.taps : p.Kp / BK;
+    p.splits = splits;
+    p.steps_per_split = st::ceil_div(nk, splits);
+    p.splits = st::ceil_div(nk, p.steps_per_split);
+    p.slab = reinterpret_cast<float*>(workspace);
+  }
   return run_nn(p, 1, st::as_stream(stream));
 }
 
@@ -774,7 +866,7 @@ size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int wi
   int M = dz->batch * dz->frames;
   int splits = bwd_filter_splits(M, kp, np);
   size_t slabs = splits > 1 ? (size_t)splits * kp * np * sizeof(float) : 0;
-  size_t colsum = (size_t)st::ceil_div(M, 256) * np * sizeof(float);
+  size_t colsum = (size_t)dz->batch * st::ceil_div(dz->frames, COLSUM_ROWS) * np * sizeof(float);
   return slabs + colsum + 256;
 }
 
@@ -830,11 +922,12 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   if (dbias) {
     size_t slab_bytes = splits > 1 ? (size_t)splits * p.Kp * p.Np * sizeof(float) : 0;
     float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + st::round_up(slab_bytes, 256));
-    const int chunks = st::ceil_div(p.M, 256);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(st::ceil_div(p.Np, 64), chunks), dim3(256), 0, s, dz->base,
-                       p.zmap, p.M, dz->channels, 256, partial, p.Np);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(st::ceil_div(p.Np, 256)), dim3(256), 0, s, partial, chunks,
-                       p.Np, dbias);
+    const int chunks = st::ceil_div(dz->frames, COLSUM_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(st::ceil_div(p.Np, 128), chunks, dz->batch), dim3(256), 0, s,
+                       dz->base, p.zmap.batch_stride, p.zmap.row0, p.zmap.row_stride, dz->frames, dz->channels,
+                       dz->c_pitch, partial, p.Np);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(st::ceil_div(p.Np, 256)), dim3(256), 0, s, partial,
+                       chunks * dz->batch, p.Np, dbias);
     if (int e = st::check_launch("colsum")) return e;
   }
   return ST_OK;

@@ -175,6 +175,8 @@ class Wav2LetterEngine:
     self.t_out = geo[-1][1]
     lib = _lib.load()
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
+    ws = max([ws] + [lib.st_conv1d_bwd_data_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
+                     for i, l in enumerate(self.layers) if i > 0])
     self.wgrad_ws = torch.zeros(ws // 4 + 64, dtype=torch.float32, device=dev)
     self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
     self.ctc_status = torch.zeros(batch, dtype=torch.int32, device=dev)
@@ -255,7 +257,7 @@ class Wav2LetterEngine:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         act = self.X[i].ref if self.layers[i - 1].relu else None
         call('st_conv1d_nwc_bwd_data_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
-             act, self.dZ[i - 1].ref, s)
+             act, self.dZ[i - 1].ref, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
 
   def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
     """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""

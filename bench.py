@@ -53,41 +53,84 @@ def train_step(eng, x_dev, reducer, lr, global_batch):
   eng.apply_update(lr)
 
 
-def measure_dominant_kernel(eng, batch, reps=5):
-  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0> (forward of the
-  wide layers L8, L9: 83 % of forward MACs) on the stream it is launched on."""
-  import ctypes
+DOMINANT = 'gemm_nn_kernel<128,128,2,2,0>'
+
+
+def measure_dominant_kernel(eng, batch, reps=10):
+  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0>: the forward
+  convolution of every layer whose packed width is a multiple of 128 (L0..L9 = 99.8 % of the forward
+  MACs; 10 launches per step, the same launches rocprofv3 --stats averages).  Events are recorded on
+  the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
   from speecht_amd._lib import call
   flops = conv_flops(eng, batch)
-  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0 and
-          -(-(batch * eng.geo[i][1]) // 128) * (l.n_pad // 128) >= 512]
-  tot_ms, tot_flops, tot_bytes, launches = 0.0, 0.0, 0.0, 0
+  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0]
+  if not wide:
+    return None
   s = eng.stream_ptr
-  for i in wide:
+
+  def launch(i):
     l = eng.layers[i]
     pf, pb = eng._slice(eng.params, i)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-      call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
-           eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
-    ev1.record()
-    ev1.synchronize()
-    tot_ms += ev0.elapsed_time(ev1) / reps
-    tot_flops += flops[i]
-    t_in, t_out = eng.geo[i][0], eng.geo[i][1]
-    tot_bytes += 4.0 * (batch * t_in * l.cin + l.width * l.cin * l.cout + batch * t_out * l.cout)
-    launches += 1
-  if not launches:
-    return None
-  avg_ms = tot_ms / launches
-  achieved = tot_flops / launches / (avg_ms * 1e-3) / 1e12
-  return dict(bound='mfma', kernel='gemm_nn_kernel<128,128,2,2,0> (conv forward L8,L9)', achieved=round(achieved, 2),
-              peak=PEAK_F32_TFLOPS, unit='TFLOP/s', frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None,
-              avg_launch_ms=round(avg_ms, 4), launches_per_step=launches,
-              algorithmic_gflop_per_launch=round(tot_flops / launches / 1e9, 2),
-              algorithmic_mb_per_launch=round(tot_bytes / launches / 1e6, 2),
-              hbm_frac_of_peak=round(tot_bytes / launches / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+    call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
+         eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
+  for _ in range(2):
+    for i in wide:
+      launch(i)
+  evs = []
+  for _ in range(reps):
+    for i in wide:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      launch(i)
+      e1.record()
+      evs.append((i, e0, e1))
+  torch.cuda.synchronize()
+  tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in evs) / reps
+  tot_flops = sum(flops[i] for i in wide)
+  tot_bytes = sum(4.0 * (batch * eng.geo[i][0] * eng.layers[i].cin + eng.layers[i].width * eng.layers[i].cin *
+                         eng.layers[i].cout + batch * eng.geo[i][1] * eng.layers[i].cout) for i in wide)
+  n = len(wide)
+  avg_ms = tot_ms / n
+  achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+  return dict(bound='mfma', kernel=DOMINANT + ' (conv forward, layers %s)' % ','.join('L%d' % i for i in wide),
+              achieved=round(achieved, 2), peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
+              frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, traffic_unit='bytes/launch (PMC, see profiles/)',
+              avg_launch_ms=round(avg_ms, 4), launches_per_step=n,
+              algorithmic_gflop_per_launch=round(tot_flops / n / 1e9, 2),
+              algorithmic_mb_per_launch=round(tot_bytes / n / 1e6, 2),
+              hbm_frac_of_peak=round(tot_bytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+
+
+def measure_mel(dev, batch, seconds, n_mels, reps=5):
+  """calc_power_spectrogram (preprocessing.py:36-58) on `batch` resident 16 kHz clips: the reference
+  runs it offline (speecht-cli preprocess), so it is reported beside, not inside, the step metric."""
+  import ctypes
+  from oracle.w2l_oracle import synthetic_audio       # deterministic clips only (SURVEY 8(d))
+  from speecht_amd import _lib
+  from speecht_amd.preprocessing import mel_filterbank
+  n = int(seconds * 16000)
+  audio = torch.as_tensor(np.concatenate([synthetic_audio(i, n) for i in range(batch)])).to(dev)
+  frames = 1 + n // 160
+  s_off = torch.arange(batch + 1, dtype=torch.int64, device=dev) * n
+  f_off = torch.arange(batch + 1, dtype=torch.int64, device=dev) * frames
+  basis = torch.as_tensor(mel_filterbank(16000.0, 512, n_mels).astype(np.float32)).to(dev)
+  out = torch.empty(batch * frames * n_mels, dtype=torch.float32, device=dev)
+  ws = torch.empty(_lib.load().st_melspec_ws(batch, batch * frames, n_mels) // 4 + 64, dtype=torch.float32, device=dev)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  run = lambda: _lib.call('st_melspec_f32', P(audio), P(s_off), batch, n, P(basis), n_mels, 512, 160, P(f_off),
+                          batch * frames, P(out), P(ws), ws.numel() * 4,
+                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+  run()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    run()
+  e1.record()
+  e1.synchronize()
+  ms = e0.elapsed_time(e1) / reps
+  bytes_alg = batch * (n * 4 + frames * n_mels * 4)
+  return dict(utterances_per_s=round(batch / (ms * 1e-3), 1), ms_per_batch=round(ms, 4),
+              algorithmic_gbs=round(bytes_alg / (ms * 1e-3) / 1e9, 1), bound='hbm/launch', n_mels=n_mels)
 
 
 def cpu_baseline(n_mels, frames, utts=2, steps=2):
@@ -182,7 +225,9 @@ def main():
     out['roofline'] = measure_dominant_kernel(eng, args.batch)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
     if out['roofline'] and os.path.exists(traffic_file):
-      out['roofline']['traffic'] = json.load(open(traffic_file)).get('gemm_nn_fwd_bytes_per_launch')
+      out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
+    if world == 1:
+      out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))

@@ -191,11 +191,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     if (pc < A_DMA) {
       // reduction tail: clamp so the read stays inside the row span (values there are unused)
       const float* g = asrc[pc < A_DMA ? pc : 0] + min(k0 + aslot4[pc < A_DMA ? pc : 0], ktail);
+      if (p.debug & 32) g = p.A + lane * 4;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + pc) * 256), 16, 0, 0);
     } else {
       const int i = pc - A_DMA;
       const int krow = min(k0 + (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR, kplast);
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
+      __builtin_amdgcn_global_load_lds((gptr_t)((p.debug & 32) ? p.Bm + lane * 4 : bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
                                        (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
     }
   };

@@ -1,0 +1,122 @@
+"""Parity at BASELINE.json's full sizes (config 2: B=32, 10 s, 80-mel, 250/2000 channels) through
+size-independent properties, plus an oracle check on a 2-utterance slice of the same batch."""
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def full(request):
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)
+  frames = [1001] * 30 + [777, 500]                       # ragged tail like a real batch
+  x, seq, labels = WL.make_batch(frames, 80, seed=3)
+  eng = Wav2LetterEngine(layers, device='cuda:0')
+  eng.set_weights(params)
+  eng.load_batch(x, seq)
+  eng.set_labels(labels)
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / 32)
+  eng.backward()
+  torch.cuda.synchronize()
+  return dict(eng=eng, layers=layers, params=params, x=x, seq=seq, labels=labels)
+
+
+def test_fullsize_logits_match_oracle_on_a_slice(full):
+  """Nothing is masked, so utterance b's logits depend only on its own padded row:
+  the oracle on rows {0, 31} alone must reproduce the batch's logits for those rows."""
+  eng = full['eng']
+  rows = [0, 31]
+  params64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in full['params']]
+  ref = O.wav2letter_forward(full['x'][rows].astype(np.float32).astype(np.float64), params64, full['layers'])
+  got = eng.logits_time_major().cpu().numpy()[:, rows, :]
+  assert got.shape == ref.shape == (501, 2, 29)
+  assert np.max(np.abs(got - ref)) < 1e-4
+  loss_ref, _ = O.ctc_loss_and_grad(ref, [full['labels'][r] for r in rows], full['seq'][rows] // 2)
+  np.testing.assert_allclose(eng.loss.cpu().numpy()[rows], loss_ref, rtol=1e-4)
+
+
+def test_fullsize_batch_independence_bit_exact(full):
+  """The same utterance alone (same padded length) gives bit-identical logits: rows never mix."""
+  from speecht_amd.engine import Wav2LetterEngine
+  eng = full['eng']
+  solo = Wav2LetterEngine(full['layers'], device='cuda:0')
+  solo.params.copy_(eng.params)
+  solo.load_batch(full['x'][5:6], full['seq'][5:6])
+  solo.forward()
+  a = solo.X[-1].interior()[0]
+  b = eng.X[-1].interior()[5]
+  assert torch.equal(a, b)
+
+
+def test_fullsize_ctc_gradient_properties(full):
+  eng = full['eng']
+  g = eng.dZ[-1].interior()                                # [B, T', 29], already scaled by 1/32
+  lens = torch.as_tensor(full['seq'] // 2, device=g.device)
+  t = torch.arange(g.shape[1], device=g.device)[None, :]
+  live = (t < lens[:, None])
+  # softmax - occupancy: both sum to 1 over the classes on every live frame
+  assert float(g.sum(dim=2)[live].abs().max()) < 5e-6
+  assert float(g[~live].abs().max()) == 0.0
+  loss = eng.loss.cpu().numpy()
+  assert np.all(np.isfinite(loss)) and np.all(loss > 0)
+  assert not eng.ctc_status.cpu().numpy().any()
+  # the blank column's gradient is y_blank - occ_blank with occ in [0, 1]
+  assert float(g.abs().max()) <= 1.0 / 32 + 1e-6
+
+
+def test_fullsize_greedy_decode_matches_argmax_of_device_logits(full):
+  eng = full['eng']
+  ids, score = eng.greedy_decode()
+  logits = eng.logits_time_major().cpu().numpy()
+  ref_ids, ref_score = O.ctc_greedy_decode(logits, full['seq'] // 2)
+  assert ids == ref_ids
+  np.testing.assert_allclose(score, ref_score, rtol=1e-5)
+  for seq_ids in ids:
+    assert all(0 <= v < 28 for v in seq_ids)
+
+
+def test_fullsize_filter_gradient_linearity_and_norm(full):
+  """Back-prop is linear in dz: grads(dz) == grads(dz/2) * 2 bit-for-bit is not required, but the
+  flat gradient must scale to fp32 accuracy and its norm must equal the reported global norm."""
+  from speecht_amd import _lib
+  import ctypes
+  eng = full['eng']
+  g1 = eng.grads.clone()
+  eng.dZ[-1].buf.mul_(0.5)
+  eng.backward()
+  torch.cuda.synchronize()
+  rel = float((eng.grads * 2 - g1).abs().max() / g1.abs().max())
+  assert rel < 1e-5
+  eng.grads.copy_(g1)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  _lib.call('st_global_norm_f32', P(eng.grads), eng.n_flat, 5.0, P(eng.stats), P(eng.norm_ws), eng.norm_ws.numel() * 4, None)
+  torch.cuda.synchronize()
+  ref = float(torch.linalg.vector_norm(g1.double()))
+  assert float(eng.stats[0]) == pytest.approx(ref, rel=1e-5)
+  assert np.isfinite(ref) and ref > 0
+
+
+def test_fullsize_update_keeps_padding_zero_and_changes_weights(full):
+  eng = full['eng']
+  before = eng.params.clone()
+  eng.apply_update(lr=1e-4)
+  torch.cuda.synchronize()
+  assert not torch.equal(before, eng.params)
+  # every padded filter row / column and pad bias is still exactly zero
+  for i, l in enumerate(eng.layers):
+    pf, pb = eng._slice(eng.params, i)
+    P = pf.view(l.k_pad, l.n_pad)
+    assert float(P[:, l.cout:].abs().max()) == 0.0
+    assert float(pb[l.cout:].abs().sum()) == 0.0
+    if l.cin_pitch > l.cin:
+      V = P[:l.width * l.cin_pitch].view(l.width, l.cin_pitch, l.n_pad)
+      assert float(V[:, l.cin:, :].abs().max()) == 0.0

@@ -129,6 +129,8 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
 
 /* ---- helpers -------------------------------------------------------------------------- */
 int st_fill_f32(float* dst, float value, size_t n, void* stream);
+/* zero the halo rows of a padded NWC tensor (needed when a buffer is re-described for a new shape) */
+int st_zero_halos_f32(const st_tensor3* t, void* stream);
 
 #ifdef __cplusplus
 }

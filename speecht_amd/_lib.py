@@ -45,6 +45,7 @@ _SIGNATURES = {
     'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_fill_f32': (c_int, [c_void_p, c_float, c_size_t, c_void_p]),
+    'st_zero_halos_f32': (c_int, [_T3P, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -628,6 +628,20 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
   }
 }
 
+// zero the halo rows (in front of frame 0 and behind the last frame) of every utterance
+__global__ __launch_bounds__(256) void zero_halos_kernel(float* base, int frames, int halo, int t_pitch, int c_pitch) {
+  const int halo_rows = t_pitch - frames;
+  const long row4 = c_pitch / 4;
+  const long total = (long)halo_rows * row4;
+  float* utt = base + (long)blockIdx.y * t_pitch * c_pitch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int r = (int)(i / row4);
+    const int c4 = (int)(i - r * row4) * 4;
+    if (r >= halo) r += frames;                       // rows behind the interior
+    *reinterpret_cast<f32x4*>(utt + (long)r * c_pitch + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 __global__ void fill_kernel(float* dst, float v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -740,6 +754,17 @@ int st_fill_f32(float* dst, float value, size_t n, void* stream) {
   int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, st::as_stream(stream), dst, value, n);
   return st::check_launch("fill");
+}
+
+int st_zero_halos_f32(const st_tensor3* t, void* stream) {
+  ST_REQUIRE(tensor_ok(t), "st_zero_halos_f32: bad tensor descriptor");
+  const int halo_rows = t->t_pitch - t->frames;
+  if (halo_rows == 0) return ST_OK;
+  const long total = (long)halo_rows * (t->c_pitch / 4);
+  const int bx = (int)std::min<long>((total + 255) / 256, 64);
+  hipLaunchKernelGGL(zero_halos_kernel, dim3(bx, t->batch), dim3(256), 0, st::as_stream(stream), t->base, t->frames,
+                     t->halo, t->t_pitch, t->c_pitch);
+  return st::check_launch("zero_halos");
 }
 
 int st_pack_filters_f32(const float* filters, int width, int cin, int cout, int cin_pitch,

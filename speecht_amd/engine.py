@@ -32,15 +32,19 @@ def same_padding(t_in, width, stride):
 
 
 class DevTensor3:
-  """A zero-initialised padded NWC buffer plus its st_tensor3 descriptor."""
+  """A padded NWC view (st_tensor3 descriptor) over a slice of persistent device storage."""
 
-  def __init__(self, batch, frames, channels, halo_l, halo_r, device):
+  def __init__(self, storage, batch, frames, channels, halo_l, halo_r):
     self.batch, self.frames, self.channels = batch, frames, channels
     self.halo = halo_l
     self.c_pitch = _round_up(channels, 16)
     self.t_pitch = halo_l + frames + halo_r
-    self.buf = torch.zeros(batch * self.t_pitch * self.c_pitch, dtype=torch.float32, device=device)
+    self.buf = storage[:batch * self.t_pitch * self.c_pitch]
     self.desc = Tensor3(self.buf.data_ptr(), batch, frames, channels, halo_l, self.t_pitch, self.c_pitch)
+
+  @staticmethod
+  def numel(batch, frames, channels, halo_l, halo_r):
+    return batch * (halo_l + frames + halo_r) * _round_up(channels, 16)
 
   @property
   def ref(self):
@@ -50,6 +54,26 @@ class DevTensor3:
     """[B, T, C] strided view of the valid region."""
     v = self.buf.view(self.batch, self.t_pitch, self.c_pitch)
     return v[:, self.halo:self.halo + self.frames, :self.channels]
+
+
+class _Storage:
+  """Grow-only named device buffers: real training batches change (B, max_T) every step, so the
+  activation buffers are re-described per shape instead of re-allocated; only the halo rows have to
+  be re-zeroed (interiors are fully overwritten by the producing kernel)."""
+
+  def __init__(self, device):
+    self.device = device
+    self.bufs = {}
+
+  def view(self, name, numel, dtype=None):
+    import torch as _t
+    dtype = dtype or _t.float32
+    cur = self.bufs.get(name)
+    fresh = cur is None or cur.numel() < numel
+    if fresh:
+      cur = _t.zeros(max(numel, 1), dtype=dtype, device=self.device)
+      self.bufs[name] = cur
+    return cur, fresh
 
 
 class LayerSpec:
@@ -93,6 +117,8 @@ class Wav2LetterEngine:
                                device=self.device)
     self.step_count = 0
     self._shape = None
+    self._storage = _Storage(self.device)
+    self.ctc_ws = None
 
   # ---- plumbing --------------------------------------------------------------------------
   @property
@@ -152,6 +178,16 @@ class Wav2LetterEngine:
     self.set_weights(params)
 
   # ---- activation buffers ------------------------------------------------------------------
+  def _tensor(self, name, batch, frames, channels, halo_l, halo_r, clear=False):
+    storage, fresh = self._storage.view(name, DevTensor3.numel(batch, frames, channels, halo_l, halo_r))
+    t = DevTensor3(storage, batch, frames, channels, halo_l, halo_r)
+    if not fresh:
+      if clear:
+        t.buf.zero_()
+      else:
+        call('st_zero_halos_f32', t.ref, self.stream_ptr)
+    return t
+
   def _ensure_shape(self, batch, frames):
     if self._shape == (batch, frames):
       return
@@ -167,24 +203,23 @@ class Wav2LetterEngine:
     for i, l in enumerate(self.layers):
       t_in, t_out, pl, pr = geo[i]
       halo_r = max(pr, (t_out - 1) * l.stride + l.width - pl - t_in)
-      self.X.append(DevTensor3(batch, t_in, l.cin, pl, halo_r, dev))
+      # X[0]'s pad channels are not written by any kernel: clear the whole view on re-use
+      self.X.append(self._tensor('X%d' % i, batch, t_in, l.cin, pl, halo_r, clear=(i == 0)))
       # gradient wrt this layer's pre-activation output; halo for its own back-prop-to-input conv
-      self.dZ.append(DevTensor3(batch, t_out, l.cout, l.width - 1 - pl, pl, dev))
+      self.dZ.append(self._tensor('dZ%d' % i, batch, t_out, l.cout, l.width - 1 - pl, pl))
     last = self.layers[-1]
-    self.X.append(DevTensor3(batch, geo[-1][1], last.cout, 0, 0, dev))     # logits [B, T', C]
+    self.X.append(self._tensor('X%d' % len(self.layers), batch, geo[-1][1], last.cout, 0, 0))   # logits [B, T', C]
     self.t_out = geo[-1][1]
     lib = _lib.load()
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
     ws = max([ws] + [lib.st_conv1d_bwd_data_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
-    self.wgrad_ws = torch.zeros(ws // 4 + 64, dtype=torch.float32, device=dev)
-    self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
-    self.ctc_status = torch.zeros(batch, dtype=torch.int32, device=dev)
-    self.ctc_ws = None
-    self._ctc_lmax = -1
-    self.dec_ids = torch.zeros(batch * self.t_out, dtype=torch.int32, device=dev)
-    self.dec_lens = torch.zeros(batch, dtype=torch.int32, device=dev)
-    self.dec_score = torch.zeros(batch, dtype=torch.float32, device=dev)
+    self.wgrad_ws, _ = self._storage.view('wgrad_ws', ws // 4 + 64)
+    self.loss = self._storage.view('loss', batch)[0][:batch]
+    self.ctc_status = self._storage.view('ctc_status', batch, torch.int32)[0][:batch]
+    self.dec_ids = self._storage.view('dec_ids', batch * self.t_out, torch.int32)[0][:batch * self.t_out]
+    self.dec_lens = self._storage.view('dec_lens', batch, torch.int32)[0][:batch]
+    self.dec_score = self._storage.view('dec_score', batch)[0][:batch]
     self._shape = (batch, frames)
 
   # ---- the path ----------------------------------------------------------------------------

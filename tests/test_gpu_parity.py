@@ -276,3 +276,29 @@ def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
   if n_mels == 80 and sr == 16000:
     gold = np.load(os.path.join(golden_dir, 'w2l_small_golden.npz'))['mel80']
     assert np.max(np.abs(feats[0] - gold)) < 1e-3
+
+
+def test_shape_switching_reuses_buffers_exactly(dev):
+  """Real batches change (B, max_T) every step: buffers are re-described, halos re-zeroed.  Results
+  after switching shapes must be bit-identical to a fresh engine's."""
+  layers = WL.w2l_layers(16, width=40, fc=72)
+  params = WL.xavier_params(layers, seed=9)
+  shapes = [[97, 80, 61], [33, 20], [140, 139, 101, 50], [33, 20], [97, 80, 61]]
+  eng = make_engine(layers, dev)
+  eng.set_weights(params)
+  for k, frames in enumerate(shapes):
+    x, seq, labels = WL.make_batch(frames, 16, seed=20 + len(frames))
+    outs = []
+    for e in (eng, make_engine(layers, dev)):
+      if e is not eng:
+        e.set_weights(params)
+      e.load_batch(x, seq)
+      e.set_labels(labels)
+      e.forward()
+      e.ctc_loss_grad(1.0 / len(frames))
+      e.backward()
+      torch.cuda.synchronize()
+      outs.append((e.X[-1].interior().clone(), e.grads.clone(), e.loss.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), k
+    assert torch.equal(outs[0][1], outs[1][1]), k
+    assert torch.equal(outs[0][2], outs[1][2]), k

@@ -161,13 +161,15 @@ def main():
   ap.add_argument('--seconds', type=float, default=10.0)
   ap.add_argument('--mels', type=int, default=80)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--force-allreduce', action='store_true', help='run the RCCL all-reduce path even on 1 rank (self-test)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world > 1:
+  if world > 1 or args.force_allreduce:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -183,7 +185,7 @@ def main():
   eng.load_batch(x, seq_lens)
   eng.set_labels(labels)
   x_dev = torch.as_tensor(x, dtype=torch.float32).to(dev)
-  reducer = GradientAllReducer(eng.grads, eng.layer_ranges) if world > 1 else None
+  reducer = GradientAllReducer(eng.grads, eng.layer_ranges, force=args.force_allreduce) if (world > 1 or args.force_allreduce) else None
   global_batch = args.batch * world
   lr = 1e-4
 
@@ -231,7 +233,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))
-  if world > 1:
+  if dist.is_initialized():
     dist.destroy_process_group()
 
 

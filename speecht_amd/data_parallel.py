@@ -42,17 +42,18 @@ def default_buckets(layer_sizes, layer_offsets):
 class GradientAllReducer:
   """Sum-all-reduces slices of one flat gradient tensor as back-prop completes them."""
 
-  def __init__(self, flat_grads, layer_offsets, group=None):
+  def __init__(self, flat_grads, layer_offsets, group=None, force=False):
     self.flat = flat_grads
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the collective on 1 rank
     sizes = [e - s for s, e in layer_offsets]
     self.buckets = default_buckets(sizes, layer_offsets)
     self._ready_at = {lo: (s, e) for lo, s, e in self.buckets}
     self._pending = []
 
   def on_layer_done(self, i):
-    if self.world == 1 or i not in self._ready_at:
+    if not self.active or i not in self._ready_at:
       return
     s, e = self._ready_at[i]
     self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -7,13 +7,18 @@
 // Semantics: SURVEY Appendix A7-A9 (center=True reflect padding, periodic Hann, power 2,
 // amin 1e-10, top_db 80, population std).
 //
-// Kernel 1 (one workgroup per frame): gather 512 reflect-padded samples (coalesced), window,
-// 512-point radix-2 Stockham FFT in LDS, |.|^2 of the 257 bins, mel projection against the
-// L2-resident basis, per-utterance running max by integer atomicMax (order independent).
-// Kernel 2 (one workgroup per utterance): dB conversion with the utterance max as reference,
-// -80 dB floor, mean and population std by fixed-shape tree sums in double (deterministic),
-// normalised write-out in the reference's [time, n_mels] layout.  HBM-bound: 640 KB in,
-// 320 KB out per 10 s utterance.
+// mel_ranges_kernel : first/last non-zero bin of every triangular filter (they are sparse:
+//                     ~2*257 non-zeros in an [n_mels x 257] basis).
+// mel_frame_kernel  : a workgroup walks FPB consecutive frames of one utterance: coalesced gather of
+//                     the 512 reflect-padded samples, Hann window, 512-point radix-2 Stockham FFT in
+//                     LDS with twiddles tabulated once per workgroup, |.|^2, sparse mel projection,
+//                     running max (integer atomicMax: order independent) for the dB reference.
+// mel_stats_kernel  : dB + -80 dB floor, per-utterance sum / sum of squares in double, fixed-shape
+//                     partials (deterministic).
+// mel_finish_kernel : mean / population std from the partials, normalised write in the reference's
+//                     [time, n_mels] layout.
+// Roofline: 640 KB in + 320 KB out per 10 s utterance (HBM floor ~0.1 us); in practice bound by the
+// FFT's LDS passes and launch latency, reported separately from the training step by bench.py.
 #include <algorithm>
 
 #include "st_common.h"
@@ -22,67 +27,93 @@ namespace {
 
 constexpr int NFFT = 512;
 constexpr int NBINS = NFFT / 2 + 1;
+constexpr int FPB = 8;          // frames per workgroup
+constexpr int STAT_CHUNKS = 64; // partial sums per utterance
+
+__global__ void mel_ranges_kernel(const float* __restrict__ basis, int n_mels, int* __restrict__ ranges) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_mels) return;
+  const float* row = basis + (long)m * NBINS;
+  int lo = NBINS, hi = 0;
+  for (int k = 0; k < NBINS; ++k)
+    if (row[k] != 0.f) { lo = min(lo, k); hi = k + 1; }
+  ranges[2 * m] = min(lo, hi);
+  ranges[2 * m + 1] = hi;
+}
 
 __global__ __launch_bounds__(256) void mel_frame_kernel(const float* __restrict__ audio,
                                                         const long* __restrict__ sample_off,
-                                                        const float* __restrict__ basis, int n_mels, int hop,
+                                                        const float* __restrict__ basis,
+                                                        const int* __restrict__ ranges, int n_mels, int hop,
                                                         const long* __restrict__ frame_off,
                                                         float* __restrict__ melpow, unsigned* __restrict__ umax) {
   __shared__ float re[2][NFFT];
   __shared__ float im[2][NFFT];
+  __shared__ float twr[NFFT / 2], twi[NFFT / 2];   // W512^k = exp(-2*pi*i*k/512)
   __shared__ float pw[NBINS + 3];
   __shared__ float wmax[4];
   const int u = blockIdx.y;
   const long s0 = sample_off[u];
   const int n = (int)(sample_off[u + 1] - s0);
   const int frames = 1 + n / hop;
-  const int t = blockIdx.x;
-  if (t >= frames) return;
+  const int t_begin = blockIdx.x * FPB;
+  if (t_begin >= frames) return;
   const int tid = threadIdx.x;
   const float* y = audio + s0;
-
-  // windowed frame; centre=True: padded index p = t*hop + k  <->  sample p - NFFT/2, reflected
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int k = tid + 256 * r;
-    int j = t * hop + k - NFFT / 2;
-    if (j < 0) j = -j;
-    if (j >= n) j = 2 * (n - 1) - j;
-    j = min(max(j, 0), n - 1);
-    const float w = 0.5f - 0.5f * cospif(2.0f * (float)k / (float)NFFT);
-    re[0][k] = y[j] * w;
-    im[0][k] = 0.f;
-  }
-  __syncthreads();
-
-  // Stockham autosort radix-2 (decimation in frequency): 9 stages, one butterfly per thread per
-  // stage, result in natural order.  stage st: stride s = 2^st, current length n = NFFT >> st.
-  int cur = 0;
-#pragma unroll
-  for (int st = 0; st < 9; ++st) {
-    const int s = 1 << st;
-    const int p = tid >> st, q = tid & (s - 1);
+  {
     float sn, cs;
-    sincospif(-2.0f * (float)p / (float)(NFFT >> st), &sn, &cs);      // w = exp(-2*pi*i*p/n)
-    const float ar = re[cur][tid], ai = im[cur][tid];
-    const float br = re[cur][tid + NFFT / 2], bi = im[cur][tid + NFFT / 2];
-    const float dr = ar - br, di = ai - bi;
-    const int o0 = q + s * 2 * p, o1 = o0 + s;
-    re[cur ^ 1][o0] = ar + br; im[cur ^ 1][o0] = ai + bi;
-    re[cur ^ 1][o1] = dr * cs - di * sn; im[cur ^ 1][o1] = dr * sn + di * cs;
-    __syncthreads();
-    cur ^= 1;
+    sincospif(-2.0f * (float)tid / (float)NFFT, &sn, &cs);
+    twr[tid] = cs;
+    twi[tid] = sn;
   }
-  for (int k = tid; k < NBINS; k += 256) pw[k] = re[cur][k] * re[cur][k] + im[cur][k] * im[cur][k];
+  const float w0 = 0.5f - 0.5f * cospif(2.0f * (float)tid / (float)NFFT);            // periodic Hann
+  const float w1 = 0.5f - 0.5f * cospif(2.0f * (float)(tid + 256) / (float)NFFT);
+  int m_lo = 0, m_hi = 0;
+  if (tid < n_mels) { m_lo = ranges[2 * tid]; m_hi = ranges[2 * tid + 1]; }
+  const float* brow = basis + (long)min(tid, n_mels - 1) * NBINS;
+  float vmax = 0.f;
   __syncthreads();
 
-  float vmax = 0.f;
-  for (int m = tid; m < n_mels; m += 256) {
-    const float* row = basis + (long)m * NBINS;
-    float acc = 0.f;
-    for (int k = 0; k < NBINS; ++k) acc = fmaf(row[k], pw[k], acc);
-    melpow[(frame_off[u] + t) * (long)n_mels + m] = acc;
-    vmax = fmaxf(vmax, acc);
+  const int t_end = min(frames, t_begin + FPB);
+  for (int t = t_begin; t < t_end; ++t) {
+    // windowed frame; centre=True: padded index p = t*hop + k  <->  sample p - NFFT/2, reflected
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = tid + 256 * r;
+      int j = t * hop + k - NFFT / 2;
+      if (j < 0) j = -j;
+      if (j >= n) j = 2 * (n - 1) - j;
+      j = min(max(j, 0), n - 1);
+      re[0][k] = y[j] * (r ? w1 : w0);
+      im[0][k] = 0.f;
+    }
+    __syncthreads();
+    // Stockham autosort radix-2 (decimation in frequency): 9 stages, one butterfly per thread per
+    // stage, natural-order result.  stage st: stride s = 2^st, twiddle W_n^p = W512^(p << st).
+    int cur = 0;
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+      const int s = 1 << st;
+      const int p = tid >> st, q = tid & (s - 1);
+      const float cs = twr[p << st], sn = twi[p << st];
+      const float ar = re[cur][tid], ai = im[cur][tid];
+      const float br = re[cur][tid + NFFT / 2], bi = im[cur][tid + NFFT / 2];
+      const float dr = ar - br, di = ai - bi;
+      const int o0 = q + s * 2 * p, o1 = o0 + s;
+      re[cur ^ 1][o0] = ar + br; im[cur ^ 1][o0] = ai + bi;
+      re[cur ^ 1][o1] = dr * cs - di * sn; im[cur ^ 1][o1] = dr * sn + di * cs;
+      __syncthreads();
+      cur ^= 1;
+    }
+    for (int k = tid; k < NBINS; k += 256) pw[k] = re[cur][k] * re[cur][k] + im[cur][k] * im[cur][k];
+    __syncthreads();
+    if (tid < n_mels) {
+      float acc = 0.f;
+      for (int k = m_lo; k < m_hi; ++k) acc = fmaf(brow[k], pw[k], acc);
+      melpow[(frame_off[u] + t) * (long)n_mels + tid] = acc;
+      vmax = fmaxf(vmax, acc);
+    }
+    // (n_mels > 256 is rejected by the host wrapper)
   }
   vmax = st::wave_max(vmax);
   if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
@@ -105,33 +136,65 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
   return t;
 }
 
-__global__ __launch_bounds__(1024) void mel_normalize_kernel(const float* __restrict__ melpow,
-                                                             const long* __restrict__ sample_off,
-                                                             const long* __restrict__ frame_off, int n_mels,
-                                                             int hop, const unsigned* __restrict__ umax,
-                                                             float* __restrict__ out) {
-  __shared__ double red[16];
-  const int u = blockIdx.x;
+// power_to_db(ref = max, amin 1e-10, top_db 80): the maximum of the dB matrix is 0 by construction
+__device__ __forceinline__ float to_db(float s, float ref_db) {
+  return fmaxf(10.f * log10f(fmaxf(1e-10f, s)) - ref_db, -80.f);
+}
+
+__global__ __launch_bounds__(256) void mel_stats_kernel(const float* __restrict__ melpow,
+                                                        const long* __restrict__ sample_off,
+                                                        const long* __restrict__ frame_off, int n_mels, int hop,
+                                                        const unsigned* __restrict__ umax,
+                                                        double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int u = blockIdx.y;
   const int n = (int)(sample_off[u + 1] - sample_off[u]);
   const long count = (long)(1 + n / hop) * n_mels;
   const float* src = melpow + frame_off[u] * (long)n_mels;
-  float* dst = out + frame_off[u] * (long)n_mels;
-  const float amin = 1e-10f;
-  const float ref_db = 10.f * log10f(fmaxf(amin, __uint_as_float(umax[u])));
-  // max over the matrix of (10 log10(max(amin,S)) - ref_db) is attained at S = max(S):
-  const float top = 10.f * log10f(fmaxf(amin, __uint_as_float(umax[u]))) - ref_db;   // == 0
-  const float floor_db = top - 80.f;
-  auto db = [&](float s) { return fmaxf(10.f * log10f(fmaxf(amin, s)) - ref_db, floor_db); };
-  double sum = 0.0;
-  for (long i = threadIdx.x; i < count; i += blockDim.x) sum += (double)db(src[i]);
-  const double mean = block_sum_d(sum, red) / (double)count;
-  double ss = 0.0;
-  for (long i = threadIdx.x; i < count; i += blockDim.x) { double d = (double)db(src[i]) - mean; ss += d * d; }
-  const double var = block_sum_d(ss, red) / (double)count;
+  const float ref_db = 10.f * log10f(fmaxf(1e-10f, __uint_as_float(umax[u])));
+  const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  const long lo = blockIdx.x * per, hi = min(count, lo + per);
+  double s = 0.0, ss = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const double d = (double)to_db(src[i], ref_db);
+    s += d;
+    ss += d * d;
+  }
+  s = block_sum_d(s, red);
+  ss = block_sum_d(ss, red);
+  if (threadIdx.x == 0) {
+    partial[((long)u * STAT_CHUNKS + blockIdx.x) * 2] = s;
+    partial[((long)u * STAT_CHUNKS + blockIdx.x) * 2 + 1] = ss;
+  }
+}
+
+__global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict__ melpow,
+                                                         const long* __restrict__ sample_off,
+                                                         const long* __restrict__ frame_off, int n_mels, int hop,
+                                                         const unsigned* __restrict__ umax,
+                                                         const double* __restrict__ partial,
+                                                         float* __restrict__ out) {
+  const int u = blockIdx.y;
+  const int n = (int)(sample_off[u + 1] - sample_off[u]);
+  const long count = (long)(1 + n / hop) * n_mels;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < STAT_CHUNKS; ++c) {          // same order in every block: deterministic
+    s += partial[((long)u * STAT_CHUNKS + c) * 2];
+    ss += partial[((long)u * STAT_CHUNKS + c) * 2 + 1];
+  }
+  const double mean = s / (double)count;
+  const double var = fmax(ss / (double)count - mean * mean, 0.0);
   const float inv_std = (float)(1.0 / sqrt(var));
   const float meanf = (float)mean;
-  for (long i = threadIdx.x; i < count; i += blockDim.x) dst[i] = (db(src[i]) - meanf) * inv_std;
+  const float* src = melpow + frame_off[u] * (long)n_mels;
+  float* dst = out + frame_off[u] * (long)n_mels;
+  const float ref_db = 10.f * log10f(fmaxf(1e-10f, __uint_as_float(umax[u])));
+  const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  const long lo = blockIdx.x * per, hi = min(count, lo + per);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) dst[i] = (to_db(src[i], ref_db) - meanf) * inv_std;
 }
+
+size_t pow_bytes(int64_t total_frames, int n_mels) { return st::round_up((size_t)total_frames * n_mels * sizeof(float), 256); }
 
 }  // namespace
 
@@ -139,7 +202,8 @@ extern "C" {
 
 size_t st_melspec_ws(int n_utts, int64_t total_frames, int n_mels) {
   if (n_utts <= 0 || total_frames <= 0 || n_mels <= 0) return 0;
-  return st::round_up((size_t)total_frames * n_mels * sizeof(float), 256) + st::round_up((size_t)n_utts * 4, 256);
+  return pow_bytes(total_frames, n_mels) + st::round_up((size_t)n_utts * 4, 256) +
+         st::round_up((size_t)n_mels * 2 * sizeof(int), 256) + (size_t)n_utts * STAT_CHUNKS * 2 * sizeof(double);
 }
 
 int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
@@ -147,23 +211,32 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
                    int64_t total_frames, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(audio && sample_offsets && mel_basis && frame_offsets && out && workspace, "melspec: null argument");
   ST_REQUIRE(n_fft == NFFT, "melspec: only n_fft = 512 (the reference default, preprocessing.py:36) is built");
-  ST_REQUIRE(n_utts > 0 && n_mels > 0 && hop > 0 && max_samples > NFFT / 2 && total_frames > 0, "melspec: bad shape");
+  ST_REQUIRE(n_utts > 0 && n_mels > 0 && n_mels <= 256 && hop > 0 && max_samples > NFFT / 2 && total_frames > 0,
+             "melspec: bad shape");
   ST_REQUIRE(workspace_bytes >= st_melspec_ws(n_utts, total_frames, n_mels), "melspec: workspace too small");
   hipStream_t s = st::as_stream(stream);
-  float* melpow = reinterpret_cast<float*>(workspace);
-  unsigned* umax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) +
-                                               st::round_up((size_t)total_frames * n_mels * sizeof(float), 256));
+  char* w = reinterpret_cast<char*>(workspace);
+  float* melpow = reinterpret_cast<float*>(w);
+  w += pow_bytes(total_frames, n_mels);
+  unsigned* umax = reinterpret_cast<unsigned*>(w);
+  w += st::round_up((size_t)n_utts * 4, 256);
+  int* ranges = reinterpret_cast<int*>(w);
+  w += st::round_up((size_t)n_mels * 2 * sizeof(int), 256);
+  double* partial = reinterpret_cast<double*>(w);
   if (hipMemsetAsync(umax, 0, (size_t)n_utts * 4, s) != hipSuccess) {
     st::set_error("melspec: memset failed");
     return ST_ELAUNCH;
   }
+  const long* soff = reinterpret_cast<const long*>(sample_offsets);
+  const long* foff = reinterpret_cast<const long*>(frame_offsets);
   const unsigned max_frames = (unsigned)(1 + max_samples / hop);
-  hipLaunchKernelGGL(mel_frame_kernel, dim3(max_frames, n_utts), dim3(256), 0, s, audio,
-                     reinterpret_cast<const long*>(sample_offsets), mel_basis, n_mels, hop,
-                     reinterpret_cast<const long*>(frame_offsets), melpow, umax);
-  hipLaunchKernelGGL(mel_normalize_kernel, dim3(n_utts), dim3(1024), 0, s, melpow,
-                     reinterpret_cast<const long*>(sample_offsets), reinterpret_cast<const long*>(frame_offsets),
-                     n_mels, hop, umax, out);
+  hipLaunchKernelGGL(mel_ranges_kernel, dim3(st::ceil_div(n_mels, 64)), dim3(64), 0, s, mel_basis, n_mels, ranges);
+  hipLaunchKernelGGL(mel_frame_kernel, dim3(st::ceil_div((int)max_frames, FPB), n_utts), dim3(256), 0, s, audio, soff,
+                     mel_basis, ranges, n_mels, hop, foff, melpow, umax);
+  hipLaunchKernelGGL(mel_stats_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, melpow, soff, foff, n_mels, hop,
+                     umax, partial);
+  hipLaunchKernelGGL(mel_finish_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, melpow, soff, foff, n_mels, hop,
+                     umax, partial, out);
   return st::check_launch("melspec");
 }
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int NORM_EVERY = 4;   // re-centre the lattice column every 4 frames
+constexpr int NORM_EVERY = 4;   // re-centre the lattice column every 4 frames (every frame measured no more accurate)
 
 // log2-softmax of every (b, t) row into the scratch [B*T][32]
 __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __restrict__ logits, RowMap2 map,

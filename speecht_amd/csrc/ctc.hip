@@ -324,17 +324,24 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   for (int k = 0; k < GF / 4; ++k) {
     const int t = blockIdx.x * GF + k * 4 + wave;
     const bool live = !bad && t < Tb && t < T;
-    float blank_sum = 0.f;
+    float blank_sum = 0.f, occ_scale = 1.f;
     if (live) {
       const float* al = alpha + ((long)b * T + t) * UP;
       const float* be = beta + ((long)b * T + t) * UP;
       const float shift = (float)(aoff[(long)b * T + t] + boff[(long)b * T + t] - logp2);
+      float label_sum = 0.f;
       for (int u = lane; u < U; u += 64) {
         const int i = sidx(u);
         float w = ex2(al[i] + be[i] + shift);
-        if (u & 1) wb[u >> 1] = w; else blank_sum += w;
+        if (u & 1) { wb[u >> 1] = w; label_sum += w; } else blank_sum += w;
       }
       blank_sum = st::wave_sum(blank_sum);
+      // sum_u alpha_t(u) beta_t(u) == p(l|x) for EVERY t; the recursions accumulate the (biased)
+      // 1-ULP error of v_exp/v_log over hundreds of dependent steps, so the per-frame sum can be off
+      // by ~1e-4 relative.  Normalising by the frame's own total removes that common factor.
+      const float total = blank_sum + st::wave_sum(label_sum);
+      occ_scale = total > 0.f ? 1.f / total : 1.f;
+      blank_sum *= occ_scale;
     }
     __syncthreads();
     if (t < T && lane < gcols) {
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         if (lane < blank) {
           occ = 0.f;
           for (int i = pos_off[lane]; i < pos_off[lane + 1]; ++i) occ += wb[pos_list[i]];
+          occ *= occ_scale;
         }
         g = (ex2(logy[((long)b * T + t) * CP + lane]) - occ) * scale;
       }

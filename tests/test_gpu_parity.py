@@ -135,8 +135,8 @@ def test_ctc_loss_grad(dev, T, lengths):
   ref_loss, ref_grad = O.ctc_loss_and_grad(logits, labels, lens)
   eng, loss, grad = run_ctc(dev, logits, labels, lens, scale=0.5)
   assert not eng.ctc_status.cpu().numpy().any()
-  np.testing.assert_allclose(loss, ref_loss, rtol=1e-4)
-  assert np.max(np.abs(grad - 0.5 * ref_grad)) < 2e-4
+  np.testing.assert_allclose(loss, ref_loss, rtol=1e-5)
+  assert np.max(np.abs(grad - 0.5 * ref_grad)) < 5e-5
   for b in range(B):
     assert np.all(grad[lens[b]:, b] == 0)
 
@@ -306,19 +306,18 @@ def test_shape_switching_reuses_buffers_exactly(dev):
 
 def test_ctc_long_form_kpl16(dev):
   """BASELINE config 5 shape: 30 s utterances -> T' = 1500 frames, ~450 labels (U = 901, 16 lattice
-  states per lane).  Loss: 1e-6 relative (measured 1.2e-7).  Gradient: 1e-3 absolute -- the residual
-  (measured 6e-4, uniform over t) is the accumulated 1-ULP bias of v_exp_f32/v_log_f32 over 1500
-  dependent steps, independent of the re-centring period; TF's own fp32 log-space recursion carries
-  ulp(|log p|) ~ 5e-4 PER STEP at this length."""
+  states per lane).  Loss 1e-6 relative (measured 8e-8), gradient 2e-4 absolute (measured 9e-5).
+  Without the per-frame occupancy normalisation of ctc_grad_kernel the gradient error is 6e-4: the
+  accumulated 1-ULP bias of v_exp_f32/v_log_f32 over 1500 dependent steps."""
   rng = np.random.default_rng(77)
   T, lengths = 1500, [450, 400]
   logits, labels, lens = _ctc_case(rng, 2, T, 29, lengths, [1500, 1377])
   ref_loss, ref_grad = O.ctc_loss_and_grad(logits, labels, lens)
   eng, loss, grad = run_ctc(dev, logits, labels, lens)
   np.testing.assert_allclose(loss, ref_loss, rtol=1e-6)
-  assert np.max(np.abs(grad - ref_grad)) < 1e-3
+  assert np.max(np.abs(grad - ref_grad)) < 2e-4
   live = np.arange(T)[:, None] < np.asarray(lens)[None, :]
-  assert np.max(np.abs(grad.sum(axis=2)[live])) < 1e-3          # occupancies sum to one
+  assert np.max(np.abs(grad.sum(axis=2)[live])) < 2e-6          # occupancies sum to one
 
 
 def test_bucketed_inference_matches_oracle_per_bucket(dev):

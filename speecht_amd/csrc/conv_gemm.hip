@@ -122,6 +122,7 @@ template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v 
 
 template <int BM, int BN, int WMW, int WNW, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
+  constexpr bool SGB = true;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int A_DMA = BM / 32;            // DMA instructions per wave for the [BM][32] A stage
@@ -278,7 +279,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
         for (int pc = q; pc < N_DMA; pc += 4) dma_piece(pc, nk0, cur ^ 1);
       }
       if (q < 3) read_frags(q + 1);
-      __builtin_amdgcn_sched_barrier(0);
       if (q < nq) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -287,6 +287,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
               acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+      }
+      if (SGB) {
+        // interleave request: one ds_read behind each of the first MFMAs, then the address VALU and
+        // one DMA behind later MFMAs (each MFMA shadows ~64 issue cycles)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -49,6 +49,15 @@ _SIGNATURES = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+# experimental entry points (csrc/conv_bf16x6.hip): not part of include/speecht_hip.h yet
+_EXPERIMENTAL = {
+    'st_exp_split3_bf16': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    'st_exp_split3_transpose_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'st_exp_conv1d_fwd_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P,
+                                         c_void_p, c_void_p]),
+    'st_exp_conv1d_bwd_data_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p]),
+}
+
 _lib = None
 
 
@@ -67,7 +76,7 @@ def load():
       raise SpeechtHipError('{} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                             '(there is no CPU fallback)'.format(LIB_PATH))
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_EXPERIMENTAL.items()):
       fn = getattr(lib, name)
       fn.restype = res
       fn.argtypes = args

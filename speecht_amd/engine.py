@@ -12,6 +12,7 @@ HBM layout (DESIGN.md "Data layout"):
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -92,8 +93,12 @@ class LayerSpec:
 class Wav2LetterEngine:
   """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
 
-  def __init__(self, layers, device='cuda:0', stream=None):
+  def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None):
     _lib.load()
+    # 'fp32': exact-f32 MFMA kernels (default).  'bf16x6': EXPERIMENTAL fp32-accurate split-bf16 path
+    # (csrc/conv_bf16x6.hip) for forward and back-prop-to-input of the wide layers.
+    self.conv_mode = conv_mode or os.environ.get('ST_CONV_MODE', 'fp32')
+    assert self.conv_mode in ('fp32', 'bf16x6'), self.conv_mode
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -119,6 +124,8 @@ class Wav2LetterEngine:
     self._shape = None
     self._storage = _Storage(self.device)
     self.ctc_ws = None
+    self._wplanes_fresh = False
+    self._wtplanes_fresh = False
 
   # ---- plumbing --------------------------------------------------------------------------
   @property
@@ -151,6 +158,7 @@ class Wav2LetterEngine:
       pb[:l.cout] = torch.as_tensor(np.asarray(b), dtype=torch.float32).to(self.device)
     torch.cuda.synchronize(self.device)
     self._packed_t_fresh = False
+    self._wplanes_fresh = False
 
   def _unpack(self, flat):
     out = []
@@ -220,7 +228,47 @@ class Wav2LetterEngine:
     self.dec_ids = self._storage.view('dec_ids', batch * self.t_out, torch.int32)[0][:batch * self.t_out]
     self.dec_lens = self._storage.view('dec_lens', batch, torch.int32)[0][:batch]
     self.dec_score = self._storage.view('dec_score', batch)[0][:batch]
+    if self.conv_mode == 'bf16x6':
+      self._alloc_planes()
     self._shape = (batch, frames)
+
+  # ---- bf16x6 (experimental) ------------------------------------------------------------------
+  def _x6_fwd(self, i):
+    return self.conv_mode == 'bf16x6' and self.layers[i].n_pad % 128 == 0
+
+  def _x6_bwd(self, i):
+    l = self.layers[i]
+    return self.conv_mode == 'bf16x6' and i > 0 and l.nt_pad % 128 == 0 and l.width * l.cout_pitch >= 256
+
+  def _planes(self, name, numel):
+    """3 zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
+    buf, fresh = self._storage.view(name, 3 * numel, torch.bfloat16)
+    v = buf[:3 * numel]
+    if not fresh:
+      v.zero_()
+    return v
+
+  def _alloc_planes(self):
+    self.Xp = {i: self._planes('Xp%d' % i, self.X[i].buf.numel()) for i in range(len(self.layers)) if self._x6_fwd(i)}
+    self.dZp = {i: self._planes('dZp%d' % i, self.dZ[i].buf.numel()) for i in range(len(self.layers)) if self._x6_bwd(i)}
+    if not hasattr(self, 'Wp'):
+      self.Wp = {i: torch.zeros(3 * l.k_pad * l.n_pad, dtype=torch.bfloat16, device=self.device)
+                 for i, l in enumerate(self.layers) if self._x6_fwd(i)}
+      self.WTp = {i: torch.zeros(3 * l.kt_pad * l.nt_pad, dtype=torch.bfloat16, device=self.device)
+                  for i, l in enumerate(self.layers) if self._x6_bwd(i)}
+
+  def _refresh_wplanes(self):
+    for i, wp in self.Wp.items():
+      l = self.layers[i]
+      pf, _ = self._slice(self.params, i)
+      call('st_exp_split3_transpose_bf16', self._ptr(pf), l.k_pad, l.n_pad, self._ptr(wp), self.stream_ptr)
+    self._wplanes_fresh = True
+
+  def _refresh_wtplanes(self):
+    for i, wp in self.WTp.items():
+      l = self.layers[i]
+      call('st_exp_split3_transpose_bf16', self._ptr(self.packed_t[i]), l.kt_pad, l.nt_pad, self._ptr(wp), self.stream_ptr)
+    self._wtplanes_fresh = True
 
   # ---- the path ----------------------------------------------------------------------------
   def load_batch(self, inputs, seq_lens):
@@ -236,10 +284,22 @@ class Wav2LetterEngine:
 
   def forward(self):
     s = self.stream_ptr
+    x6 = self.conv_mode == 'bf16x6'
+    if x6 and not self._wplanes_fresh:
+      self._refresh_wplanes()
+    if x6 and self._x6_fwd(0):
+      call('st_exp_split3_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xp[0]), s)
     for i, l in enumerate(self.layers):
       pf, pb = self._slice(self.params, i)
-      call('st_conv1d_nwc_fwd_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
-           self.geo[i][2], int(l.relu), self.X[i + 1].ref, s)
+      if x6 and self._x6_fwd(i):
+        if i > 0 and not self._x6_fwd(i - 1):
+          call('st_exp_split3_bf16', self._ptr(self.X[i].buf), self.X[i].buf.numel(), self._ptr(self.Xp[i]), s)
+        yp = self._ptr(self.Xp[i + 1]) if (i + 1 < len(self.layers) and self._x6_fwd(i + 1)) else None
+        call('st_exp_conv1d_fwd_bf16x6', self.X[i].ref, self._ptr(self.Xp[i]), self._ptr(self.Wp[i]), self._ptr(pb),
+             l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref, yp, s)
+      else:
+        call('st_conv1d_nwc_fwd_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
+             self.geo[i][2], int(l.relu), self.X[i + 1].ref, s)
 
   def logits_time_major(self):
     """[T', B, C] like tf.transpose(outputs, (1, 0, 2)) (speech_model.py:295)."""
@@ -274,6 +334,7 @@ class Wav2LetterEngine:
       call('st_filters_flip_transpose_f32', self._ptr(pf), l.width, l.cin, l.cout, l.cin_pitch, l.cout_pitch,
            self._ptr(self.packed_t[i]), s)
     self._packed_t_fresh = True
+    self._wtplanes_fresh = False
 
   def backward(self, on_layer_done=None):
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
@@ -288,7 +349,16 @@ class Wav2LetterEngine:
            self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       if on_layer_done is not None:
         on_layer_done(i)
-      if i > 0:
+      if i > 0 and self._x6_bwd(i):
+        act = self.X[i].ref if self.layers[i - 1].relu else None
+        if not self._wtplanes_fresh:
+          self._refresh_wtplanes()
+        if not (i + 1 < len(self.layers) and self._x6_bwd(i + 1)):       # producer was not on this path
+          call('st_exp_split3_bf16', self._ptr(self.dZ[i].buf), self.dZ[i].buf.numel(), self._ptr(self.dZp[i]), s)
+        dxp = self._ptr(self.dZp[i - 1]) if self._x6_bwd(i - 1) else None
+        call('st_exp_conv1d_bwd_data_bf16x6', self.dZ[i].ref, self._ptr(self.dZp[i]), self._ptr(self.WTp[i]), l.width,
+             self.geo[i][2], act, self.dZ[i - 1].ref, dxp, s)
+      elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         act = self.X[i].ref if self.layers[i - 1].relu else None
         call('st_conv1d_nwc_bwd_data_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
@@ -303,6 +373,7 @@ class Wav2LetterEngine:
          self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), float(lr_t), beta1, beta2, eps,
          self._ptr(self.stats), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
     self._packed_t_fresh = False
+    self._wplanes_fresh = False
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

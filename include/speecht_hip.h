@@ -80,6 +80,9 @@ int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int 
                                int pad_left, const st_tensor3* act, const st_tensor3* dx,
                                void* workspace, size_t workspace_bytes, void* stream);
 size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width);
+/* bias gradient alone: dbias[o] = sum_{b,t} dz[b,t,o]  (n_pad floats) */
+size_t st_bias_grad_ws(const st_tensor3* dz);
+int st_bias_grad_f32(const st_tensor3* dz, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int width, int stride,
                                  int pad_left, float* dpacked, float* dbias, void* workspace,
                                  size_t workspace_bytes, void* stream);

@@ -33,6 +33,8 @@ _SIGNATURES = {
     'st_conv1d_bwd_filter_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_filter_f32': (c_int, [_T3P, _T3P, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                              c_size_t, c_void_p]),
+    'st_bias_grad_ws': (c_size_t, [_T3P]),
+    'st_bias_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_ctc_ws': (c_size_t, [c_int, c_int, c_int]),
     'st_ctc_loss_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, _T3P,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -56,6 +58,8 @@ _EXPERIMENTAL = {
     'st_exp_conv1d_fwd_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P,
                                          c_void_p, c_void_p]),
     'st_exp_conv1d_bwd_data_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p]),
+    'st_exp_transpose_split3_bf16': (c_int, [_T3P, c_int, c_int, c_int, c_size_t, c_void_p, c_void_p]),
+    'st_exp_conv1d_bwd_filter_bf16x6': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -70,6 +70,31 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
   }
 }
 
+// src: padded NWC fp32 tensor.  dst planes [c_rows][batch * tq] (reduction-major for the filter
+// gradient): plane[c][b * tq + j] = src[b][row0 + j][c] for j < rows; everything else stays zero.
+__global__ __launch_bounds__(256) void transpose_split3_kernel(const float* __restrict__ src, int rows, int row0,
+                                                               int t_pitch, int c_pitch, int tq, size_t plane,
+                                                               __bf16* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* s = src + ((long)b * t_pitch + row0) * c_pitch;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (j0 + r < rows && c0 + tx < c_pitch) ? s[(long)(j0 + r) * c_pitch + c0 + tx] : 0.f;
+  __syncthreads();
+  const long row_len = (long)gridDim.z * tq;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, j = j0 + tx;
+    if (c < c_pitch && j < rows) {
+      __bf16 h, m, l;
+      split3(tile[tx][r], h, m, l);
+      const size_t o = (size_t)c * row_len + (size_t)b * tq + j;
+      dst[o] = h; dst[plane + o] = m; dst[2 * plane + o] = l;
+    }
+  }
+}
+
 struct RowMapB {
   int frames, row_stride;
   long batch_stride, row0;
@@ -372,6 +397,48 @@ int st_exp_conv1d_bwd_data_bf16x6(const st_tensor3* dz, const void* dz_planes, c
   p.n_store = std::min(dx->c_pitch, p.Np);
   p.taps = width;
   p.cp = dz->c_pitch;
+  return launch_x6(p, st::as_stream(stream));
+}
+
+// planes [c_rows][batch * tq] of a padded tensor, rows [row0, row0 + rows) of every utterance
+int st_exp_transpose_split3_bf16(const st_tensor3* t, int row0, int rows, int tq, size_t plane_elems, void* planes,
+                                 void* stream) {
+  ST_REQUIRE(t && t->base && planes && rows > 0 && row0 >= 0 && row0 + rows <= t->t_pitch && tq >= rows &&
+                 plane_elems >= (size_t)t->c_pitch * t->batch * tq, "transpose_split3: bad args");
+  dim3 grid(st::ceil_div(rows, 32), st::ceil_div(t->c_pitch, 32), t->batch);
+  hipLaunchKernelGGL(transpose_split3_kernel, grid, dim3(256), 0, st::as_stream(stream), t->base, rows, row0, t->t_pitch,
+                     t->c_pitch, tq, plane_elems, reinterpret_cast<__bf16*>(planes));
+  return st::check_launch("transpose_split3");
+}
+
+// filter gradient on the bf16x6 path (stride-1 layers): dF[(w,c)][n] = sum_r XT[c][r + w + lead] * dZT[n][r],
+// r = b * tq + t.  xt_planes: [x.c_pitch][batch*tq (+ slack)], dzt_planes: [n_pad][batch*tq].
+int st_exp_conv1d_bwd_filter_bf16x6(const void* xt_planes, const void* dzt_planes, int batch, int tq, int width,
+                                    int cin_pitch, int x_first_row, int cout, float* dpacked, void* stream) {
+  ST_REQUIRE(xt_planes && dzt_planes && dpacked && tq % 32 == 0 && cin_pitch % 16 == 0, "bwd_filter bf16x6: bad args");
+  X6Params p{};
+  const long red = (long)batch * tq;                   // reduction length
+  p.A = reinterpret_cast<const __bf16*>(xt_planes);
+  p.a_plane = (size_t)cin_pitch * red + 4096;          // planes are allocated with slack behind the last row
+  p.amap.frames = cin_pitch;                           // output row k = w * cin_pitch + c
+  p.amap.batch_stride = 1;                             // tap w shifts the window by one frame
+  p.amap.row_stride = (int)red;                        // channel c selects the plane row
+  p.amap.row0 = x_first_row;
+  p.Np = npad_of(cout);
+  ST_REQUIRE(p.Np % 128 == 0 && red < (1L << 31), "bwd_filter bf16x6: unsupported shape");
+  p.Kvalid = (int)red;
+  p.Kp = (int)red;
+  p.B = reinterpret_cast<const __bf16*>(dzt_planes);
+  p.b_plane = (size_t)p.Np * red;
+  p.C = dpacked;
+  p.M = width * cin_pitch;
+  p.cmap.frames = p.M;
+  p.cmap.batch_stride = 0;
+  p.cmap.row_stride = p.Np;
+  p.cmap.row0 = 0;
+  p.n_store = p.Np;
+  p.taps = 1;
+  p.cp = cin_pitch;
   return launch_x6(p, st::as_stream(stream));
 }
 

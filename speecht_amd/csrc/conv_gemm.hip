@@ -925,6 +925,24 @@ static int bwd_filter_splits(int M, int kp, int np) {
   return best;
 }
 
+size_t st_bias_grad_ws(const st_tensor3* dz) {
+  if (!dz) return 0;
+  return (size_t)dz->batch * st::ceil_div(dz->frames, COLSUM_ROWS) * npad_of(dz->channels) * sizeof(float) + 256;
+}
+
+int st_bias_grad_f32(const st_tensor3* dz, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && dbias && workspace && workspace_bytes >= st_bias_grad_ws(dz), "bias_grad: bad args");
+  hipStream_t s = st::as_stream(stream);
+  const int np = npad_of(dz->channels);
+  const int chunks = st::ceil_div(dz->frames, COLSUM_ROWS);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const RowMap zmap = make_map(*dz, dz->halo, 1, dz->frames);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(st::ceil_div(np, 128), chunks, dz->batch), dim3(256), 0, s, dz->base,
+                     zmap.batch_stride, zmap.row0, zmap.row_stride, dz->frames, dz->channels, dz->c_pitch, partial, np);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(st::ceil_div(np, 32)), dim3(256), 0, s, partial, chunks * dz->batch, np, dbias);
+  return st::check_launch("bias_grad");
+}
+
 size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width) {
   if (!x || !dz) return 0;
   int kp = (int)st::round_up((size_t)width * x->c_pitch, BK), np = npad_of(dz->channels);

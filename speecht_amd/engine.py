@@ -240,6 +240,11 @@ class Wav2LetterEngine:
     l = self.layers[i]
     return self.conv_mode == 'bf16x6' and i > 0 and l.nt_pad % 128 == 0 and l.width * l.cout_pitch >= 256
 
+  def _x6_wgrad(self, i):
+    l = self.layers[i]
+    tiles = -(-(l.width * l.cin_pitch) // 128) * (l.n_pad // 128)
+    return self.conv_mode == 'bf16x6' and i > 0 and l.stride == 1 and l.n_pad % 128 == 0 and tiles >= 192
+
   def _planes(self, name, numel):
     """3 zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
     buf, fresh = self._storage.view(name, 3 * numel, torch.bfloat16)
@@ -251,6 +256,15 @@ class Wav2LetterEngine:
   def _alloc_planes(self):
     self.Xp = {i: self._planes('Xp%d' % i, self.X[i].buf.numel()) for i in range(len(self.layers)) if self._x6_fwd(i)}
     self.dZp = {i: self._planes('dZp%d' % i, self.dZ[i].buf.numel()) for i in range(len(self.layers)) if self._x6_bwd(i)}
+    # filter gradient: transposed (reduction-major) planes of the layer input and of dz
+    self.tq, self.XTp, self.dZTp = {}, {}, {}
+    for i, l in enumerate(self.layers):
+      if self._x6_wgrad(i):
+        tq = _round_up(max(self.X[i].t_pitch, self.dZ[i].frames), 32)
+        red = self.X[i].batch * tq
+        self.tq[i] = tq
+        self.XTp[i] = self._planes('XTp%d' % i, l.cin_pitch * red + 4096)
+        self.dZTp[i] = self._planes('dZTp%d' % i, l.n_pad * red)
     if not hasattr(self, 'Wp'):
       self.Wp = {i: torch.zeros(3 * l.k_pad * l.n_pad, dtype=torch.bfloat16, device=self.device)
                  for i, l in enumerate(self.layers) if self._x6_fwd(i)}
@@ -345,8 +359,18 @@ class Wav2LetterEngine:
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
-      call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
-           self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+      if self.conv_mode == 'bf16x6' and self._x6_wgrad(i):
+        tq, red = self.tq[i], self.X[i].batch * self.tq[i]
+        call('st_exp_transpose_split3_bf16', self.X[i].ref, 0, self.X[i].t_pitch, tq, l.cin_pitch * red + 4096,
+             self._ptr(self.XTp[i]), s)
+        call('st_exp_transpose_split3_bf16', self.dZ[i].ref, self.dZ[i].halo, self.dZ[i].frames, tq, l.n_pad * red,
+             self._ptr(self.dZTp[i]), s)
+        call('st_exp_conv1d_bwd_filter_bf16x6', self._ptr(self.XTp[i]), self._ptr(self.dZTp[i]), self.X[i].batch, tq,
+             l.width, l.cin_pitch, self.X[i].halo - self.geo[i][2], l.cout, self._ptr(gf), s)
+        call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+      else:
+        call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
+             self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       if on_layer_done is not None:
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):

@@ -161,6 +161,7 @@ def main():
   ap.add_argument('--seconds', type=float, default=10.0)
   ap.add_argument('--mels', type=int, default=80)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-alt', action='store_true', help='skip the experimental bf16x6 side measurement')
   ap.add_argument('--force-allreduce', action='store_true', help='run the RCCL all-reduce path even on 1 rank (self-test)')
   args = ap.parse_args()
 
@@ -230,6 +231,26 @@ def main():
       out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
+    if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
+      # Second measurement, NOT the headline: the experimental bf16x6 path (fp32 operands split exactly
+      # into 3 bf16 pieces, 6 cross terms on the bf16 matrix pipe, fp32 accumulate; passes the same
+      # parity tests).  Reported so that the two can be compared on the same box and inputs.
+      alt = Wav2LetterEngine(layers, device=dev, conv_mode='bf16x6')
+      alt.params.copy_(eng.params)
+      alt.load_batch(x, seq_lens)
+      alt.set_labels(labels)
+      for _ in range(args.warmup):
+        train_step(alt, x_dev, None, lr, global_batch)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(args.steps):
+        train_step(alt, x_dev, None, lr, global_batch)
+      torch.cuda.synchronize()
+      alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
+      out['alt_bf16x6'] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),
+                           'dtype': 'f32 operands, exact 3-way bf16 split, 6 bf16 MFMA terms, f32 accumulate',
+                           'note': 'experimental opt-in (ST_CONV_MODE=bf16x6); not the headline value'}
+      del alt
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))

@@ -10,12 +10,6 @@ from tests import workloads as WL
 from scripts.bench_conv import timeit
 
 lib = _lib.load()
-for name, args in [('st_exp_split3_bf16', [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
-                   ('st_exp_split3_transpose_bf16', [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
-                   ('st_exp_conv1d_fwd_bf16x6', [ctypes.POINTER(_lib.Tensor3), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_lib.Tensor3), ctypes.c_void_p])]:
-  getattr(lib, name).restype = ctypes.c_int
-  getattr(lib, name).argtypes = args
 
 layers = WL.w2l_layers(80)
 eng = Wav2LetterEngine(layers, device='cuda:0')
@@ -37,7 +31,7 @@ for i in (1, 8, 9):
   out_store = torch.zeros(Y.buf.numel(), dtype=torch.float32, device='cuda:0')
   Y2 = DevTensor3(out_store, Y.batch, Y.frames, Y.channels, Y.halo, Y.t_pitch - Y.halo - Y.frames)
   run = lambda: _lib.check(lib.st_exp_conv1d_fwd_bf16x6(X.ref, P(xpl), P(wpl), P(pb), l.width, l.stride, eng.geo[i][2],
-                                                        int(l.relu), Y2.ref, None), 'x6')
+                                                        int(l.relu), Y2.ref, None, None), 'x6')
   run(); torch.cuda.synchronize()
   ref, got = Y.interior(), Y2.interior()
   err = float((ref - got).abs().max()); scale = float(ref.abs().max())

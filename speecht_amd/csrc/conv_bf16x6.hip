@@ -323,6 +323,7 @@ static int launch_x6(X6Params& p, hipStream_t s) {
   p.tiles_n = p.Np / BT;
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16x6_kernel<256, 2, 4, 16>), dim3(p.chunk * 8), dim3(512), 0, s, p);
+  else if (big == 16) hipLaunchKernelGGL((gemm_nn_bf16x6_kernel<128, 2, 2, 16>), dim3(p.chunk * 8), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_bf16x6_kernel<128, 2, 2, 32>), dim3(p.chunk * 8), dim3(256), 0, s, p);
   return st::check_launch("gemm_nn_bf16x6");
 }

@@ -123,3 +123,35 @@ def test_fullsize_update_keeps_padding_zero_and_changes_weights(full):
     if l.cin_pitch > l.cin:
       V = P[:l.width * l.cin_pitch].view(l.width, l.cin_pitch, l.n_pad)
       assert float(V[:, l.cin:, :].abs().max()) == 0.0
+
+
+def test_bf16x6_mode_matches_oracle_and_fp32_path():
+  """EXPERIMENTAL bf16x6 convolution path (exact 3-way bf16 split, 6 MFMA terms, fp32 accumulate):
+  same tolerances as the fp32-MFMA path -- logits 1e-4 vs the float64 oracle on a slice, and the two
+  GPU paths within 2e-5 of each other for logits and 1e-3 (relative to the max) for every gradient."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)
+  x, seq, labels = WL.make_batch([401, 333, 401, 250], 80, seed=8)
+  res = {}
+  for mode in ('fp32', 'bf16x6'):
+    eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode=mode)
+    eng.set_weights(params)
+    eng.load_batch(x, seq)
+    eng.set_labels(labels)
+    eng.forward()
+    eng.ctc_loss_grad(0.25)
+    eng.backward()
+    torch.cuda.synchronize()
+    res[mode] = (eng.logits_time_major().cpu().numpy(), eng.loss.cpu().numpy(), eng.get_grads())
+  assert np.max(np.abs(res['fp32'][0] - res['bf16x6'][0])) < 2e-5
+  np.testing.assert_allclose(res['fp32'][1], res['bf16x6'][1], rtol=1e-5)
+  for i, ((gF, gb), (hF, hb)) in enumerate(zip(res['fp32'][2], res['bf16x6'][2])):
+    # two fp32-grade evaluations of an 11-layer chain with ReLU masks: 1e-3 of the tensor max
+    assert np.max(np.abs(gF - hF)) < 1e-3 * np.max(np.abs(gF)), i
+    assert np.max(np.abs(gb - hb)) < 1e-3 * np.max(np.abs(gb)), i
+  params64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  ref = O.wav2letter_forward(x[:1].astype(np.float32).astype(np.float64), params64, layers)
+  assert np.max(np.abs(res['bf16x6'][0][:, :1] - ref)) < 1e-4

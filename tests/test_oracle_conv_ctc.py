@@ -191,3 +191,33 @@ def test_levenshtein():
   assert O.levenshtein('kitten', 'sitting') == 3
   assert O.levenshtein('', 'abc') == 3
   assert O.levenshtein('a b c'.split(), 'a c'.split()) == 1
+
+
+def test_bf16_three_way_split_is_exact_and_six_terms_suffice():
+  """Numerical model of the experimental bf16x6 path (csrc/conv_bf16x6.hip): every fp32 value is the
+  exact sum of three bf16 pieces, and the six largest cross terms reproduce an fp32 dot product at
+  least as accurately as an fp32 FMA chain."""
+  def bf16_rn(x):
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+  def split3(x):
+    h = bf16_rn(x); r = (x - h).astype(np.float32); m = bf16_rn(r); lo = bf16_rn((r - m).astype(np.float32))
+    return h, m, lo
+  rng = np.random.default_rng(0)
+  a = (rng.standard_normal(200000) * np.exp(rng.uniform(-20, 20, 200000))).astype(np.float32)
+  h, m, lo = split3(a)
+  assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + lo.astype(np.float64), a.astype(np.float64))
+  K = 4096
+  A = np.maximum(rng.standard_normal((8, K)), 0).astype(np.float32)
+  B = (rng.uniform(-1, 1, (K, 8)) * 0.02).astype(np.float32)
+  ref = A.astype(np.float64) @ B.astype(np.float64)
+  chain = np.zeros((8, 8), np.float32)
+  for k in range(K):
+    chain = (chain + A[:, k:k + 1] * B[k:k + 1, :]).astype(np.float32)
+  Ap, Bp = split3(A), split3(B)
+  acc = np.zeros((8, 8), np.float32)
+  for k in range(0, K, 16):
+    for ia, ib in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+      acc = (acc + Ap[ia][:, k:k + 16].astype(np.float64) @ Bp[ib][k:k + 16].astype(np.float64)).astype(np.float32)
+  assert np.max(np.abs(acc - ref)) <= np.max(np.abs(chain - ref))

@@ -12,7 +12,7 @@
 // overlap in memory; nothing is ever materialised.  Back-prop to the input is the same kernel
 // run over dz with the flipped/transposed filter operand; back-prop to the filters is
 // A^T * dz reduced over all (b, t) rows, split over row ranges into slabs that a second
-// kernel sums (deterministic, no atomics).
+// kernel sums (deterministic, no atomics).  Staging is LDS-DMA everywhere (global_load_lds).
 #include <algorithm>
 #include <cstdlib>
 
@@ -51,34 +51,6 @@ struct NNParams {
   int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
   int splits, steps_per_split;       // split-K over blockIdx.y: raw partial tiles go to `slab`
   float* slab;                       // [splits][M][Np]
-};
-
-// ------------------------------------------------------------------------------------
-// "Interleaved-4" LDS image of a row-major [32 x COLS] stage whose ROWS are the reduction index:
-// element (r, c) lives at ((r>>2)*4 + (c&3)) * PITCH + (c>>2)*4 + (r&3), PITCH = COLS + 16.
-// A lane then fetches 4 consecutive reduction rows of its column with ONE ds_read_b128 (the four
-// k-steps of an MFMA quad), and both the transposing ds_write_b128 (lanes 16 B apart) and the
-// fragment ds_read_b128 (16 lanes -> 16 distinct 16-byte bank slots, PITCH = 16 mod 64 dwords)
-// are bank-conflict free.
-// ------------------------------------------------------------------------------------
-template <int COLS>
-struct Il4 {
-  static constexpr int PITCH = COLS + 16;
-  static constexpr int SIZE = 32 * PITCH;
-  static constexpr int BLOCKS = 8 * (COLS / 4);      // 4x4 blocks per stage
-  // write the 4x4 block (rows 4g..4g+3, cols 4cq..4cq+3) held as 4 row vectors
-  static __device__ __forceinline__ void store_block(float* base, int g, int cq, const f32x4 (&r)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v = {r[0][i], r[1][i], r[2][i], r[3][i]};
-      *reinterpret_cast<f32x4*>(base + (g * 4 + i) * PITCH + cq * 4) = v;
-    }
-  }
-  // float offset of the fragment base of a lane: column c0 + l31 (c0 % 4 == 0), row group h
-  static __device__ __forceinline__ int frag_base(int c0, int l31, int h) {
-    return (h * 4 + (l31 & 3)) * PITCH + (c0 / 4 + (l31 >> 2)) * 4;
-  }
-  static constexpr int Q_STRIDE = 8 * PITCH;          // next pair of row groups (8 reduction rows)
 };
 
 // ------------------------------------------------------------------------------------
@@ -362,8 +334,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 // ------------------------------------------------------------------------------------
 // Filter gradient: out[split][k][n] = sum over the split's rows m of A[m][k] * Z[m][n].
 // Both operands are reduction-major in memory (a row of A / Z is one value of the reduction
-// index m), so both use the interleaved-4 LDS image.  Tile 128(k) x BN(n), 32 rows of m per
-// stage, the row range of a split walked incrementally (no per-row division).
+// index m) and are staged as they are, linear [m][cols], by LDS-DMA.  A lane fetches MT (NT)
+// adjacent columns of row m with one ds_read_b64, so MFMA tile i of a wave covers output rows
+// {MT*lane + i}; the epilogue undoes that permutation.  Tile 128(k) x BN(n), 32 rows of m per
+// stage, the row range of a split walked with a scalar base per DMA piece (no per-row division).
 // ------------------------------------------------------------------------------------
 struct TNParams {
   const float* A; RowMap amap;

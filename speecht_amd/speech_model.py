@@ -8,9 +8,7 @@ hand-written HIP kernels through ``engine.Wav2LetterEngine``.  ``sess`` is an op
 (device + stream) instead of a tf.Session.
 """
 import json
-import math
 import os
-import time
 
 import numpy as np
 

@@ -1,117 +1,118 @@
-"""`speecht-cli evaluate`: decode, compare, report LED/LER/WED/WER (mirror of speecht/evaluation.py)."""
+"""`speecht-cli evaluate` -- greedy decoding of a data set with letter / word error statistics.
+
+Output lines and statistics follow speecht/evaluation.py (``validation average loss ...``,
+``expected: ...``, ``decoded: ...``, ``LED: .. LER: .. WED: .. WER: ..``, ``Global statistics``).
+"""
 import itertools
+import math
 
-import numpy as np
-
-from . import editdistance, vocabulary
-from .execution import DatasetExecutor
-from .speech_input import OutOfRangeError
-from .speech_model import Session, SpeechModel
-
-
-class EvalStatistics:
-  """Running letter / word edit distances and error rates (evaluation.py:27-65)."""
-
-  def __init__(self):
-    self.decodings_counter = 0
-    self.sum_letter_edit_distance = self.sum_letter_error_rate = 0
-    self.sum_word_edit_distance = self.sum_word_error_rate = 0
-    self.letter_edit_distance = self.letter_error_rate = 0
-    self.word_edit_distance = self.word_error_rate = 0
-
-  def track_decoding(self, decoded_str, expected_str):
-    expected_words = expected_str.split()
-    self.letter_edit_distance = editdistance.eval(expected_str, decoded_str)
-    self.letter_error_rate = self.letter_edit_distance / len(expected_str)
-    self.word_edit_distance = editdistance.eval(expected_words, decoded_str.split())
-    self.word_error_rate = self.word_edit_distance / len(expected_words)
-    self.sum_letter_edit_distance += self.letter_edit_distance
-    self.sum_letter_error_rate += self.letter_error_rate
-    self.sum_word_edit_distance += self.word_edit_distance
-    self.sum_word_error_rate += self.word_error_rate
-    self.decodings_counter += 1
-
-  def _mean(self, total):
-    return total / self.decodings_counter
-
-  global_letter_edit_distance = property(lambda self: self._mean(self.sum_letter_edit_distance))
-  global_letter_error_rate = property(lambda self: self._mean(self.sum_letter_error_rate))
-  global_word_edit_distance = property(lambda self: self._mean(self.sum_word_edit_distance))
-  global_word_error_rate = property(lambda self: self._mean(self.sum_word_error_rate))
-
+from . import editdistance, execution, speech_input, speech_model, vocabulary
 
 STATS_FORMAT = 'LED: {} LER: {:.2f} WED: {} WER: {:.2f}'
 
 
-class Evaluation(DatasetExecutor):
+class EvalStatistics:
+  """Edit distances of the last decoding plus running sums over all of them
+  (letter = per character, word = per whitespace-separated token; rates are relative to the
+  expected string, evaluation.py:40-49)."""
+
+  _FIELDS = ('letter_edit_distance', 'letter_error_rate', 'word_edit_distance', 'word_error_rate')
+
+  def __init__(self):
+    self.decodings_counter = 0
+    for name in self._FIELDS:
+      setattr(self, name, 0)
+      setattr(self, 'sum_' + name, 0)
+
+  def track_decoding(self, decoded_str, expected_str):
+    expected_tokens, decoded_tokens = expected_str.split(), decoded_str.split()
+    self.letter_edit_distance = editdistance.eval(expected_str, decoded_str)
+    self.word_edit_distance = editdistance.eval(expected_tokens, decoded_tokens)
+    self.letter_error_rate = self.letter_edit_distance / len(expected_str)
+    self.word_error_rate = self.word_edit_distance / len(expected_tokens)
+    for name in self._FIELDS:
+      setattr(self, 'sum_' + name, getattr(self, 'sum_' + name) + getattr(self, name))
+    self.decodings_counter += 1
+
+  def __getattr__(self, name):
+    # global_<field> = mean of <field> over all tracked decodings
+    if name.startswith('global_') and name[len('global_'):] in self._FIELDS:
+      return getattr(self, 'sum_' + name[len('global_'):]) / self.decodings_counter
+    raise AttributeError(name)
+
+  def last_line(self):
+    return STATS_FORMAT.format(*(getattr(self, f) for f in self._FIELDS))
+
+  def global_line(self):
+    return STATS_FORMAT.format(*(getattr(self, 'global_' + f) for f in self._FIELDS))
+
+
+class Evaluation(execution.DatasetExecutor):
 
   def create_sample_generator(self, limit_count: int):
     return self.reader.load_samples(self.flags.dataset, loop_infinitely=False, limit_count=limit_count,
                                     feature_type=self.flags.feature_type)
 
   def get_loader_limit_count(self):
-    return self.flags.step_count * self.flags.batch_size
+    return self.flags.batch_size * self.flags.step_count
 
   def get_max_steps(self):
-    return self.flags.step_count or None
+    return self.flags.step_count if self.flags.step_count else None
 
   def run(self):
     stats = EvalStatistics()
-    with Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
+    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
       model = self.create_model(sess)
       print('Starting input pipeline')
-      coord = self.start_pipeline(sess)
+      coordinator = self.start_pipeline(sess)
+      print('Begin evaluation')
       try:
-        print('Begin evaluation')
-        steps = range(self.flags.step_count) if self.flags.step_count else itertools.count()
-        for step in steps:
-          if coord.should_stop():
+        for step in (range(self.flags.step_count) if self.flags.step_count else itertools.count()):
+          if coordinator.should_stop():
             break
-          self.run_step(model, sess, stats, self.flags.should_save and step == 0)
-      except OutOfRangeError:
+          self.run_step(model, sess, stats, save=self.flags.should_save and step == 0)
+      except speech_input.OutOfRangeError:
         print('Done evaluating -- step limit reached')
       finally:
-        coord.request_stop()
+        coordinator.request_stop()
       self.print_global_statistics(stats)
-      coord.join()
+      coordinator.join()
     return stats
 
   @staticmethod
   def print_global_statistics(stats):
     print('Global statistics')
-    print(STATS_FORMAT.format(stats.global_letter_edit_distance, stats.global_letter_error_rate,
-                              stats.global_word_edit_distance, stats.global_word_error_rate))
+    print(stats.global_line())
 
-  def run_step(self, model: SpeechModel, sess, stats: EvalStatistics, save: bool, verbose=True, feed_dict=None):
-    global_step = model.global_step.eval()
+  def run_step(self, model, sess, stats: EvalStatistics, save: bool, verbose=True, feed_dict=None):
+    """One batch: loss + greedy decoding + labels, then per-utterance statistics."""
+    step_index = model.global_step.eval()
+    fetched = model.step(sess, update=False, decode=True, return_label=True, summary=bool(save), feed_dict=feed_dict)
+    avg_loss, decoded, label = fetched[:3]
     if save:
-      avg_loss, decoded, label, summary = model.step(sess, update=False, decode=True, return_label=True,
-                                                     summary=True, feed_dict=feed_dict)
-      model.summary_writer.add_summary(summary, global_step)
-    else:
-      avg_loss, decoded, label = model.step(sess, update=False, decode=True, return_label=True, feed_dict=feed_dict)
+      model.summary_writer.add_summary(fetched[3], step_index)
     if verbose:
-      perplexity = np.exp(float(avg_loss)) if avg_loss < 300 else float('inf')
+      perplexity = math.exp(float(avg_loss)) if avg_loss < 300 else float('inf')
       print('validation average loss {:.2f} perplexity {:.2f}'.format(avg_loss, perplexity))
-    # Deliberate fix of a reference defect: evaluation.py:144-151 pairs labels with decodings via
-    # extract_decoded_ids, which skips utterances that decode to the empty string (shifting every
-    # later pairing, and raising StopIteration when the last ones are empty).  Rows are paired by
-    # their batch index here; extract_decoded_ids itself is kept faithful for other callers.
-    decoded_rows = [Evaluation.rows_by_batch(path) for path in decoded]
-    for row, label_ids in enumerate(Evaluation.rows_by_batch(label)):
-      expected_str = vocabulary.ids_to_sentence(label_ids)
+    # Deliberate fix of a reference defect: evaluation.py:144-151 pairs labels with decodings through
+    # extract_decoded_ids, which drops utterances that decode to the empty string (shifting every later
+    # pairing and raising StopIteration when the last ones are empty).  Here rows are paired by batch
+    # index; extract_decoded_ids itself stays faithful for other callers.
+    paths = [self.rows_by_batch(path) for path in decoded]
+    for row, label_ids in enumerate(self.rows_by_batch(label)):
+      expected = vocabulary.ids_to_sentence(label_ids)
       if verbose:
-        print('expected: {}'.format(expected_str))
-      for rows in decoded_rows:
-        decoded_str = vocabulary.ids_to_sentence(rows[row])
-        stats.track_decoding(decoded_str, expected_str)
+        print('expected: {}'.format(expected))
+      for rows in paths:
+        hypothesis = vocabulary.ids_to_sentence(rows[row])
+        stats.track_decoding(hypothesis, expected)
         if verbose:
-          print('decoded: {}'.format(decoded_str))
-          print(STATS_FORMAT.format(stats.letter_edit_distance, stats.letter_error_rate,
-                                    stats.word_edit_distance, stats.word_error_rate))
+          print('decoded: {}'.format(hypothesis))
+          print(stats.last_line())
 
   @staticmethod
   def rows_by_batch(sparse_tensor):
+    """Sparse (indices, values, dense_shape) -> one id list per batch row (empty rows included)."""
     rows = [[] for _ in range(int(sparse_tensor.dense_shape[0]))]
     for (batch_id, _), value in zip(sparse_tensor.indices, sparse_tensor.values):
       rows[int(batch_id)].append(value)
@@ -119,15 +120,12 @@ class Evaluation(DatasetExecutor):
 
   @staticmethod
   def extract_decoded_ids(sparse_tensor):
-    """Groups sparse values by batch row.  Faithful to evaluation.py:160-171, including its quirk:
-    a row is only emitted when a LATER row starts, so an utterance that decodes to the empty string
-    yields nothing and shifts the pairing of every following utterance."""
-    ids = []
-    last_batch_id = 0
-    for (batch_id, _), value in zip(sparse_tensor.indices, sparse_tensor.values):
-      if batch_id > last_batch_id:
-        yield ids
-        ids = []
-        last_batch_id = batch_id
-      ids.append(value)
-    yield ids
+    """Generator with the reference's semantics (evaluation.py:160-171), quirk included: a row is only
+    emitted once a LATER row starts, so an empty row yields nothing and shifts what follows."""
+    current, current_row = [], 0
+    for position, (batch_id, _) in enumerate(sparse_tensor.indices):
+      if batch_id > current_row:
+        yield current
+        current, current_row = [], batch_id
+      current.append(sparse_tensor.values[position])
+    yield current

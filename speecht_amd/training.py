@@ -1,15 +1,36 @@
-"""`speecht-cli train`: the step loop with checkpoint cadence and LR decay (mirror of speecht/training.py)."""
+"""`speecht-cli train` -- the optimisation loop around ``SpeechModel.step``.
+
+Behaviour follows speecht/training.py:44-98: statistics are averaged over windows of
+``--steps-per-checkpoint`` steps; at the end of every window the model is checkpointed as
+``<train_dir>/<run_name>/speechT.ckpt-<global_step>`` and, when a decay factor is set, the learning
+rate is multiplied by it if the window loss is worse than each of the previous three windows.
+"""
+import math
 import os
 import time
 
-import numpy as np
-
-from .execution import DatasetExecutor
-from .speech_input import OutOfRangeError
-from .speech_model import Session, create_default_model
+from . import execution, speech_input, speech_model
 
 
-class Training(DatasetExecutor):
+class _Window:
+  """Running means over one checkpoint window."""
+
+  def __init__(self, size):
+    self.size = size
+    self.reset()
+
+  def reset(self):
+    self.mean_step_time = 0.0
+    self.mean_loss = 0.0
+
+  def add(self, seconds, loss):
+    self.mean_step_time += seconds / self.size
+    self.mean_loss += loss / self.size
+
+
+class Training(execution.DatasetExecutor):
+
+  CHECKPOINT_NAME = 'speechT.ckpt'
 
   def create_sample_generator(self, limit_count: int):
     return self.reader.load_samples('train', loop_infinitely=True, limit_count=limit_count,
@@ -19,50 +40,48 @@ class Training(DatasetExecutor):
     return self.flags.limit_training_set
 
   def create_model(self, sess):
-    model = create_default_model(self.flags, self.input_size, self.speech_input)
-    model.restore_or_create(sess, self.flags.run_train_dir,
-                            self.flags.learning_rate if self.flags.reset_learning_rate else None)
+    model = speech_model.create_default_model(self.flags, self.input_size, self.speech_input)
+    reset_to = self.flags.learning_rate if self.flags.reset_learning_rate else None
+    model.restore_or_create(sess, self.flags.run_train_dir, reset_to)
     return model
 
+  def _end_of_window(self, sess, model, window, last_loss, summary, history):
+    step = model.global_step.eval()
+    perplexity = math.exp(float(last_loss)) if last_loss < 300 else float('inf')
+    print('global step {:d} learning rate {:.4f} step-time {:.2f} average loss {:.2f} perplexity {:.2f}'.format(
+        step, model.learning_rate.eval(), window.mean_step_time, last_loss, perplexity))
+    model.summary_writer.add_summary(summary, step)
+    decay = self.flags.learning_rate_decay_factor
+    if decay > 0 and len(history) > 2 and window.mean_loss > max(history[-3:]):
+      sess.run(model.learning_rate_decay_op)
+    history.append(window.mean_loss)
+    model.saver.save(sess, os.path.join(self.flags.run_train_dir, self.CHECKPOINT_NAME), global_step=model.global_step)
+    print('Model saved')
+    window.reset()
+
   def run(self, max_steps=None):
-    """Same bookkeeping as training.py:44-98: every ``steps_per_checkpoint`` steps print the window
-    statistics, decay the learning rate if the window loss exceeds the last three, and checkpoint.
-    ``max_steps`` (not in the reference) bounds the loop for tests."""
-    with Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
+    """``max_steps`` (not a reference flag) bounds the loop for tests and smoke runs."""
+    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
       model = self.create_model(sess)
-      coord = self.start_pipeline(sess, n_threads=2)
-      step_time, loss = 0.0, 0.0
-      current_step = 0
-      previous_losses = []
-      every = self.flags.steps_per_checkpoint
+      coordinator = self.start_pipeline(sess, n_threads=2)
+      window = _Window(self.flags.steps_per_checkpoint)
+      history = []
+      steps_done = 0
+      print('Begin training')
       try:
-        print('Begin training')
-        while not coord.should_stop():
-          current_step += 1
-          is_checkpoint_step = current_step % every == 0
-          start_time = time.time()
-          step_result = model.step(sess, summary=is_checkpoint_step)
-          avg_loss = step_result[0]
-          step_time += (time.time() - start_time) / every
-          loss += avg_loss / every
-          if is_checkpoint_step:
-            global_step = model.global_step.eval()
-            perplexity = np.exp(float(avg_loss)) if avg_loss < 300 else float('inf')
-            print('global step {:d} learning rate {:.4f} step-time {:.2f} average loss {:.2f} perplexity {:.2f}'
-                  .format(global_step, model.learning_rate.eval(), step_time, avg_loss, perplexity))
-            model.summary_writer.add_summary(step_result[2], global_step)
-            if self.flags.learning_rate_decay_factor > 0 and len(previous_losses) > 2 and loss > max(previous_losses[-3:]):
-              sess.run(model.learning_rate_decay_op)
-            previous_losses.append(loss)
-            checkpoint_path = os.path.join(self.flags.run_train_dir, 'speechT.ckpt')
-            model.saver.save(sess, checkpoint_path, global_step=model.global_step)
-            print('Model saved')
-            step_time, loss = 0.0, 0.0
-          if max_steps and current_step >= max_steps:
+        while not coordinator.should_stop():
+          steps_done += 1
+          closes_window = steps_done % window.size == 0
+          began = time.time()
+          fetched = model.step(sess, summary=closes_window)     # [avg_loss, None(update), summary?]
+          window.add(time.time() - began, fetched[0])
+          if closes_window:
+            self._end_of_window(sess, model, window, fetched[0], fetched[2], history)
+          if max_steps and steps_done >= max_steps:
             break
-      except OutOfRangeError:
+      except speech_input.OutOfRangeError:
         print('Done training -- step limit reached')
       finally:
-        coord.request_stop()
-      coord.join()
+        coordinator.request_stop()
+      coordinator.join()
       return model

@@ -163,6 +163,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-alt', action='store_true', help='skip the experimental bf16x6 side measurement')
   ap.add_argument('--force-allreduce', action='store_true', help='run the RCCL all-reduce path even on 1 rank (self-test)')
+  ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
+                  help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,7 +188,7 @@ def main():
   eng.load_batch(x, seq_lens)
   eng.set_labels(labels)
   x_dev = torch.as_tensor(x, dtype=torch.float32).to(dev)
-  reducer = GradientAllReducer(eng.grads, eng.layer_ranges, force=args.force_allreduce) if (world > 1 or args.force_allreduce) else None
+  reducer = GradientAllReducer(eng.grads, eng.layer_ranges, force=args.force_allreduce, transport=args.allreduce) if (world > 1 or args.force_allreduce) else None
   global_batch = args.batch * world
   lr = 1e-4
 
@@ -221,7 +223,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: 1xMI355X training step, batch {} of {:g} s synthetic clips, {}-mel, '
                                'default Wav2Letter depth, fp32'.format(args.batch, args.seconds, args.mels),
-                   'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world},
+                   'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world,
+                   'allreduce': reducer.transport if reducer else None},
         'final_avg_loss': round(loss, 4),
         'step_tflops_algorithmic': round(step_gflop / ms, 2),
     }

@@ -32,6 +32,7 @@ extern "C" {
 #define ST_EINVAL (-1)   /* bad argument / layout precondition violated */
 #define ST_ELAUNCH (-2)  /* HIP launch error */
 #define ST_EWORKSPACE (-3)
+#define ST_ECOMM (-4)    /* RCCL unavailable or a collective failed */
 
 /* element (b, t, c) lives at base[((int64)b * t_pitch + halo + t) * c_pitch + c];
  * rows outside [0, frames) and channels in [channels, c_pitch) must hold zeros. */
@@ -105,6 +106,17 @@ int st_ctc_greedy_decode(const st_tensor3* logits, const int32_t* seq_lens, int 
                          int32_t* ids, int max_out, int32_t* out_lens, float* neg_sum_logits,
                          void* stream);
 
+/* ---- LM-free CTC prefix beam search, top path (BASELINE config 5) -----
+ * The reference only reaches a beam search through its KenLM TensorFlow fork
+ * (speech_model.py:101-111: beam_width=100, merge_repeated=False, top_paths=1); this is the stock
+ * tf.nn.ctc_beam_search_decoder recursion without a scorer.  blank = C-1, C <= 32, beam <= 64.
+ * ids [B][max_out] int32 (labels beyond max_out are dropped, out_lens still reports the true
+ * length), log_prob [B] = ln p(top prefix) under the per-frame softmax. */
+size_t st_ctc_beam_ws(int batch, int frames, int beam_width);
+int st_ctc_beam_search_decode(const st_tensor3* logits, const int32_t* seq_lens, int beam_width,
+                              int32_t* ids, int max_out, int32_t* out_lens, float* log_prob,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K12-K13: clip_by_global_norm + AdamOptimizer(epsilon outside) (speech_model.py:77-82)
  * Flat fp32 buffers of n floats.  stats (device, 2 floats) receives {global_norm, scale}.
  * lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller (host, double).
@@ -129,6 +141,20 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
                    const float* mel_basis, int n_mels, int n_fft, int hop,
                    const int64_t* frame_offsets, int64_t total_frames, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* ---- gradient exchange (RCCL over xGMI) ---------------------------------
+ * The reference is single-replica (training.py:46); data parallelism follows from
+ * speech_model.py:75-82 (mean loss over the batch, clip and Adam on the mean gradient).  One
+ * communicator per process.  Rank 0 creates the id, the host moves its bytes to the other ranks,
+ * every rank calls st_comm_init (collective).  st_allreduce_f32 SUMS in place, asynchronously on
+ * `stream`; the bucket form groups several slices of one flat buffer into a single RCCL launch. */
+int st_comm_unique_id_bytes(void);
+int st_comm_unique_id(void* id_out, size_t id_bytes);
+int st_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);
+int st_comm_destroy(void* comm);
+int st_allreduce_f32(void* comm, float* buf, size_t n, void* stream);
+int st_allreduce_buckets_f32(void* comm, float* base, const size_t* starts, const size_t* counts, int n_buckets,
+                             void* stream);
 
 /* ---- helpers -------------------------------------------------------------------------- */
 int st_fill_f32(float* dst, float value, size_t n, void* stream);

@@ -357,6 +357,60 @@ def ctc_greedy_decode(logits_tm, seq_lens, merge_repeated=True):
   return out, score
 
 
+def ctc_beam_search_decode(logits_tm, seq_lens, beam_width=16):
+  """LM-free CTC prefix beam search, top path only (SURVEY 8(f) item 3 / BASELINE config 5).
+
+  PARITY UNPINNED: the reference only ever calls a beam search through its KenLM TensorFlow fork
+  (speech_model.py:101-111, beam_width=100, merge_repeated=False, top_paths=1), which is not vendored.
+  This restates the stock ``tf.nn.ctc_beam_search_decoder`` recursion (ctc_beam_search.h ``Step``) without
+  a scorer: a beam entry is a label prefix with (p_blank, p_label); per frame an entry is kept
+  ("stay": blank or repeat of its last label, plus the mass flowing in from its parent prefix when that
+  is also in the beam) and extended by every non-blank class whose child prefix is not already in the
+  beam; the best ``beam_width`` candidates by total probability survive.  Ordering is made total so that
+  an implementation can match it exactly: candidates are ranked by (total desc, slot*C + c asc) where
+  ``slot`` is the parent entry's rank in the previous frame and c == blank marks the stay candidate.
+  Scores are natural-log probabilities under the per-frame softmax.
+
+  Returns (list of id lists, log_prob [B,1]).
+  """
+  logits_tm = np.asarray(logits_tm, dtype=np.float64)
+  T, B, C = logits_tm.shape
+  blank, ninf = C - 1, -np.inf
+  lse = np.logaddexp
+  out, score = [], np.zeros((B, 1))
+  for b in range(B):
+    beams = [((), 0.0, ninf)]                      # (prefix, log p_blank, log p_label), best first
+    for t in range(min(int(seq_lens[b]), T)):
+      row = logits_tm[t, b]
+      lp = row - row.max()
+      lp = lp - math.log(np.exp(lp).sum())
+      slot_of = {pre: i for i, (pre, _, _) in enumerate(beams)}
+      cands = []
+      for slot, (pre, pb, pl) in enumerate(beams):
+        tot = lse(pb, pl)
+        stay_b = tot + lp[blank]
+        stay_l = ninf
+        if pre:
+          mass = pl
+          if pre[:-1] in slot_of:
+            ppre, ppb, ppl = beams[slot_of[pre[:-1]]]
+            mass = lse(mass, ppb if (ppre and ppre[-1] == pre[-1]) else lse(ppb, ppl))
+          stay_l = mass + lp[pre[-1]]
+        cands.append((lse(stay_b, stay_l), slot * C + blank, pre, stay_b, stay_l))
+        for c in range(C - 1):
+          child = pre + (c,)
+          if child in slot_of:
+            continue
+          v = (pb if (pre and pre[-1] == c) else tot) + lp[c]
+          cands.append((v, slot * C + c, child, ninf, v))
+      cands = [x for x in cands if x[0] > ninf]
+      cands.sort(key=lambda x: (-x[0], x[1]))
+      beams = [(pre, pb, pl) for _, _, pre, pb, pl in cands[:beam_width]]
+    out.append([int(i) for i in beams[0][0]])
+    score[b, 0] = lse(beams[0][1], beams[0][2])
+  return out, score
+
+
 def decoded_to_sparse(id_lists):
   """Sparse form of the decoder output: indices [N,2] row-major, values [N] int64, shape [B,max]."""
   idx, vals = [], []

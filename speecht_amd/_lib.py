@@ -39,6 +39,9 @@ _SIGNATURES = {
     'st_ctc_loss_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, _T3P,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_ctc_greedy_decode': (c_int, [_T3P, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'st_ctc_beam_ws': (c_size_t, [c_int, c_int, c_int]),
+    'st_ctc_beam_search_decode': (c_int, [_T3P, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_size_t, c_void_p]),
     'st_global_norm_ws': (c_size_t, [c_size_t]),
     'st_global_norm_clip_adam_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                              c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -46,6 +49,12 @@ _SIGNATURES = {
     'st_melspec_ws': (c_size_t, [c_int, c_int64, c_int]),
     'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_comm_unique_id_bytes': (c_int, []),
+    'st_comm_unique_id': (c_int, [c_void_p, c_size_t]),
+    'st_comm_init': (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p)]),
+    'st_comm_destroy': (c_int, [c_void_p]),
+    'st_allreduce_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_allreduce_buckets_f32': (c_int, [c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_int, c_void_p]),
     'st_fill_f32': (c_int, [c_void_p, c_float, c_size_t, c_void_p]),
     'st_zero_halos_f32': (c_int, [_T3P, c_void_p]),
 }

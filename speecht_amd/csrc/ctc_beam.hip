@@ -1,0 +1,304 @@
+// LM-free CTC prefix beam search (top path) on gfx950 -- SURVEY 8(f) item 3, BASELINE config 5.
+//
+// The reference reaches a beam search only through its KenLM TensorFlow fork (speech_model.py:101-111);
+// this kernel follows the stock tf.nn.ctc_beam_search_decoder recursion without a scorer, with the
+// candidate order of oracle/w2l_oracle.py::ctc_beam_search_decode (total desc, slot*C + c asc).
+//
+// Mapping: ONE wavefront per utterance (the recursion is sequential in time, utterances are the
+// parallel axis).  Everything that lives across frames -- the beam entries -- sits in LDS, double
+// buffered; a frame is: log-softmax of the 29 logits (wave reduce), parent matching (W^2 hash compares
+// spread over the lanes), one sortable 64-bit key per candidate (W*C of them, lane-strided, in registers),
+// and W rounds of a wave-wide arg-max on the DPP network where only the winning lane refreshes its local best.  Prefix identity is a
+// 64-bit mixed hash + length (the trie TF keeps in host memory would be a pointer chase per candidate);
+// the emitted labels are recorded as (parent node, label) pairs in a per-utterance pool whose slot is a
+// pure function of (frame, rank), so there are no atomics and the result is deterministic.
+#include <math.h>
+
+#include "st_common.h"
+
+namespace {
+
+constexpr int kMaxBeam = 64;
+constexpr int kMaxClasses = 32;
+constexpr unsigned long long kRootHash = 0x243F6A8885A308D3ull;
+
+struct RowMap {   // (b, t) -> float offset into a padded NWC tensor
+  long batch_stride;
+  long row0;
+  int row_stride;
+  __device__ __forceinline__ long off(int b, int t) const { return (long)b * batch_stride + row0 + (long)t * row_stride; }
+};
+
+struct BeamSet {   // structure of arrays: lane r reads/writes entry r without bank conflicts
+  unsigned long long hash[kMaxBeam];
+  unsigned long long parent_hash[kMaxBeam];
+  int len[kMaxBeam];
+  int last[kMaxBeam];
+  int node[kMaxBeam];
+  float pb[kMaxBeam];
+  float pl[kMaxBeam];
+  float total[kMaxBeam];
+};
+
+__device__ __forceinline__ unsigned long long child_hash(unsigned long long h, int c) {
+  unsigned long long x = h + 0x9E3779B97F4A7C15ull * (unsigned long long)(c + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ float lse(float a, float b) {
+  float hi = fmaxf(a, b), lo = fminf(a, b);
+  return hi == -INFINITY ? -INFINITY : hi + log1pf(expf(lo - hi));
+}
+
+// ---- wave64 reductions on the DPP network (row shifts + row broadcasts; no LDS round trips) --------
+template <int CTRL, int ROW_MASK, bool ZERO_INVALID>
+__device__ __forceinline__ int dpp_i32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, ZERO_INVALID);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+  int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  unsigned long long o = ((unsigned long long)(unsigned)dpp_i32<CTRL, 0xf, false>(hi, hi) << 32) |
+                         (unsigned)dpp_i32<CTRL, 0xf, false>(lo, lo);          // invalid source lane -> own value
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0x111>(v);   // row_shr:1
+  v = dpp_max_u64<0x112>(v);   // row_shr:2
+  v = dpp_max_u64<0x114>(v);   // row_shr:4
+  v = dpp_max_u64<0x118>(v);   // row_shr:8   -> lane 15 of every row holds the row maximum
+  v = dpp_max_u64<0x142>(v);   // row_bcast:15
+  v = dpp_max_u64<0x143>(v);   // row_bcast:31 -> lane 63 holds the wave maximum
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define ST_STEP(CTRL) v = fmaxf(v, __int_as_float(dpp_i32<CTRL, 0xf, false>(__float_as_int(v), __float_as_int(v))))
+  ST_STEP(0x111); ST_STEP(0x112); ST_STEP(0x114); ST_STEP(0x118); ST_STEP(0x142); ST_STEP(0x143);
+#undef ST_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#define ST_STEP(CTRL, MASK) v += __int_as_float(dpp_i32<CTRL, MASK, true>(0, __float_as_int(v)))
+  ST_STEP(0x111, 0xf); ST_STEP(0x112, 0xf); ST_STEP(0x114, 0xf); ST_STEP(0x118, 0xf);   // scan inside each row
+  ST_STEP(0x142, 0xa); ST_STEP(0x143, 0xc);                                            // fold rows into lane 63
+#undef ST_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// candidate key: larger total first, then smaller candidate index; unique per candidate
+__device__ __forceinline__ unsigned long long make_key(float v, int k) {
+  unsigned bits = (unsigned)__float_as_int(v);
+  unsigned ord = bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+  return ((unsigned long long)ord << 32) | (0xFFFFFFFFu - (unsigned)k);
+}
+constexpr unsigned kOrdNegInf = 0x007FFFFFu;      // make_key(-inf, .) >> 32
+__device__ __forceinline__ float key_value(unsigned long long key) {
+  unsigned ord = (unsigned)(key >> 32);
+  unsigned bits = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  return __int_as_float((int)bits);
+}
+
+// CPL = candidates per lane (beam_width * C <= 64 * CPL)
+template <int CPL>
+__global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ logits, RowMap map, int T, int C,
+                                                      const int* __restrict__ seq_lens, int W,
+                                                      int2* __restrict__ node_pool, long pool_stride,
+                                                      int* __restrict__ ids, int max_out,
+                                                      int* __restrict__ out_lens, float* __restrict__ out_logp) {
+  __shared__ BeamSet sets[2];
+  __shared__ float lp_s[kMaxClasses];
+  __shared__ float2 base_s[kMaxBeam];           // {total, p_blank} of the previous frame
+  __shared__ float stay_pb[kMaxBeam], stay_pl[kMaxBeam], stay_total[kMaxBeam];
+  __shared__ int parent_of[kMaxBeam];
+  __shared__ unsigned dead[kMaxBeam];
+  __shared__ int sel_k[kMaxBeam];
+  __shared__ float sel_v[kMaxBeam];
+
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int Tb = min(seq_lens[b], T);
+  const int blank = C - 1;
+  int2* nodes = node_pool + (long)b * pool_stride;
+
+  // (slot, class) of this lane's candidates k = lane + 64 j: fixed for the whole utterance
+  int cslot[CPL], ccls[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    int k = lane + 64 * j;
+    cslot[j] = k / C;
+    ccls[j] = k - cslot[j] * C;
+  }
+
+  int cur = 0, nb = 1;
+  if (lane == 0) {
+    BeamSet& s = sets[0];
+    s.hash[0] = kRootHash; s.parent_hash[0] = 0; s.len[0] = 0; s.last[0] = -1; s.node[0] = 0;
+    s.pb[0] = 0.f; s.pl[0] = -INFINITY; s.total[0] = 0.f;
+  }
+  __syncthreads();
+
+  float x_next = (lane < C && Tb > 0) ? logits[map.off(b, 0) + lane] : -INFINITY;
+  for (int t = 0; t < Tb; ++t) {
+    const BeamSet& S = sets[cur];
+    BeamSet& N = sets[cur ^ 1];
+    const float x = x_next;
+    if (t + 1 < Tb && lane < C) x_next = logits[map.off(b, t + 1) + lane];     // hide the HBM latency of frame t+1
+    // (1) log-softmax of this frame
+    {
+      float m = wave_max_f32(x);
+      float z = wave_sum_f32(lane < C ? expf(x - m) : 0.f);
+      if (lane < C) lp_s[lane] = x - m - logf(z);
+      parent_of[lane] = -1;
+      dead[lane] = 0u;
+    }
+    __syncthreads();
+    // (2) which entries have their parent prefix in the beam?  (e, p) pairs spread over the lanes
+    {
+      int lg = 32 - __clz(max(nb - 1, 1));
+      if (nb <= 1) lg = 0;
+      const int wp = 1 << lg;
+      for (int idx = lane; idx < (nb << lg); idx += 64) {
+        int e = idx >> lg, p = idx & (wp - 1);
+        if (p < nb && S.len[p] + 1 == S.len[e] && S.hash[p] == S.parent_hash[e]) {
+          parent_of[e] = p;
+          atomicOr(&dead[p], 1u << S.last[e]);     // child (p, last[e]) already exists: merged into e's stay
+        }
+      }
+    }
+    __syncthreads();
+    // (2b) the stay candidate of entry `lane`
+    if (lane < nb) {
+      float tot = S.total[lane];
+      float npb = tot + lp_s[blank];
+      float npl = -INFINITY;
+      if (S.len[lane] > 0) {
+        float mass = S.pl[lane];
+        int p = parent_of[lane];
+        if (p >= 0) mass = lse(mass, (S.len[p] > 0 && S.last[p] == S.last[lane]) ? S.pb[p] : S.total[p]);
+        npl = mass + lp_s[S.last[lane]];
+      }
+      stay_pb[lane] = npb;
+      stay_pl[lane] = npl;
+      stay_total[lane] = lse(npb, npl);
+      base_s[lane] = make_float2(tot, S.pb[lane]);
+    }
+    __syncthreads();
+    // (3) one key per candidate, in registers
+    unsigned long long key[CPL];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int slot = cslot[j], c = ccls[j];
+      unsigned long long kj = 0ull;                       // below every real candidate
+      if (slot < nb) {
+        float v;
+        if (c == blank) {
+          v = stay_total[slot];
+        } else {
+          float2 base = base_s[slot];
+          v = ((dead[slot] >> c) & 1u) ? -INFINITY : ((S.last[slot] == c) ? base.y : base.x) + lp_s[c];
+        }
+        kj = make_key(v, lane + 64 * j);
+      }
+      key[j] = kj;
+      best = kj > best ? kj : best;
+    }
+    // (4) up to W rounds of a wave arg-max; the winner's lane retires it and refreshes its local best
+    int n_new = 0;
+    for (int r = 0; r < W; ++r) {
+      unsigned long long top = wave_max_u64(best);
+      if ((unsigned)(top >> 32) <= kOrdNegInf) break;      // nothing with non-zero probability left
+      const int k = (int)(0xFFFFFFFFu - (unsigned)top);
+      if (lane == 0) { sel_k[r] = k; sel_v[r] = key_value(top); }
+      n_new = r + 1;
+      if ((k & 63) == lane) {
+        const int jw = k >> 6;
+        best = 0ull;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (j == jw) key[j] = 0ull;
+          best = key[j] > best ? key[j] : best;
+        }
+      }
+    }
+    __syncthreads();
+    // (5) materialise the surviving entries, best first
+    if (lane < n_new) {
+      int k = sel_k[lane];
+      int slot = k / C, c = k - slot * C;
+      if (c == blank) {
+        N.hash[lane] = S.hash[slot]; N.parent_hash[lane] = S.parent_hash[slot];
+        N.len[lane] = S.len[slot]; N.last[lane] = S.last[slot]; N.node[lane] = S.node[slot];
+        N.pb[lane] = stay_pb[slot]; N.pl[lane] = stay_pl[slot];
+      } else {
+        int id = 1 + t * W + lane;
+        nodes[id] = make_int2(S.node[slot], c);
+        N.hash[lane] = child_hash(S.hash[slot], c); N.parent_hash[lane] = S.hash[slot];
+        N.len[lane] = S.len[slot] + 1; N.last[lane] = c; N.node[lane] = id;
+        N.pb[lane] = -INFINITY; N.pl[lane] = sel_v[lane];
+      }
+      N.total[lane] = sel_v[lane];
+    }
+    nb = n_new;
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // top path: entry 0 of the final set; walk the node chain backwards
+  if (lane == 0) {
+    const BeamSet& S = sets[cur];
+    int n = min(S.len[0], max_out);
+    out_lens[b] = S.len[0];
+    out_logp[b] = S.total[0];
+    int id = S.node[0];
+    for (int i = S.len[0] - 1; i >= 0; --i) {
+      int2 nd = nodes[id];
+      if (i < n) ids[(long)b * max_out + i] = nd.y;
+      id = nd.x;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t st_ctc_beam_ws(int batch, int frames, int beam_width) {
+  if (batch <= 0 || frames < 0 || beam_width <= 0) return 0;
+  return (size_t)batch * ((size_t)frames * beam_width + 1) * sizeof(int2);
+}
+
+int st_ctc_beam_search_decode(const st_tensor3* logits, const int32_t* seq_lens, int beam_width, int32_t* ids,
+                              int max_out, int32_t* out_lens, float* log_prob, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(logits && logits->base && seq_lens && ids && out_lens && log_prob, "beam search: null argument");
+  ST_REQUIRE(logits->channels >= 2 && logits->channels <= kMaxClasses, "beam search: 2..%d classes supported, got %d",
+             kMaxClasses, logits->channels);
+  ST_REQUIRE(beam_width >= 1 && beam_width <= kMaxBeam, "beam search: beam width 1..%d supported, got %d", kMaxBeam,
+             beam_width);
+  ST_REQUIRE(max_out >= 1, "beam search: max_out must be positive");
+  size_t need = st_ctc_beam_ws(logits->batch, logits->frames, beam_width);
+  if (!workspace || workspace_bytes < need) {
+    st::set_error("beam search: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    return ST_EWORKSPACE;
+  }
+  if (logits->batch == 0) return ST_OK;
+  RowMap map{(long)logits->t_pitch * logits->c_pitch, (long)logits->halo * logits->c_pitch, logits->c_pitch};
+  const int per_lane = st::ceil_div(beam_width * logits->channels, 64);
+#define ST_LAUNCH_BEAM(CPL)                                                                                          \
+  hipLaunchKernelGGL(ctc_beam_kernel<CPL>, dim3(logits->batch), dim3(64), 0, st::as_stream(stream), logits->base,    \
+                     map, logits->frames, logits->channels, seq_lens, beam_width,                                    \
+                     reinterpret_cast<int2*>(workspace), (long)logits->frames * beam_width + 1, ids, max_out,        \
+                     out_lens, log_prob)
+  if (per_lane <= 4) ST_LAUNCH_BEAM(4);
+  else if (per_lane <= 8) ST_LAUNCH_BEAM(8);
+  else if (per_lane <= 16) ST_LAUNCH_BEAM(16);
+  else ST_LAUNCH_BEAM(32);
+#undef ST_LAUNCH_BEAM
+  return st::check_launch("ctc_beam_search");
+}
+
+}  // extern "C"

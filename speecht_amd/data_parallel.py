@@ -10,6 +10,9 @@ used purely as the collective transport.  Buckets are contiguous slices of the f
 in the order back-prop finishes them (L10+L9, L8, L7..L0), launched asynchronously so that the
 xGMI transfer overlaps the remaining back-prop kernels.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,26 +42,103 @@ def default_buckets(layer_sizes, layer_offsets):
   return [(lo, layer_offsets[lo][0], layer_offsets[hi][1]) for lo, hi in groups]
 
 
-class GradientAllReducer:
-  """Sum-all-reduces slices of one flat gradient tensor as back-prop completes them."""
+class RcclCommunicator:
+  """An RCCL communicator owned by libspeecht_hip.so (``st_comm_*`` / ``st_allreduce_*`` of
+  include/speecht_hip.h) plus the side stream its collectives run on.
 
-  def __init__(self, flat_grads, layer_offsets, group=None, force=False):
+  ``torch.distributed`` is only the bootstrap channel here: rank 0's 128-byte unique id is broadcast as
+  a Python object, then every rank joins with ``st_comm_init``.  Collectives are ordered after the
+  compute stream with an event and joined back with another, so the xGMI transfer of one gradient
+  bucket overlaps the back-prop kernels of the layers below it.
+  """
+
+  def __init__(self, device, group=None):
+    from . import _lib
+    self._lib = _lib
+    self.device = torch.device(device)
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lib = _lib.load()
+    n = lib.st_comm_unique_id_bytes()
+    uid = ctypes.create_string_buffer(n)
+    if self.rank == 0:
+      _lib.call('st_comm_unique_id', uid, n)
+    if self.world > 1:
+      box = [uid.raw]
+      dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+      uid = ctypes.create_string_buffer(box[0], n)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(self.device):        # RCCL binds the communicator to the current device
+      _lib.call('st_comm_init', uid, n, self.rank, self.world, ctypes.byref(handle))
+      self.stream = torch.cuda.Stream(self.device)
+    self._handle = handle
+    self._joined = None
+
+  def all_reduce_slices(self, flat, slices, after_stream):
+    """SUM-all-reduce ``flat[s:e]`` for every (s, e), in one RCCL group, once ``after_stream`` has
+    reached this point."""
+    ready = torch.cuda.Event()
+    ready.record(after_stream)
+    self.stream.wait_event(ready)
+    k = len(slices)
+    starts = (ctypes.c_size_t * k)(*[s for s, _ in slices])
+    counts = (ctypes.c_size_t * k)(*[e - s for s, e in slices])
+    self._lib.call('st_allreduce_buckets_f32', self._handle, ctypes.c_void_p(flat.data_ptr()), starts, counts, k,
+                   ctypes.c_void_p(self.stream.cuda_stream))
+    self._joined = torch.cuda.Event()
+    self._joined.record(self.stream)
+
+  def join(self, stream):
+    """Make ``stream`` wait for every collective issued so far."""
+    if self._joined is not None:
+      stream.wait_event(self._joined)
+      self._joined = None
+
+  def close(self):
+    if self._handle:
+      self._lib.call('st_comm_destroy', self._handle)
+      self._handle = ctypes.c_void_p()
+
+
+class GradientAllReducer:
+  """Sum-all-reduces slices of one flat gradient tensor as back-prop completes them.
+
+  transport 'torch' (default): ``torch.distributed`` async all-reduce (nccl == RCCL on ROCm, gloo on CPU).
+  transport 'rccl': the library's own communicator (``st_allreduce_buckets_f32``); env ST_ALLREDUCE=rccl
+  selects it without code changes.
+  """
+
+  def __init__(self, flat_grads, layer_offsets, group=None, force=False, transport=None, compute_stream=None):
     self.flat = flat_grads
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-    self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the collective on 1 rank
+    self.transport = transport or os.environ.get('ST_ALLREDUCE', 'torch')
+    if self.transport not in ('torch', 'rccl'):
+      raise ValueError('transport must be "torch" or "rccl", got {!r}'.format(self.transport))
+    # force: exercise the collective on 1 rank
+    self.active = self.world > 1 or (force and (dist.is_initialized() or self.transport == 'rccl'))
     sizes = [e - s for s, e in layer_offsets]
     self.buckets = default_buckets(sizes, layer_offsets)
     self._ready_at = {lo: (s, e) for lo, s, e in self.buckets}
     self._pending = []
+    self._compute_stream = compute_stream
+    self.comm = RcclCommunicator(flat_grads.device, group) if (self.active and self.transport == 'rccl') else None
+
+  def _stream(self):
+    return self._compute_stream if self._compute_stream is not None else torch.cuda.current_stream(self.flat.device)
 
   def on_layer_done(self, i):
     if not self.active or i not in self._ready_at:
       return
     s, e = self._ready_at[i]
-    self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    if self.comm is not None:
+      self.comm.all_reduce_slices(self.flat, [(s, e)], self._stream())
+    else:
+      self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
   def finish(self):
+    if self.comm is not None:
+      self.comm.join(self._stream())
     for w in self._pending:
       w.wait()
     self._pending = []

@@ -407,6 +407,21 @@ class Wav2LetterEngine:
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
     return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
 
+  def beam_search_decode(self, beam_width=16):
+    """LM-free CTC prefix beam search, top path (stock tf.nn.ctc_beam_search_decoder semantics; the
+    reference's own beam search needs its KenLM fork, speech_model.py:101-111)
+    -> (list of id lists, log_prob [B,1])."""
+    lib = _lib.load()
+    B = self.dec_lens.numel()
+    need = lib.st_ctc_beam_ws(B, self.t_out, int(beam_width))
+    ws = self._storage.view('beam_ws', need // 4 + 16, torch.int32)[0]
+    call('st_ctc_beam_search_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(beam_width),
+         self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score),
+         self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+    lens = self.dec_lens.cpu().numpy()
+    ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
+    return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
+
   def check_ctc_status(self):
     st = self.ctc_status.cpu().numpy()
     if st.any():

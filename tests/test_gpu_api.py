@@ -165,3 +165,23 @@ def test_cli_preprocess_train_evaluate(dev, tmp_path):
   r = run(['evaluate', '--step-count', '1', '--run-name', 'missing', '--data-dir', str(data),
            '--train-dir', str(tmp_path / 'train'), '--log-dir', str(tmp_path / 'log'), '--batch-size', '4'])
   assert r.returncode != 0 and 'No checkpoint for evaluation found' in r.stderr
+
+
+def test_library_rccl_allreduce_single_rank(dev):
+  """st_comm_* / st_allreduce_buckets_f32 (include/speecht_hip.h) on a 1-rank communicator: a SUM over
+  one rank must leave every bucket bit-identical, on the side stream, joined back by events."""
+  import torch
+  from speecht_amd.data_parallel import GradientAllReducer
+  torch.manual_seed(3)
+  flat = torch.randn(1 << 20, device=dev)
+  before = flat.clone()
+  offsets = [(0, 1000), (1000, 300000), (300000, 900000), (900000, 1 << 20)]
+  red = GradientAllReducer(flat, offsets, force=True, transport='rccl')
+  assert red.active and red.comm is not None and red.comm.world == 1
+  for i in reversed(range(len(offsets))):
+    flat[offsets[i][0]:offsets[i][1]].mul_(1.0)       # producer work on the compute stream
+    red.on_layer_done(i)
+  red.finish()
+  torch.cuda.synchronize()
+  assert torch.equal(flat, before)
+  red.comm.close()

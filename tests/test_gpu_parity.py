@@ -178,6 +178,41 @@ def test_greedy_decode_bit_identical(dev):
     np.testing.assert_allclose(score, ref_score, rtol=1e-5)
 
 
+@pytest.mark.parametrize('beam', [1, 4, 16, 64])
+def test_beam_search_matches_oracle(dev, beam):
+  """st_ctc_beam_search_decode vs the float64 prefix beam search of the oracle: identical label
+  sequences, log-probabilities within 1e-4 relative (fp32 log-sum-exp over up to 401 frames)."""
+  rng = np.random.default_rng(40 + beam)
+  T, B, C = 401, 8, 29
+  logits = (rng.standard_normal((T, B, C)) * 2.0).astype(np.float32)
+  logits[:, 1, 28] += 4.0                                # mostly blanks
+  logits[:, 2, :] *= 4.0                                 # sharply peaked: beam collapses onto greedy
+  logits[50:300, 3, 7] += 6.0                            # one long run of a single label
+  logits[:, 4, :] *= 0.1
+  logits[::2, 4, 11] += 9.0; logits[1::2, 4, 28] += 9.0  # l, blank, l, blank ... -> repeated labels
+  lens = np.array([401, 400, 333, 301, 200, 1, 0, 57])
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits, (1, 0, 2))))
+  eng.ctc_lens = torch.as_tensor(lens.astype(np.int32)).to(dev)
+  ids, logp = eng.beam_search_decode(beam)
+  ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, beam)
+  assert ids == ref_ids
+  np.testing.assert_allclose(logp, ref_logp, rtol=1e-4, atol=1e-4)
+  assert ids[6] == [] and logp[6, 0] == 0.0              # zero frames: empty prefix with probability 1
+  if beam >= 16:
+    assert ids[4] == [11] * 100                          # repeats separated by blanks survive (200 frames)
+
+
+def test_beam_search_rejects_bad_arguments(dev):
+  eng = make_engine([(1, 1, 16, 29, False)], dev)
+  eng.load_batch(np.zeros((2, 9, 16)), [9, 9])
+  eng.ctc_lens = torch.as_tensor(np.array([9, 9], dtype=np.int32)).to(dev)
+  from speecht_amd._lib import SpeechtHipError
+  with pytest.raises(SpeechtHipError, match='beam width'):
+    eng.beam_search_decode(65)
+
+
 @pytest.mark.parametrize('n,clip', [(1000, 5.0), (1 << 20, 5.0), (4099, 0.01)])
 def test_clip_adam(dev, n, clip):
   from speecht_amd import _lib

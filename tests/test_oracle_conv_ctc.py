@@ -221,3 +221,34 @@ def test_bf16_three_way_split_is_exact_and_six_terms_suffice():
     for ia, ib in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
       acc = (acc + Ap[ia][:, k:k + 16].astype(np.float64) @ Bp[ib][k:k + 16].astype(np.float64)).astype(np.float32)
   assert np.max(np.abs(acc - ref)) <= np.max(np.abs(chain - ref))
+
+
+def test_beam_search_oracle_equals_exhaustive_enumeration():
+  """With a beam wide enough to hold every prefix the search is exact: its top path is the most probable
+  labelling and its score that labelling's total probability (all 4^5 alignments enumerated)."""
+  import itertools
+  rng = np.random.default_rng(0)
+  T, C = 5, 4
+  for _ in range(10):
+    x = rng.standard_normal((T, 1, C)) * 2
+    lp = x[:, 0] - np.log(np.exp(x[:, 0]).sum(1, keepdims=True))
+    mass = {}
+    for path in itertools.product(range(C), repeat=T):
+      lab, prev = [], -1
+      for k in path:
+        if k != C - 1 and k != prev:
+          lab.append(k)
+        prev = k
+      mass[tuple(lab)] = np.logaddexp(mass.get(tuple(lab), -np.inf), sum(lp[t, k] for t, k in enumerate(path)))
+    best = max(mass, key=mass.get)
+    ids, score = O.ctc_beam_search_decode(x, [T], beam_width=1000)
+    assert tuple(ids[0]) == best
+    assert abs(score[0, 0] - mass[best]) < 1e-9
+
+
+def test_beam_search_oracle_beam1_and_empty():
+  rng = np.random.default_rng(1)
+  x = rng.standard_normal((30, 2, 29)) * 3
+  ids, score = O.ctc_beam_search_decode(x, [30, 0], beam_width=1)
+  assert ids[1] == [] and score[1, 0] == 0.0
+  assert len(ids[0]) > 0 and score[0, 0] < 0.0

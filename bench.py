@@ -161,7 +161,7 @@ def main():
   ap.add_argument('--seconds', type=float, default=10.0)
   ap.add_argument('--mels', type=int, default=80)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--no-alt', action='store_true', help='skip the experimental bf16x6 side measurement')
+  ap.add_argument('--no-alt', action='store_true', help='skip the bf16x6 / bf16 side measurements')
   ap.add_argument('--force-allreduce', action='store_true', help='run the RCCL all-reduce path even on 1 rank (self-test)')
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
                   help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
@@ -235,25 +235,33 @@ def main():
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
-      # Second measurement, NOT the headline: the experimental bf16x6 path (fp32 operands split exactly
-      # into 3 bf16 pieces, 6 cross terms on the bf16 matrix pipe, fp32 accumulate; passes the same
-      # parity tests).  Reported so that the two can be compared on the same box and inputs.
-      alt = Wav2LetterEngine(layers, device=dev, conv_mode='bf16x6')
-      alt.params.copy_(eng.params)
-      alt.load_batch(x, seq_lens)
-      alt.set_labels(labels)
-      for _ in range(args.warmup):
-        train_step(alt, x_dev, None, lr, global_batch)
-      torch.cuda.synchronize()
-      t1 = time.perf_counter()
-      for _ in range(args.steps):
-        train_step(alt, x_dev, None, lr, global_batch)
-      torch.cuda.synchronize()
-      alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
-      out['alt_bf16x6'] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),
-                           'dtype': 'f32 operands, exact 3-way bf16 split, 6 bf16 MFMA terms, f32 accumulate',
-                           'note': 'experimental opt-in (ST_CONV_MODE=bf16x6); not the headline value'}
-      del alt
+      # Side measurements on the same box and inputs, NOT the headline:
+      #  * bf16x6 (experimental): fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on the bf16
+      #    matrix pipe, fp32 accumulate; passes the same parity tests as the fp32 path.
+      #  * bf16: BASELINE configs[3]'s arithmetic ("bf16 activations / fp32 CTC") on one GPU -- reduced
+      #    precision by design, parity against the oracle's bf16 storage model (tests/test_gpu_bf16.py).
+      alts = [('alt_bf16x6', 'bf16x6', 'f32 operands, exact 3-way bf16 split, 6 bf16 MFMA terms, f32 accumulate',
+               'experimental opt-in (ST_CONV_MODE=bf16x6); not the headline value'),
+              ('alt_bf16', 'bf16', 'bf16 activations + activation gradients, f32 masters/accumulate/logits/CTC/Adam',
+               'configs[3] arithmetic on 1 GPU (ST_CONV_MODE=bf16); reduced precision, not the headline value')]
+      for key, mode, dtype, note in alts:
+        alt = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
+        alt.params.copy_(eng.params)
+        alt.load_batch(x, seq_lens)
+        alt.set_labels(labels)
+        for _ in range(args.warmup):
+          train_step(alt, x_dev, None, lr, global_batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+          train_step(alt, x_dev, None, lr, global_batch)
+        torch.cuda.synchronize()
+        alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        out[key] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),
+                    'step_tflops_algorithmic': round(step_gflop / alt_ms, 2),
+                    'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
+        del alt
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))

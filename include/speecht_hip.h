@@ -142,6 +142,35 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
                    const int64_t* frame_offsets, int64_t total_frames, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- bf16 activations (BASELINE config 4: "bf16 activations / fp32 CTC") ------------------
+ * Additional symbols, not a second code path for fp32.  Activations and activation gradients are
+ * stored in HBM as bf16 (round-to-nearest-even) with the SAME padded NWC geometry as the fp32
+ * tensors: every entry point takes the st_tensor3 for the geometry (its `base` is ignored) and a
+ * separate pointer to the bf16 data.  Filters stay fp32 masters (packed layout above) with a
+ * transposed bf16 copy [n_pad][k_pad] made by st_filters_bf16 (k_pad, n_pad from st_packed_dims;
+ * the back-prop operand is the same conversion of st_filters_flip_transpose_f32's output).
+ * Accumulation, bias, ReLU, the logits of the last layer, CTC, clip and Adam are fp32.
+ *   forward : y = relu?(conv(x) + bias) -> y_bf16 and/or y_f32 (either may be NULL)
+ *   bwd-data: dx = conv^T(dz) * [act > 0]  (stride-1 layers; act = the layer input, NULL = no mask)
+ *   bwd-filt: dpacked [k_pad][n_pad] (rows < width*c_pitch written) and dbias [n_pad], fp32;
+ *             stride 1 or 2; workspace from st_conv1d_bwd_filter_bf16_ws. */
+int st_cast_bf16(const float* src, size_t n, void* dst, void* stream);
+int st_filters_bf16(const float* packed, int k_pad, int n_pad, void* wt, void* stream);
+int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16,
+                           const float* bias, int width, int stride, int pad_left, int relu,
+                           const st_tensor3* y, void* y_bf16, float* y_f32, void* stream);
+size_t st_conv1d_bwd_data_bf16_ws(const st_tensor3* dz, const st_tensor3* dx, int width);
+int st_conv1d_nwc_bwd_data_bf16(const st_tensor3* dz, const void* dz_bf16, const void* wtt_bf16,
+                                int width, int pad_left, const st_tensor3* act, const void* act_bf16,
+                                const st_tensor3* dx, void* dx_bf16, void* workspace,
+                                size_t workspace_bytes, void* stream);
+size_t st_conv1d_bwd_filter_bf16_ws(const st_tensor3* x, const st_tensor3* dz, int width, int stride,
+                                    int pad_left);
+int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const st_tensor3* dz,
+                                  const void* dz_bf16, int width, int stride, int pad_left,
+                                  float* dpacked, float* dbias, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* ---- gradient exchange (RCCL over xGMI) ---------------------------------
  * The reference is single-replica (training.py:46); data parallelism follows from
  * speech_model.py:75-82 (mean loss over the batch, clip and Adam on the mean gradient).  One

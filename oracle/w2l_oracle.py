@@ -225,26 +225,43 @@ def xavier_init(layers, seed=42, bias_range=0.0, dtype=np.float64):
   return params
 
 
-def wav2letter_forward(x, params, layers, keep=False):
-  """speech_model.py:275-295 -> logits time-major [T', B, C] (and the per-layer outputs)."""
-  acts = [x]
-  h = x
-  for (F, b), (W, s, cin, cout, relu) in zip(params, layers):
-    h = conv1d_same_fwd(h, F, b, s, relu)
+def bf16_round(a):
+  """Round-to-nearest-even to bfloat16 precision (8 significand bits), returned as float64.
+  Storage model of BASELINE config 4 ("bf16 activations"): not a reference behaviour."""
+  u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+  u = (u + (((u >> 16) & 1) + 0x7FFF)) & np.uint32(0xFFFF0000)
+  return u.view(np.float32).astype(np.float64)
+
+
+def wav2letter_forward(x, params, layers, keep=False, store=None):
+  """speech_model.py:275-295 -> logits time-major [T', B, C] (and the per-layer outputs).
+
+  ``store`` (e.g. ``bf16_round``) models reduced-precision storage: it is applied to the input, to the
+  filters used in the products and to every layer output that is written back for the next layer -- not to
+  the biases, the accumulation or the logits."""
+  q = store if store is not None else (lambda a: a)
+  h = q(x)
+  acts = [h]
+  for i, ((F, b), (W, s, cin, cout, relu)) in enumerate(zip(params, layers)):
+    h = conv1d_same_fwd(h, q(F), b, s, relu)
+    if i + 1 < len(layers):
+      h = q(h)
     acts.append(h)
   logits = np.transpose(h, (1, 0, 2))
   return (logits, acts) if keep else logits
 
 
-def wav2letter_backward(acts, params, layers, dlogits_tm):
-  """Gradients of all filters/biases given d(avg_loss)/d(logits) time-major [T',B,C]."""
-  dy = np.transpose(dlogits_tm, (1, 0, 2))
+def wav2letter_backward(acts, params, layers, dlogits_tm, store=None):
+  """Gradients of all filters/biases given d(avg_loss)/d(logits) time-major [T',B,C].
+  ``store``: see wav2letter_forward; also applied to every activation gradient that is written back."""
+  q = store if store is not None else (lambda a: a)
+  dy = q(np.transpose(dlogits_tm, (1, 0, 2)))
   grads = [None] * len(layers)
   for i in reversed(range(len(layers))):
     (F, b), (W, s, cin, cout, relu) = params[i], layers[i]
-    dx, dF, db = conv1d_same_bwd(acts[i], F, acts[i + 1], dy, s, relu, need_dx=(i > 0))
+    dx, dF, db = conv1d_same_bwd(acts[i], q(F), acts[i + 1], dy, s, relu, need_dx=(i > 0))
     grads[i] = (dF, db)
-    dy = dx
+    dy = q(dx) if dx is not None else None
   return grads
 
 
@@ -445,17 +462,17 @@ def adam_tf_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-3):
 # one training step of the whole path  (speech_model.py:53-82 via step(), :197-235)
 # ----------------------------------------------------------------------------------------
 def train_step(x, seq_lens, labels, params, layers, opt_state, lr=1e-4, max_grad_norm=5.0,
-               update=True):
+               update=True, store=None):
   """x [B,T,C] padded batch, seq_lens [B] unpadded frames, labels list of id lists.
 
   opt_state = dict(step=int, m=[(mF,mb)...], v=[...]).  Returns dict with avg_loss, loss,
   logits (time-major), grads (unclipped), grad_norm and the new params/opt_state.
   """
-  logits, acts = wav2letter_forward(x, params, layers, keep=True)
+  logits, acts = wav2letter_forward(x, params, layers, keep=True, store=store)
   B = x.shape[0]
   loss, g_logits = ctc_loss_and_grad(logits, labels, np.asarray(seq_lens) // 2)
   avg_loss = float(np.mean(loss))
-  grads = wav2letter_backward(acts, params, layers, g_logits / B)
+  grads = wav2letter_backward(acts, params, layers, g_logits / B, store=store)
   flat = [g for pair in grads for g in pair]
   clipped, gn = clip_by_global_norm(flat, max_grad_norm)
   out = dict(avg_loss=avg_loss, loss=loss, logits=logits, grads=grads, grad_norm=gn)

@@ -49,6 +49,16 @@ _SIGNATURES = {
     'st_melspec_ws': (c_size_t, [c_int, c_int64, c_int]),
     'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_cast_bf16': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    'st_filters_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'st_conv1d_nwc_fwd_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p,
+                                       c_void_p, c_void_p]),
+    'st_conv1d_bwd_data_bf16_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_conv1d_nwc_bwd_data_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, c_void_p, _T3P, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    'st_conv1d_bwd_filter_bf16_ws': (c_size_t, [_T3P, _T3P, c_int, c_int, c_int]),
+    'st_conv1d_nwc_bwd_filter_bf16': (c_int, [_T3P, c_void_p, _T3P, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]),
     'st_comm_unique_id_bytes': (c_int, []),
     'st_comm_unique_id': (c_int, [c_void_p, c_size_t]),
     'st_comm_init': (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p)]),

@@ -1,0 +1,792 @@
+// Convolution GEMMs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation).  One kernel
+// template, two operand models selected by NP (bf16 planes per operand):
+//
+//   NP = 1  "bf16 activations" (BASELINE config 4): activations and activation gradients live in HBM as
+//           bf16 (round-to-nearest-even, written once by the producing kernel's epilogue), filters are
+//           fp32 masters with a bf16 transposed copy, every accumulation and the bias/ReLU epilogue is
+//           fp32, the last layer's logits and everything in CTC / clip / Adam stay fp32.
+//   NP = 3  "bf16x6" (opt-in, fp32-accurate), described next.
+//
+// bf16x6: fp32-accurate convolution GEMM on the bf16 matrix pipe.
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces a = a_h + a_m + a_l (8 + 8 + 8
+// significand bits, same exponent range as fp32), and a*b is evaluated as the six largest cross
+// terms  a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_l b_h + a_m b_m  on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation; the dropped terms are below 2^-24 relative.  Products of bf16 pairs are exact in
+// fp32, so the result is at least as accurate as an fp32 FMA chain (numpy model, K = 8000: error
+// 2.0e-6 vs 5.9e-6 for the chain, scale 2.6) while the matrix pipe runs 16/6 = 2.7x the fp32-MFMA
+// rate.  (The same idea as cuBLAS's "BF16x9" fp32 emulation.)
+//
+// Operands are pre-split in HBM: activation planes keep the padded NWC geometry of the fp32 tensor
+// (2-byte elements), filter planes are stored transposed [n_pad][k_pad] so that both MFMA operands
+// are reduction-contiguous 16-byte fragments.
+#include <algorithm>
+#include <cstdlib>
+
+#include "st_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BKB = 32;           // bf16 elements of reduction per LDS stage (2 MFMA k-steps)
+constexpr int NT_ = 256;
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;          // exact
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);            // exact: at most 8 significant bits remain
+}
+
+// one fp32 value -> NP planes at element offset o (NP = 1: plain round-to-nearest-even cast)
+template <int NP>
+__device__ __forceinline__ void store_planes(float v, __bf16* dst, size_t plane, size_t o) {
+  if constexpr (NP == 1) {
+    dst[o] = (__bf16)v;
+  } else {
+    __bf16 h, m, l;
+    split3(v, h, m, l);
+    dst[o] = h; dst[plane + o] = m; dst[2 * plane + o] = l;
+  }
+}
+
+// elementwise split / cast of a padded tensor (same geometry for every plane)
+template <int NP>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, size_t n4, __bf16* __restrict__ dst) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    if constexpr (NP == 1) {
+      reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    } else {
+      __bf16 h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(v[e], h[e], m[e], l[e]);
+      reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{h[0], h[1], h[2], h[3]};
+      reinterpret_cast<bf16x4*>(dst + 4 * n4)[i] = bf16x4{m[0], m[1], m[2], m[3]};
+      reinterpret_cast<bf16x4*>(dst + 8 * n4)[i] = bf16x4{l[0], l[1], l[2], l[3]};
+    }
+  }
+}
+
+// packed filters [Kp][Np] fp32 -> NP planes [Np][Kp] bf16 (32x32 LDS transpose)
+template <int NP>
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ packed, int Kp, int Np,
+                                                               __bf16* __restrict__ planes) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + r < Kp) ? packed[(long)(k0 + r) * Np + n0 + tx] : 0.f;
+  __syncthreads();
+  const size_t plane = (size_t)Np * Kp;
+  for (int r = ty; r < 32; r += 8) {
+    if (k0 + tx < Kp) store_planes<NP>(tile[tx][r], planes, plane, (size_t)(n0 + r) * Kp + k0 + tx);
+  }
+}
+
+// src: padded NWC fp32 tensor.  dst planes [c_rows][batch * tq] (reduction-major for the filter
+// gradient): plane[c][b * tq + j] = src[b][row0 + j][c] for j < rows; everything else stays zero.
+template <int NP>
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, int rows, int row0,
+                                                               int t_pitch, int c_pitch, int tq, size_t plane,
+                                                               __bf16* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* s = src + ((long)b * t_pitch + row0) * c_pitch;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (j0 + r < rows && c0 + tx < c_pitch) ? s[(long)(j0 + r) * c_pitch + c0 + tx] : 0.f;
+  __syncthreads();
+  const long row_len = (long)gridDim.z * tq;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, j = j0 + tx;
+    if (c < c_pitch && j < rows) store_planes<NP>(tile[tx][r], dst, plane, (size_t)c * row_len + (size_t)b * tq + j);
+  }
+}
+
+// bf16 source (bf16-activation mode): dst[c][b * tq + j] = src[b][row0 + step * j][c] for j < rows, c < c_pitch;
+// zero for every other (c < c_rows, j < tq), so the GEMM never meets stale bits.
+// step 2 de-interleaves the frames of a stride-2 layer's input into two phase planes (one launch each).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int rows, int row0,
+                                                             int step, int t_pitch, int c_pitch, int c_rows, int tq,
+                                                             unsigned short* __restrict__ dst) {
+  __shared__ unsigned short tile[32][34];
+  const int b = blockIdx.z;
+  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const unsigned short* s = src + ((long)b * t_pitch + row0) * c_pitch;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (j0 + r < rows && c0 + tx < c_pitch) ? s[(long)(j0 + r) * step * c_pitch + c0 + tx] : (unsigned short)0;
+  __syncthreads();
+  const long row_len = (long)gridDim.z * tq;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, j = j0 + tx;
+    if (c < c_rows && j < tq) dst[(size_t)c * row_len + (size_t)b * tq + j] = tile[tx][r];   // zeros outside the source
+  }
+}
+
+struct RowMapB {
+  int frames, row_stride;
+  long batch_stride, row0;
+  int phase_shift, phase_mask;     // b -> (b >> shift) * batch_stride + (b & mask) * phase_stride
+  long phase_stride;
+  __device__ __forceinline__ long off(int m) const {
+    int b = m / frames;
+    int t = m - b * frames;
+    return (long)(b >> phase_shift) * batch_stride + (long)(b & phase_mask) * phase_stride + row0 +
+           (long)t * row_stride;
+  }
+};
+
+struct X6Params {
+  const __bf16* A; size_t a_plane;       // NP activation planes, element stride between planes
+  RowMapB amap;
+  const __bf16* B; size_t b_plane;       // NP transposed filter planes [Np][Kp]
+  float* C; RowMapB cmap;                // fp32 output (nullable when only planes are wanted)
+  const float* bias;
+  const float* mask;                     // relu mask source (back-prop to the input): fp32 tensor ...
+  const __bf16* mask_b;                  // ... or bf16 tensor; both may be null
+  RowMapB mmap;
+  __bf16* Cp; size_t c_plane;            // optional: the NP planes of the output (same geometry as C)
+  int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
+  int tiles_m, tiles_n, chunk;
+  int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+};
+
+// Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
+// three planes of both operands (1 KiB DMA pieces), so a stage costs 6 * (64 / rows-per-piece)
+// DMA instructions per wave: 12 for <128, 2x2, BK 32>, 6 for <256, 2x4, BK 16>.
+template <int BT, int WM, int WN, int BK, int NP>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = BT, BN = BT;
+  static_assert(BT == 32 * NW && (BK == 16 || BK == 32 || BK == 64) && (NP == 1 || NP == 3), "tile config");
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int KS = BK / 16;                        // MFMA k-steps per stage
+  constexpr int SLOTS = BK / 8;                      // 16-byte slots per row
+  constexpr int RPB = 128 / BK;                      // rows per 256-byte bank span
+  constexpr int RPP = 512 / BK;                      // rows per 1-KiB DMA piece
+  constexpr int PPW = 32 / RPP;                      // pieces per wave, plane and operand
+  constexpr int PL = BM * BK;                        // elements per plane tile
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NP * PL * 2 + 12 * BM];
+  unsigned short* const As = smem;                   // [buf][plane][BM][BK]
+  unsigned short* const Bs = smem + 2 * NP * PL;
+  long* const a_off = reinterpret_cast<long*>(smem + 4 * NP * PL);
+  long* const c_off = a_off + BM;
+  long* const m_off = c_off + BM;
+
+  const int split = blockIdx.x / (p.chunk * 8);
+  const int bid = blockIdx.x - split * (p.chunk * 8);
+  const int idx = (bid & 7) * p.chunk + (bid >> 3);
+  if ((bid >> 3) >= p.chunk || idx >= p.tiles_m * p.tiles_n) return;
+  const int tile_n = idx / p.tiles_m;
+  const int tile_m = idx - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  if (tid < BM) {
+    int m = m0 + tid;
+    bool valid = m < p.M;
+    int mm = valid ? m : p.M - 1;
+    a_off[tid] = p.amap.off(mm);
+    c_off[tid] = valid ? p.cmap.off(mm) : -1;
+    m_off[tid] = (p.mask || p.mask_b) ? p.mmap.off(mm) : 0;
+  }
+  __syncthreads();
+
+  // physical 16-byte slot s of row r holds source slot s ^ ((r / RPB) % SLOTS)
+  const int prow = lane / SLOTS, pslot = lane % SLOTS;
+  const __bf16* asrc[PPW];
+  const __bf16* bsrc[PPW];
+  int slot8[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int r = wave * 32 + i * RPP + prow;
+    asrc[i] = p.A + a_off[r];
+    slot8[i] = (pslot ^ ((r / RPB) % SLOTS)) * 8;
+    bsrc[i] = p.B + (long)min(n0 + r, p.Np - 1) * p.Kp;
+  }
+  const int ktail = p.Kvalid - 8;
+  constexpr int N_DMA = 2 * NP * PPW;
+  auto dma_piece = [&](int pc, int k0, int buf) {        // pc -> (operand, plane, i)
+    const int op = pc / (NP * PPW), pl = (pc / PPW) % NP, i = pc % PPW;
+    if (op == 0) {
+      const __bf16* g = asrc[i] + pl * p.a_plane + min(k0 + slot8[i], ktail);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (buf * NP + pl) * PL + (wave * 32 + i * RPP) * BK), 16, 0, 0);
+    } else {
+      const __bf16* g = bsrc[i] + pl * p.b_plane + min(k0 + slot8[i], p.Kp - 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (buf * NP + pl) * PL + (wave * 32 + i * RPP) * BK), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses (elements): row * BK + ((KS-step slot) ^ swizzle) * 8
+  int a_frag[KS], b_frag[KS];
+  {
+    const int ra = wm * WTM + l31, rb = wn * WTN + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a_frag[ks] = ra * BK + (((2 * ks + h) ^ ((ra / RPB) % SLOTS)) * 8);
+      b_frag[ks] = rb * BK + (((2 * ks + h) ^ ((rb / RPB) % SLOTS)) * 8);
+    }
+  }
+
+  const bool tap_inner = p.taps > 1;
+  const int chunks = (p.cp + BK - 1) / BK;
+  const int nk_all = tap_inner ? chunks * p.taps : (p.Kvalid + BK - 1) / BK;
+  // reduction split (filter gradients of the small layers, back-prop through L8): this workgroup owns a
+  // contiguous range of stages
+  // (tap-inner convolutions split over channel chunks, every split walks all taps)
+  const int units = tap_inner ? chunks : nk_all;
+  const int per_split = (units + p.splits - 1) / p.splits;
+  const int unit0 = split * per_split;
+  const int nk = max(min(per_split, units - unit0), 0) * (tap_inner ? p.taps : 1);
+  int tap = 0, chunk = unit0;
+  auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
+  auto tile_ks = [&](int t, int c) {
+    const int valid = tap_inner ? p.cp - c * BK : p.Kvalid - c * BK;
+    return valid >= BK ? KS : (valid + 15) / 16;
+  };
+#pragma unroll
+  for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, tile_k0(tap, chunk), 0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int nks = tile_ks(tap, chunk);
+    int ntap = tap, nchunk = chunk;
+    if (tap_inner) { if (++ntap == p.taps) { ntap = 0; ++nchunk; } } else { ++nchunk; }
+    const bool more = kt + 1 < nk;
+    const int nk0 = tile_k0(ntap, nchunk);
+    tap = ntap; chunk = nchunk;
+    const unsigned short* as = As + cur * NP * PL;
+    const unsigned short* bs = Bs + cur * NP * PL;
+    bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
+    auto read_frags = [&](int ks) {
+#pragma unroll
+      for (int pl = NP - 1; pl >= 0; --pl) {         // low planes first: their MFMAs are issued first
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[ks][pl][i] = *reinterpret_cast<const bf16x8*>(as + pl * PL + a_frag[ks] + i * 32 * BK);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[ks][pl][n] = *reinterpret_cast<const bf16x8*>(bs + pl * PL + b_frag[ks] + n * 32 * BK);
+      }
+    };
+    read_frags(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (more) {
+#pragma unroll
+        for (int pc = ks * (N_DMA / KS); pc < (ks + 1) * (N_DMA / KS); ++pc) dma_piece(pc, nk0, cur ^ 1);
+      }
+      if (ks + 1 < KS) read_frags(ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < nks) {
+        constexpr int TERMS = NP == 3 ? 6 : 1;
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) {           // smallest terms first
+          constexpr int TA[6] = {NP - 1, 0, NP / 2, NP / 2, 0, 0}, TB[6] = {0, NP - 1, NP / 2, 0, NP / 2, 0};
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][TB[t]][n], af[ks][TA[t]][i], acc[i][n], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue.  The MFMAs above were issued with the operands swapped (filter fragment first), so the
+  // accumulator holds the TRANSPOSED 32x32 sub-tile: lane&31 = output row m, register r = output column
+  // (r&3) + 8*(r>>2) + 4*h.  Every lane therefore owns runs of 4 consecutive channels of one row and the
+  // epilogue moves 8-byte (bf16x4) / 16-byte (fp32x4) pieces instead of single elements.
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 32 + l31;
+    const long co = c_off[row];
+    const long mo = m_off[row];                          // valid for every tile row (clamped)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      // the ReLU mask of the 4 runs first: loads interleaved with the stores below would be serialised
+      // (for all the compiler knows the output may alias the mask source)
+      bool keep[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * WTN + n * 32 + 8 * g + 4 * h;
+        const int colc = col < p.n_store ? col : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[4 * g + e] = true;
+        if (p.mask) {
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mask + mo + colc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep[4 * g + e] = mv[e] > 0.f;
+        }
+        if (p.mask_b) {
+          const bf16x4 mv = *reinterpret_cast<const bf16x4*>(p.mask_b + mo + colc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep[4 * g + e] = (float)mv[e] > 0.f;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * WTN + n * 32 + 8 * g + 4 * h;
+        if (co < 0 || col >= p.n_store) continue;         // n_store is a multiple of 16: runs are all-or-nothing
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][n][4 * g + e];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = keep[4 * g + e] ? v[e] : 0.f;
+        }
+        if (p.C) *reinterpret_cast<f32x4*>(p.C + (long)split * p.slab_stride + co + col) = v;
+        if (p.Cp) {                                       // the consumer's operand, written once
+          if constexpr (NP == 1) {
+            *reinterpret_cast<bf16x4*>(p.Cp + co + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          } else {
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __bf16 sh, sm, sl;
+              split3(v[e], sh, sm, sl);
+              ph[e] = sh; pm[e] = sm; pl[e] = sl;
+            }
+            *reinterpret_cast<bf16x4*>(p.Cp + co + col) = ph;
+            *reinterpret_cast<bf16x4*>(p.Cp + p.c_plane + co + col) = pm;
+            *reinterpret_cast<bf16x4*>(p.Cp + 2 * p.c_plane + co + col) = pl;
+          }
+        }
+      }
+    }
+  }
+}
+
+int npad_of(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)st::round_up(cout, 128)); }
+
+// out[i] = sum_s slabs[s][i]
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int n_slabs, size_t n4,
+                                                       float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int s = 1; s < n_slabs; ++s) a += reinterpret_cast<const f32x4*>(slabs + (size_t)s * n4 * 4)[i];
+    reinterpret_cast<f32x4*>(out)[i] = a;
+  }
+}
+
+// second half of a split convolution: out = [mask] relu?(sum_s slabs[s] + bias) -> bf16 padded NWC tensor
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(const float* __restrict__ slabs, int n_slabs, long slab_stride,
+                                                            int M, int Np, int n_store, const float* __restrict__ bias,
+                                                            int relu, const __bf16* __restrict__ mask_b, RowMapB mmap,
+                                                            RowMapB cmap, __bf16* __restrict__ out) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int q = n_store / 4;                                     // n_store is a multiple of 16
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)M * q; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / q), c = (int)(idx - (long)m * q) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(slabs + (long)m * Np + c);
+    for (int s = 1; s < n_slabs; ++s) a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + (long)m * Np + c);
+    if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
+    bf16x4 keep{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    if (mask_b) keep = *reinterpret_cast<const bf16x4*>(mask_b + mmap.off(m) + c);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = relu ? fmaxf(a[e], 0.f) : a[e];
+      o[e] = (__bf16)((float)keep[e] > 0.f ? v : 0.f);
+    }
+    *reinterpret_cast<bf16x4*>(out + cmap.off(m) + c) = o;
+  }
+}
+
+// bias gradient from the reduction-major copy of dz: dbias[n] = sum_r dzt[n][r] (fp32 accumulation)
+__global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restrict__ dzt, long red, float* __restrict__ out) {
+  __shared__ float part[256];
+  const __bf16* row = dzt + (size_t)blockIdx.x * red;
+  float acc = 0.f;
+  for (long r = (long)threadIdx.x * 8; r < red; r += 256 * 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)v[e];
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+template <int NP>
+int launch_gemm(X6Params& p, hipStream_t s) {
+  static const int big = getenv("ST_X6_TILE") ? atoi(getenv("ST_X6_TILE")) : 256;
+  if (p.splits < 1) p.splits = 1;
+  const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
+  const int BT = (big == 256 && fits256 && (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192) ? 256 : 128;
+  p.tiles_m = st::ceil_div(p.M, BT);
+  p.tiles_n = st::ceil_div(p.Np, BT);
+  p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
+  const dim3 grid(p.chunk * 8 * p.splits);
+  if constexpr (NP == 3) {
+    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3>), grid, dim3(512), 0, s, p);
+    else if (big == 16) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 16, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 3>), grid, dim3(256), 0, s, p);
+  } else {
+    static const int bk = getenv("ST_BF16_BK") ? atoi(getenv("ST_BF16_BK")) : 64;
+    if (BT == 256 && bk == 64) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 64, 1>), grid, dim3(512), 0, s, p);
+    else if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1>), grid, dim3(512), 0, s, p);
+    else if (bk == 64) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 64, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 1>), grid, dim3(256), 0, s, p);
+  }
+  return st::check_launch("gemm_nn_bf16");
+}
+
+RowMapB map_of(const st_tensor3& t, int first_row, int frame_stride, int frames) {
+  RowMapB m{};
+  m.frames = frames;
+  m.row_stride = frame_stride * t.c_pitch;
+  m.batch_stride = (long)t.t_pitch * t.c_pitch;
+  m.row0 = (long)first_row * t.c_pitch;
+  return m;
+}
+
+// ---- shared bodies of the forward / back-prop-to-input / filter-gradient entry points ------------------
+template <int NP>
+int conv_fwd(const st_tensor3* x, const void* x_planes, const void* w_planes, const float* bias, int width, int stride,
+             int pad_left, int relu, const st_tensor3* y, float* y_f32, void* y_planes, hipStream_t s) {
+  X6Params p{};
+  p.A = reinterpret_cast<const __bf16*>(x_planes);
+  p.a_plane = (size_t)x->batch * x->t_pitch * x->c_pitch;
+  p.amap = map_of(*x, x->halo - pad_left, stride, y->frames);
+  p.Np = npad_of(y->channels);
+  p.Kvalid = width * x->c_pitch;
+  p.Kp = (int)st::round_up(p.Kvalid, 32);
+  p.B = reinterpret_cast<const __bf16*>(w_planes);
+  p.b_plane = (size_t)p.Np * p.Kp;
+  p.C = y_f32;
+  p.cmap = map_of(*y, y->halo, 1, y->frames);
+  p.Cp = reinterpret_cast<__bf16*>(y_planes);
+  p.c_plane = (size_t)y->batch * y->t_pitch * y->c_pitch;
+  p.bias = bias;
+  p.M = y->batch * y->frames;
+  p.n_store = std::min(y->c_pitch, p.Np);
+  p.relu = relu;
+  p.taps = width;
+  p.cp = x->c_pitch;
+  return launch_gemm<NP>(p, s);
+}
+
+// channel-chunk split of a tap-inner convolution whose tile grid cannot fill the chip (back-prop through L8:
+// 252 tiles, 1000 stages each): 1 = no split
+int bwd_data_splits(const st_tensor3& dz, const st_tensor3& dx, int width) {
+  const long tiles = (long)st::ceil_div(dx.batch * dx.frames, 128) * st::ceil_div(npad_of(dx.channels), 128);
+  const int chunks = st::ceil_div(dz.c_pitch, 64);
+  if (tiles >= 384 || (long)chunks * width < 128) return 1;
+  return (int)std::max(1L, std::min<long>(st::ceil_div(768, (int)tiles), chunks / 4));
+}
+
+template <int NP>
+int conv_bwd_data(const st_tensor3* dz, const void* dz_planes, const void* wt_planes, int width, int pad_left,
+                  const st_tensor3* act, const float* act_f32, const void* act_bf16, const st_tensor3* dx,
+                  float* dx_f32, void* dx_planes, hipStream_t s, int splits = 1, float* slabs = nullptr) {
+  const int lead = width - 1 - pad_left;
+  X6Params p{};
+  p.A = reinterpret_cast<const __bf16*>(dz_planes);
+  p.a_plane = (size_t)dz->batch * dz->t_pitch * dz->c_pitch;
+  p.amap = map_of(*dz, dz->halo - lead, 1, dx->frames);
+  p.Np = npad_of(dx->channels);
+  p.Kvalid = width * dz->c_pitch;
+  p.Kp = (int)st::round_up(p.Kvalid, 32);
+  p.B = reinterpret_cast<const __bf16*>(wt_planes);
+  p.b_plane = (size_t)p.Np * p.Kp;
+  p.C = dx_f32;
+  p.cmap = map_of(*dx, dx->halo, 1, dx->frames);
+  p.Cp = reinterpret_cast<__bf16*>(dx_planes);
+  p.c_plane = (size_t)dx->batch * dx->t_pitch * dx->c_pitch;
+  if (act) {
+    p.mask = act_f32;
+    p.mask_b = reinterpret_cast<const __bf16*>(act_bf16);
+    p.mmap = map_of(*act, act->halo, 1, act->frames);
+  }
+  p.M = dx->batch * dx->frames;
+  p.n_store = std::min(dx->c_pitch, p.Np);
+  p.taps = width;
+  p.cp = dz->c_pitch;
+  if (splits <= 1) return launch_gemm<NP>(p, s);
+  // split: fp32 partial sums [split][M][Np], then one pass that sums, masks and writes the bf16 tensor
+  const RowMapB out_map = p.cmap, mask_map = p.mmap;
+  const __bf16* mask_b = p.mask_b;
+  __bf16* out = p.Cp;
+  p.C = slabs; p.Cp = nullptr; p.mask = nullptr; p.mask_b = nullptr;
+  p.cmap = RowMapB{};
+  p.cmap.frames = p.M;
+  p.cmap.row_stride = p.Np;
+  p.splits = splits;
+  p.slab_stride = (long)p.M * p.Np;
+  if (int e = launch_gemm<NP>(p, s)) return e;
+  const long work = (long)p.M * (p.n_store / 4);
+  hipLaunchKernelGGL(slab_epilogue_kernel, dim3((unsigned)std::min<long>((work + 255) / 256, 4096)), dim3(256), 0, s, slabs,
+                     splits, p.slab_stride, p.M, p.Np, p.n_store, (const float*)nullptr, 0, mask_b, mask_map, out_map, out);
+  return st::check_launch("slab_epilogue");
+}
+
+// dF[(w,c)][n] = sum_r XT[c][r + shift(w)] * dZT[n][r], r = b * tq + t; `phases` = stride of the layer (1 or 2):
+// tap w reads phase plane (w & (phases-1)) at shift w / phases
+template <int NP>
+int conv_bwd_filter(const void* xt_planes, size_t xt_plane, long xt_phase_stride, int phases, const void* dzt_planes,
+                    int batch, int tq, int width, int cin_pitch, int x_first_row, int cout, float* dpacked, int splits,
+                    float* slabs, hipStream_t s) {
+  X6Params p{};
+  const long red = (long)batch * tq;                   // reduction length
+  p.A = reinterpret_cast<const __bf16*>(xt_planes);
+  p.a_plane = xt_plane;
+  p.amap.frames = cin_pitch;                           // output row k = w * cin_pitch + c
+  p.amap.batch_stride = 1;                             // a tap shifts the window by one (phase) frame
+  p.amap.row_stride = (int)red;                        // channel c selects the plane row
+  p.amap.row0 = x_first_row;
+  p.amap.phase_shift = phases == 2 ? 1 : 0;
+  p.amap.phase_mask = phases - 1;
+  p.amap.phase_stride = xt_phase_stride;
+  p.Np = npad_of(cout);
+  p.Kvalid = (int)red;
+  p.Kp = (int)red;
+  p.B = reinterpret_cast<const __bf16*>(dzt_planes);
+  p.b_plane = (size_t)p.Np * red;
+  p.M = width * cin_pitch;
+  p.cmap.frames = p.M;
+  p.cmap.row_stride = p.Np;
+  p.n_store = p.Np;
+  p.taps = 1;
+  p.cp = cin_pitch;
+  p.splits = splits;
+  p.slab_stride = (long)p.M * p.Np;
+  p.C = splits > 1 ? slabs : dpacked;
+  if (int e = launch_gemm<NP>(p, s)) return e;
+  if (splits > 1) {
+    const size_t n4 = (size_t)p.M * p.Np / 4;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, slabs,
+                       splits, n4, dpacked);
+    return st::check_launch("slab_sum");
+  }
+  return ST_OK;
+}
+
+// geometry of the filter-gradient workspace of the bf16-activation path
+struct WgradPlan {
+  int tq, phases, splits, n_pad;
+  long red;
+  size_t xt_phase_elems, xt_bytes, dzt_bytes, slab_bytes;
+};
+WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int stride, int x_first_row) {
+  WgradPlan w{};
+  w.phases = stride;
+  const int x_rows = st::ceil_div(x.t_pitch - x_first_row, stride);
+  w.tq = (int)st::round_up(std::max(x_rows, dz.frames), 32);
+  w.red = (long)x.batch * w.tq;
+  w.n_pad = npad_of(dz.channels);
+  w.xt_phase_elems = (size_t)x.c_pitch * w.red + 4096;           // slack: the last taps read past the last row
+  w.xt_bytes = st::round_up(w.xt_phase_elems * stride * 2, 256);
+  w.dzt_bytes = st::round_up((size_t)w.n_pad * w.red * 2, 256);
+  const long M = (long)width * x.c_pitch;
+  const long tiles = st::ceil_div((int)M, 128) * (long)st::ceil_div(w.n_pad, 128);
+  const int stages = (int)((w.red + 63) / 64);
+  w.splits = tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(st::ceil_div(512, (int)tiles), stages / 8));
+  w.slab_bytes = w.splits > 1 ? (size_t)w.splits * M * w.n_pad * 4 : 0;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ======== bf16x6 (experimental, opt-in) =================================================================
+// planes: 3 * n bf16 elements (h | m | l)
+int st_exp_split3_bf16(const float* src, size_t n, void* planes, void* stream) {
+  ST_REQUIRE(src && planes && n % 4 == 0, "split3: bad args");
+  const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_kernel<3>, dim3(blocks), dim3(256), 0, st::as_stream(stream), src, n / 4,
+                     reinterpret_cast<__bf16*>(planes));
+  return st::check_launch("split3");
+}
+
+// packed [k_pad][n_pad] fp32 -> planes 3 x [n_pad][k_pad] bf16
+int st_exp_split3_transpose_bf16(const float* packed, int k_pad, int n_pad, void* planes, void* stream) {
+  ST_REQUIRE(packed && planes && k_pad % 32 == 0 && n_pad % 32 == 0, "split3_transpose: bad args");
+  hipLaunchKernelGGL(split_transpose_kernel<3>, dim3(k_pad / 32, n_pad / 32), dim3(256), 0, st::as_stream(stream),
+                     packed, k_pad, n_pad, reinterpret_cast<__bf16*>(planes));
+  return st::check_launch("split3_transpose");
+}
+
+// forward conv on the bf16x6 path; x gives the geometry of the three activation planes;
+// y_planes (nullable) receives the three planes of the output for the next layer
+int st_exp_conv1d_fwd_bf16x6(const st_tensor3* x, const void* x_planes, const void* w_planes, const float* bias,
+                             int width, int stride, int pad_left, int relu, const st_tensor3* y, void* y_planes,
+                             void* stream) {
+  ST_REQUIRE(x && y && x_planes && w_planes && y->base, "conv bf16x6: null argument");
+  ST_REQUIRE(x->halo >= pad_left && y->frames == st::ceil_div(x->frames, stride) && x->c_pitch % 16 == 0,
+             "conv bf16x6: bad geometry");
+  ST_REQUIRE(npad_of(y->channels) % 128 == 0, "conv bf16x6: n_pad must be a multiple of 128");
+  return conv_fwd<3>(x, x_planes, w_planes, bias, width, stride, pad_left, relu, y, y->base, y_planes,
+                     st::as_stream(stream));
+}
+
+// back-prop to the layer input on the bf16x6 path (stride-1 layers): dz planes x planes of the
+// flipped/transposed filter operand; act (nullable) is the ReLU mask source
+int st_exp_conv1d_bwd_data_bf16x6(const st_tensor3* dz, const void* dz_planes, const void* wt_planes, int width,
+                                  int pad_left, const st_tensor3* act, const st_tensor3* dx, void* dx_planes,
+                                  void* stream) {
+  ST_REQUIRE(dz && dx && dz_planes && wt_planes && dx->base, "conv bwd bf16x6: null argument");
+  const int lead = width - 1 - pad_left;
+  ST_REQUIRE(lead >= 0 && dz->halo >= lead && dz->frames == dx->frames && dz->batch == dx->batch, "conv bwd bf16x6: bad geometry");
+  ST_REQUIRE(npad_of(dx->channels) % 128 == 0, "conv bwd bf16x6: n_pad must be a multiple of 128");
+  return conv_bwd_data<3>(dz, dz_planes, wt_planes, width, pad_left, act, act ? act->base : nullptr, nullptr, dx,
+                          dx->base, dx_planes, st::as_stream(stream));
+}
+
+// planes [c_rows][batch * tq] of a padded tensor, rows [row0, row0 + rows) of every utterance
+int st_exp_transpose_split3_bf16(const st_tensor3* t, int row0, int rows, int tq, size_t plane_elems, void* planes,
+                                 void* stream) {
+  ST_REQUIRE(t && t->base && planes && rows > 0 && row0 >= 0 && row0 + rows <= t->t_pitch && tq >= rows &&
+                 plane_elems >= (size_t)t->c_pitch * t->batch * tq, "transpose_split3: bad args");
+  dim3 grid(st::ceil_div(rows, 32), st::ceil_div(t->c_pitch, 32), t->batch);
+  hipLaunchKernelGGL(transpose_split_kernel<3>, grid, dim3(256), 0, st::as_stream(stream), t->base, rows, row0,
+                     t->t_pitch, t->c_pitch, tq, plane_elems, reinterpret_cast<__bf16*>(planes));
+  return st::check_launch("transpose_split3");
+}
+
+// filter gradient on the bf16x6 path (stride-1 layers): dF[(w,c)][n] = sum_r XT[c][r + w + lead] * dZT[n][r],
+// r = b * tq + t.  xt_planes: [x.c_pitch][batch*tq (+ slack)], dzt_planes: [n_pad][batch*tq].
+int st_exp_conv1d_bwd_filter_bf16x6(const void* xt_planes, const void* dzt_planes, int batch, int tq, int width,
+                                    int cin_pitch, int x_first_row, int cout, float* dpacked, void* stream) {
+  ST_REQUIRE(xt_planes && dzt_planes && dpacked && tq % 32 == 0 && cin_pitch % 16 == 0, "bwd_filter bf16x6: bad args");
+  const long red = (long)batch * tq;
+  ST_REQUIRE(npad_of(cout) % 128 == 0 && red < (1L << 31), "bwd_filter bf16x6: unsupported shape");
+  return conv_bwd_filter<3>(xt_planes, (size_t)cin_pitch * red + 4096, 0, 1, dzt_planes, batch, tq, width, cin_pitch,
+                            x_first_row, cout, dpacked, 1, nullptr, st::as_stream(stream));
+}
+
+// ======== bf16 activations (BASELINE config 4; declared in include/speecht_hip.h) ======================
+int st_cast_bf16(const float* src, size_t n, void* dst, void* stream) {
+  ST_REQUIRE(src && dst && n % 4 == 0, "st_cast_bf16: null argument or n not a multiple of 4");
+  if (n == 0) return ST_OK;
+  const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_kernel<1>, dim3(blocks), dim3(256), 0, st::as_stream(stream), src, n / 4,
+                     reinterpret_cast<__bf16*>(dst));
+  return st::check_launch("cast_bf16");
+}
+
+int st_filters_bf16(const float* packed, int k_pad, int n_pad, void* wt, void* stream) {
+  ST_REQUIRE(packed && wt && k_pad > 0 && n_pad > 0 && k_pad % 32 == 0 && n_pad % 32 == 0, "st_filters_bf16: bad args");
+  hipLaunchKernelGGL(split_transpose_kernel<1>, dim3(k_pad / 32, n_pad / 32), dim3(256), 0, st::as_stream(stream),
+                     packed, k_pad, n_pad, reinterpret_cast<__bf16*>(wt));
+  return st::check_launch("filters_bf16");
+}
+
+int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16, const float* bias, int width,
+                           int stride, int pad_left, int relu, const st_tensor3* y, void* y_bf16, float* y_f32,
+                           void* stream) {
+  ST_REQUIRE(x && y && x_bf16 && wt_bf16 && (y_bf16 || y_f32), "conv fwd bf16: null argument");
+  ST_REQUIRE(width >= 1 && stride >= 1 && x->halo >= pad_left && y->frames == st::ceil_div(x->frames, stride) &&
+                 x->batch == y->batch && x->c_pitch % 16 == 0 && y->c_pitch % 16 == 0,
+             "conv fwd bf16: bad geometry");
+  ST_REQUIRE(x->halo - pad_left + (y->frames - 1) * stride + width <= x->t_pitch, "conv fwd bf16: right halo too small");
+  return conv_fwd<1>(x, x_bf16, wt_bf16, bias, width, stride, pad_left, relu, y, y_f32, y_bf16, st::as_stream(stream));
+}
+
+size_t st_conv1d_bwd_data_bf16_ws(const st_tensor3* dz, const st_tensor3* dx, int width) {
+  if (!dz || !dx) return 0;
+  const int splits = bwd_data_splits(*dz, *dx, width);
+  return splits > 1 ? (size_t)splits * dx->batch * dx->frames * npad_of(dx->channels) * sizeof(float) : 0;
+}
+
+int st_conv1d_nwc_bwd_data_bf16(const st_tensor3* dz, const void* dz_bf16, const void* wtt_bf16, int width, int pad_left,
+                                const st_tensor3* act, const void* act_bf16, const st_tensor3* dx, void* dx_bf16,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(dz && dx && dz_bf16 && wtt_bf16 && dx_bf16 && (!act || act_bf16), "conv bwd-data bf16: null argument");
+  const int lead = width - 1 - pad_left;
+  ST_REQUIRE(lead >= 0 && dz->halo >= lead && dz->frames == dx->frames && dz->batch == dx->batch &&
+                 dz->t_pitch >= dz->halo - lead + dz->frames + width - 1 && dz->c_pitch % 16 == 0,
+             "conv bwd-data bf16: bad geometry (stride-1 layers only)");
+  ST_REQUIRE(!act || (act->frames == dx->frames && act->batch == dx->batch && act->c_pitch >= dx->c_pitch),
+             "conv bwd-data bf16: mask geometry");
+  const int splits = bwd_data_splits(*dz, *dx, width);
+  const size_t need = st_conv1d_bwd_data_bf16_ws(dz, dx, width);
+  if (need && (!workspace || workspace_bytes < need)) {
+    st::set_error("conv bwd-data bf16: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    return ST_EWORKSPACE;
+  }
+  return conv_bwd_data<1>(dz, dz_bf16, wtt_bf16, width, pad_left, act, nullptr, act_bf16, dx, nullptr, dx_bf16,
+                          st::as_stream(stream), splits, reinterpret_cast<float*>(workspace));
+}
+
+size_t st_conv1d_bwd_filter_bf16_ws(const st_tensor3* x, const st_tensor3* dz, int width, int stride, int pad_left) {
+  if (!x || !dz || stride < 1 || stride > 2 || x->halo < pad_left) return 0;
+  const WgradPlan w = wgrad_plan(*x, *dz, width, stride, x->halo - pad_left);
+  return w.xt_bytes + w.dzt_bytes + w.slab_bytes;
+}
+
+int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const st_tensor3* dz, const void* dz_bf16,
+                                  int width, int stride, int pad_left, float* dpacked, float* dbias, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(x && dz && x_bf16 && dz_bf16 && dpacked && dbias, "conv bwd-filter bf16: null argument");
+  ST_REQUIRE((stride == 1 || stride == 2) && x->halo >= pad_left && x->batch == dz->batch &&
+                 dz->frames == st::ceil_div(x->frames, stride) && x->c_pitch % 16 == 0,
+             "conv bwd-filter bf16: bad geometry (stride 1 or 2)");
+  const int first = x->halo - pad_left;
+  const WgradPlan w = wgrad_plan(*x, *dz, width, stride, first);
+  ST_REQUIRE(w.red < (1L << 31), "conv bwd-filter bf16: reduction too long");
+  const size_t need = w.xt_bytes + w.dzt_bytes + w.slab_bytes;
+  if (!workspace || workspace_bytes < need) {
+    st::set_error("conv bwd-filter bf16: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    return ST_EWORKSPACE;
+  }
+  hipStream_t s = st::as_stream(stream);
+  unsigned short* xt = reinterpret_cast<unsigned short*>(workspace);
+  unsigned short* dzt = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + w.xt_bytes);
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.xt_bytes + w.dzt_bytes);
+  // reduction-major copies (every element of [c][b*tq + j] is written: zeros where the source has no row)
+  for (int ph = 0; ph < stride; ++ph) {
+    const int rows = st::ceil_div(x->t_pitch - first - ph, stride);
+    dim3 grid(w.tq / 32, st::ceil_div(x->c_pitch, 32), x->batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x_bf16),
+                       rows, first + ph, stride, x->t_pitch, x->c_pitch, x->c_pitch, w.tq, xt + ph * w.xt_phase_elems);
+    if (hipMemsetAsync(xt + ph * w.xt_phase_elems + (size_t)x->c_pitch * w.red, 0, 4096 * 2, s) != hipSuccess) {
+      st::set_error("conv bwd-filter bf16: memset failed");
+      return ST_ELAUNCH;
+    }
+  }
+  {
+    dim3 grid(w.tq / 32, st::ceil_div(w.n_pad, 32), dz->batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(dz_bf16),
+                       dz->frames, dz->halo, 1, dz->t_pitch, dz->c_pitch, w.n_pad, w.tq, dzt);
+  }
+  if (int e = st::check_launch("transpose_bf16")) return e;
+  if (int e = conv_bwd_filter<1>(xt, 0, (long)w.xt_phase_elems, stride, dzt, x->batch, w.tq, width, x->c_pitch, 0,
+                                 dz->channels, dpacked, w.splits, slabs, s))
+    return e;
+  hipLaunchKernelGGL(row_sum_bf16_kernel, dim3(w.n_pad), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dzt), w.red, dbias);
+  return st::check_launch("row_sum_bf16");
+}
+
+}  // extern "C"

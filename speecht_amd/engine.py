@@ -96,9 +96,11 @@ class Wav2LetterEngine:
   def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None):
     _lib.load()
     # 'fp32': exact-f32 MFMA kernels (default).  'bf16x6': EXPERIMENTAL fp32-accurate split-bf16 path
-    # (csrc/conv_bf16x6.hip) for forward and back-prop-to-input of the wide layers.
+    # (csrc/conv_bf16.hip, NP = 3) for forward and back-prop-to-input of the wide layers.
+    # 'bf16': BASELINE config 4 -- bf16 activations and activation gradients, fp32 masters / accumulation /
+    # logits / CTC / Adam (csrc/conv_bf16.hip, NP = 1).
     self.conv_mode = conv_mode or os.environ.get('ST_CONV_MODE', 'fp32')
-    assert self.conv_mode in ('fp32', 'bf16x6'), self.conv_mode
+    assert self.conv_mode in ('fp32', 'bf16x6', 'bf16'), self.conv_mode
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -230,7 +232,67 @@ class Wav2LetterEngine:
     self.dec_score = self._storage.view('dec_score', batch)[0][:batch]
     if self.conv_mode == 'bf16x6':
       self._alloc_planes()
+    if self.conv_mode == 'bf16':
+      self._alloc_bf16()
     self._shape = (batch, frames)
+
+  # ---- bf16 activations (config 4) ------------------------------------------------------------------
+  def _alloc_bf16(self):
+    L = len(self.layers)
+    self.Xb = [self._planes('Xb%d' % i, self.X[i].buf.numel(), 1) for i in range(L)]
+    self.dZb = [self._planes('dZb%d' % i, self.dZ[i].buf.numel(), 1) for i in range(L)]
+    lib = _lib.load()
+    ws = max(lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2])
+             for i, l in enumerate(self.layers))
+    ws = max([ws] + [lib.st_conv1d_bwd_data_bf16_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
+                     for i, l in enumerate(self.layers) if i > 0])
+    self.wgrad_ws_b, _ = self._storage.view('wgrad_ws_b', ws // 4 + 64)
+    if not hasattr(self, 'Wb'):
+      z = lambda n: torch.zeros(n, dtype=torch.bfloat16, device=self.device)
+      self.Wb = [z(l.k_pad * l.n_pad) for l in self.layers]
+      self.WTb = [None] + [z(l.kt_pad * l.nt_pad) for l in self.layers[1:]]
+
+  def _refresh_bf16_filters(self, transposed):
+    for i, l in enumerate(self.layers):
+      if transposed and i > 0:
+        call('st_filters_bf16', self._ptr(self.packed_t[i]), l.kt_pad, l.nt_pad, self._ptr(self.WTb[i]), self.stream_ptr)
+      elif not transposed:
+        call('st_filters_bf16', self._ptr(self._slice(self.params, i)[0]), l.k_pad, l.n_pad, self._ptr(self.Wb[i]),
+             self.stream_ptr)
+    if transposed:
+      self._wtplanes_fresh = True
+    else:
+      self._wplanes_fresh = True
+
+  def _forward_bf16(self):
+    s, L = self.stream_ptr, len(self.layers)
+    if not self._wplanes_fresh:
+      self._refresh_bf16_filters(False)
+    call('st_cast_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xb[0]), s)
+    for i, l in enumerate(self.layers):
+      last = i + 1 == L
+      call('st_conv1d_nwc_fwd_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(self.Wb[i]),
+           self._ptr(self._slice(self.params, i)[1]), l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref,
+           None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None, s)
+
+  def _backward_bf16(self, on_layer_done):
+    s, L = self.stream_ptr, len(self.layers)
+    if not self._wtplanes_fresh:
+      self._refresh_bf16_filters(True)
+    call('st_cast_bf16', self._ptr(self.dZ[L - 1].buf), self.dZ[L - 1].buf.numel(), self._ptr(self.dZb[L - 1]), s)
+    for i in reversed(range(L)):
+      l = self.layers[i]
+      gf, gb = self._slice(self.grads, i)
+      call('st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]),
+           l.width, l.stride, self.geo[i][2], self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws_b),
+           self.wgrad_ws_b.numel() * 4, s)
+      if on_layer_done is not None:
+        on_layer_done(i)
+      if i > 0:
+        relu_in = self.layers[i - 1].relu
+        call('st_conv1d_nwc_bwd_data_bf16', self.dZ[i].ref, self._ptr(self.dZb[i]), self._ptr(self.WTb[i]), l.width,
+             self.geo[i][2], self.X[i].ref if relu_in else None, self._ptr(self.Xb[i]) if relu_in else None,
+             self.dZ[i - 1].ref, self._ptr(self.dZb[i - 1]), self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4, s)
 
   # ---- bf16x6 (experimental) ------------------------------------------------------------------
   def _x6_fwd(self, i):
@@ -245,10 +307,10 @@ class Wav2LetterEngine:
     tiles = -(-(l.width * l.cin_pitch) // 128) * (l.n_pad // 128)
     return self.conv_mode == 'bf16x6' and i > 0 and l.stride == 1 and l.n_pad % 128 == 0 and tiles >= 192
 
-  def _planes(self, name, numel):
-    """3 zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
-    buf, fresh = self._storage.view(name, 3 * numel, torch.bfloat16)
-    v = buf[:3 * numel]
+  def _planes(self, name, numel, n=3):
+    """n zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
+    buf, fresh = self._storage.view(name, n * numel, torch.bfloat16)
+    v = buf[:n * numel]
     if not fresh:
       v.zero_()
     return v
@@ -297,6 +359,8 @@ class Wav2LetterEngine:
     self.ctc_lens = torch.as_tensor((self.seq_lens_host // 2).astype(np.int32)).to(self.device, non_blocking=True)
 
   def forward(self):
+    if self.conv_mode == 'bf16':
+      return self._forward_bf16()
     s = self.stream_ptr
     x6 = self.conv_mode == 'bf16x6'
     if x6 and not self._wplanes_fresh:
@@ -356,6 +420,8 @@ class Wav2LetterEngine:
     s = self.stream_ptr
     if not self._packed_t_fresh:
       self.refresh_packed_t()
+    if self.conv_mode == 'bf16':
+      return self._backward_bf16(on_layer_done)
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)

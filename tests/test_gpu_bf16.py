@@ -1,0 +1,168 @@
+"""BASELINE config 4 ("bf16 activations / fp32 CTC"): the bf16-activation entry points of
+include/speecht_hip.h against the oracle run with its bf16 *storage model* (oracle.bf16_round applied
+exactly where the device path writes bf16: input, filter copies, layer outputs, activation gradients).
+
+Tolerances: both sides round the same real numbers to bf16, but the device accumulates in fp32 and the
+oracle in float64, so a value that sits on a rounding boundary may land one bf16 ulp (2^-8 relative) apart;
+such flips are rare and stay local, hence "max error <= a few ulp of the tensor's scale, mean error far
+below one ulp".  Against the unrounded fp32 oracle the gap is the expected bf16 quantisation noise."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+  return torch.device('cuda:0')
+
+
+def engine(layers, dev, mode='bf16'):
+  from speecht_amd.engine import Wav2LetterEngine
+  return Wav2LetterEngine(layers, device=dev, conv_mode=mode)
+
+
+def scaled_err(a, b):
+  s = float(np.max(np.abs(b))) + 1e-30
+  d = np.abs(np.asarray(a, np.float64) - b) / s
+  return float(d.max()), float(d.mean())
+
+
+ULP = 2.0 ** -8
+
+CASES = [
+    # B, T, W, s, cin, cout, relu
+    (3, 41, 48, 2, 16, 24, True),       # L0-like: stride 2 (two phase planes in the filter gradient), odd T
+    (2, 40, 48, 2, 80, 250, True),      # L0 real channels
+    (2, 37, 7, 1, 250, 250, True),      # L1-L7
+    (2, 33, 32, 1, 40, 200, True),      # L8-like (pad 15/16)
+    (2, 29, 1, 1, 200, 29, False),      # L10: 29 outputs on a 128-wide tile, fp32 logits
+    (1, 300, 7, 1, 32, 48, True),       # long reduction -> split filter gradient
+]
+
+
+@pytest.mark.parametrize('B,T,W,s,cin,cout,relu', CASES)
+def test_conv_layer_pair_bf16(dev, B, T, W, s, cin, cout, relu):
+  """Two stacked layers [probe (W,s,cin->cout), 1x1 head -> 29] so that forward, back-prop to the input of
+  the head, both filter gradients and the ReLU mask of the probe layer are all exercised."""
+  layers = [(W, s, cin, cout, relu), (1, 1, cout, 29, False)]
+  rng = np.random.default_rng(B * 1000 + T + W)
+  params = WL.xavier_params(layers, seed=T, bias_range=0.05)
+  x = rng.standard_normal((B, T, cin))
+  eng = engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, [T] * B)
+  eng.forward()
+  logits = eng.logits_time_major().cpu().numpy()
+  ref_logits, acts = O.wav2letter_forward(x, params, layers, keep=True, store=O.bf16_round)
+  mx, mean = scaled_err(logits, ref_logits)
+  assert mx < 4 * ULP and mean < 0.1 * ULP, (mx, mean)
+  # the stored bf16 activation of the probe layer
+  got = eng.Xb[1].view(eng.X[1].batch, eng.X[1].t_pitch, eng.X[1].c_pitch)[
+      :, eng.X[1].halo:eng.X[1].halo + eng.X[1].frames, :cout].float().cpu().numpy()
+  mx, mean = scaled_err(got, acts[1])
+  assert mx < 2 * ULP and mean < 0.05 * ULP, (mx, mean)
+  # back-prop of a random upstream gradient
+  t_out = ref_logits.shape[0]
+  dl = rng.standard_normal((t_out, B, 29)) / (B * t_out)
+  eng.dZ[-1].interior().copy_(torch.as_tensor(np.transpose(dl, (1, 0, 2)), dtype=torch.float32))
+  eng.backward()
+  grads = eng.get_grads()
+  ref = O.wav2letter_backward(acts, params, layers, dl, store=O.bf16_round)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(grads, ref)):
+    mx, mean = scaled_err(gF, rF)
+    assert mx < 4 * ULP and mean < 0.2 * ULP, (i, mx, mean)
+    mx, _ = scaled_err(gb, rb)
+    assert mx < 4 * ULP, (i, mx)
+
+
+def test_split_backprop_bf16(dev):
+  """Back-prop through a wide layer whose tile grid is small (the L8 situation): the reduction is split over
+  channel chunks into fp32 slabs and a second pass sums, masks and rounds (st_conv1d_bwd_data_bf16_ws > 0)."""
+  from speecht_amd import _lib
+  layers = [(1, 1, 16, 48, True), (16, 1, 48, 512, True), (1, 1, 512, 29, False)]
+  rng = np.random.default_rng(5)
+  params = WL.xavier_params(layers, seed=5, bias_range=0.05)
+  B, T = 2, 50
+  x = rng.standard_normal((B, T, 16))
+  eng = engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, [T] * B)
+  assert _lib.load().st_conv1d_bwd_data_bf16_ws(eng.dZ[1].ref, eng.dZ[0].ref, 16) > 0
+  eng.forward()
+  _, acts = O.wav2letter_forward(x, params, layers, keep=True, store=O.bf16_round)
+  dl = rng.standard_normal((T, B, 29)) / (B * T)
+  eng.dZ[-1].interior().copy_(torch.as_tensor(np.transpose(dl, (1, 0, 2)), dtype=torch.float32))
+  eng.backward()
+  ref = O.wav2letter_backward(acts, params, layers, dl, store=O.bf16_round)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref)):
+    mx, mean = scaled_err(gF, rF)
+    assert mx < 8 * ULP and mean < 0.5 * ULP, (i, mx, mean)
+    assert scaled_err(gb, rb)[0] < 8 * ULP, i
+
+
+def test_small_train_step_bf16(dev):
+  case = WL.small_train_case()
+  eng = engine(case['layers'], dev)
+  eng.set_weights(case['params'])
+  eng.load_batch(case['x'], case['seq_lens'])
+  eng.set_labels(case['labels'])
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / 3)
+  eng.backward()
+  grads = eng.get_grads()
+  eng.apply_update(lr=1e-4)
+  torch.cuda.synchronize()
+  args = (case['x'], case['seq_lens'], case['labels'], case['params'], case['layers'], O.zero_opt_state(case['params']))
+  ref = O.train_step(*args, lr=1e-4, store=O.bf16_round)
+  ref32 = O.train_step(*args, lr=1e-4)
+  logits = eng.logits_time_major().cpu().numpy()
+  mx, mean = scaled_err(logits, ref['logits'])
+  assert mx < 8 * ULP and mean < 0.5 * ULP, (mx, mean)
+  loss = eng.loss.cpu().numpy()
+  np.testing.assert_allclose(loss, ref['loss'], rtol=2e-3)         # same bf16 model
+  np.testing.assert_allclose(loss, ref32['loss'], rtol=2e-2)       # vs full precision: quantisation noise only
+  assert float(eng.stats[0]) == pytest.approx(ref['grad_norm'], rel=2e-2)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(grads, ref['grads'])):
+    mx, mean = scaled_err(gF, rF)
+    assert mx < 16 * ULP and mean < 1.0 * ULP, (i, mx, mean)
+    assert scaled_err(gb, rb)[0] < 16 * ULP, i
+  # masters stay fp32: the Adam step moves every weight by at most lr
+  for (pF, pb), (rF, rb), (oF, ob) in zip(eng.get_weights(), ref['params'], case['params']):
+    assert np.max(np.abs(pF - oF)) <= 1.01e-4 and np.max(np.abs(pF - rF)) < 2.1e-4
+
+
+def test_full_width_forward_bf16_vs_fp32_oracle(dev):
+  """Real widths, B=2 ragged: bf16 storage costs < 2 % of the logit scale against the fp32 reference math."""
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42)
+  x, seq_lens, _ = WL.make_batch([201, 160], 80, seed=2)
+  eng = engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, seq_lens)
+  eng.forward()
+  logits = eng.logits_time_major().cpu().numpy()
+  ref_b = O.wav2letter_forward(x, params, layers, store=O.bf16_round)
+  ref = O.wav2letter_forward(x, params, layers)
+  mx, mean = scaled_err(logits, ref_b)
+  assert mx < 8 * ULP and mean < 0.5 * ULP, (mx, mean)
+  assert scaled_err(logits, ref)[0] < 2e-2
+  dec, _ = eng.greedy_decode()
+  ref_dec, _ = O.ctc_greedy_decode(logits.astype(np.float64), np.asarray(seq_lens) // 2)
+  assert dec == ref_dec
+
+
+def test_bf16_entry_points_reject_bad_arguments(dev):
+  from speecht_amd import _lib
+  eng = engine([(7, 1, 16, 16, True), (1, 1, 16, 29, False)], dev)
+  eng.load_batch(np.zeros((1, 20, 16)), [20])
+  with pytest.raises(_lib.SpeechtHipError, match='null argument'):
+    _lib.call('st_conv1d_nwc_fwd_bf16', eng.X[0].ref, None, None, None, 7, 1, 3, 1, eng.X[1].ref, None, None, None)
+  with pytest.raises(_lib.SpeechtHipError, match='workspace'):
+    _lib.call('st_conv1d_nwc_bwd_filter_bf16', eng.X[0].ref, eng._ptr(eng.Xb[0]), eng.dZ[0].ref, eng._ptr(eng.dZb[0]),
+              7, 1, 3, eng._ptr(eng.grads), eng._ptr(eng.grads), None, 0, None)

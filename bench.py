@@ -163,6 +163,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-alt', action='store_true', help='skip the bf16x6 / bf16 side measurements')
   ap.add_argument('--force-allreduce', action='store_true', help='run the RCCL all-reduce path even on 1 rank (self-test)')
+  ap.add_argument('--conv-mode', choices=('fp32', 'bf16x6', 'bf16'), default=None,
+                  help='arithmetic of the timed loop (default fp32 = BASELINE configs[1]; bf16 = configs[3] arithmetic)')
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
                   help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
   args = ap.parse_args()
@@ -182,7 +184,7 @@ def main():
 
   frames = 1 + int(args.seconds * 16000) // 160
   layers = WL.w2l_layers(args.mels)
-  eng = Wav2LetterEngine(layers, device=dev)
+  eng = Wav2LetterEngine(layers, device=dev, conv_mode=args.conv_mode)
   eng.set_weights(WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32))   # same replica everywhere
   x, seq_lens, labels = WL.make_batch([frames] * args.batch, args.mels, seed=100 + rank)
   eng.load_batch(x, seq_lens)
@@ -220,9 +222,12 @@ def main():
         'metric': 'utterances/sec (training step, 10 s@16 kHz, batch 32)',
         'value': round(global_batch / (elapsed / args.steps), 2), 'unit': 'utterances/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: 1xMI355X training step, batch {} of {:g} s synthetic clips, {}-mel, '
-                               'default Wav2Letter depth, fp32'.format(args.batch, args.seconds, args.mels),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x6': 'f32 (bf16x6 split)', 'bf16': 'bf16 activations, f32 accumulate/CTC/Adam'}[eng.conv_mode],
+        'data': 'synthetic',
+        'config': {'workload': ('configs[3] arithmetic: data-parallel training step, batch {} per GPU of {:g} s synthetic clips, '
+                                '{}-mel, bf16 activations / fp32 CTC' if eng.conv_mode == 'bf16' else
+                                'configs[1]: 1xMI355X training step, batch {} of {:g} s synthetic clips, {}-mel, '
+                                'default Wav2Letter depth, fp32').format(args.batch, args.seconds, args.mels),
                    'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world,
                    'allreduce': reducer.transport if reducer else None},
         'final_avg_loss': round(loss, 4),

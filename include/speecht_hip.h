@@ -185,6 +185,16 @@ int st_allreduce_f32(void* comm, float* buf, size_t n, void* stream);
 int st_allreduce_buckets_f32(void* comm, float* base, const size_t* starts, const size_t* counts, int n_buckets,
                              void* stream);
 
+/* ---- calc_mfccs (preprocessing.py:61-84): librosa.feature.mfcc + delta + delta-delta ----------
+ * Same input conventions as st_melspec_f32 (mel_basis is the n_mels = 128 filterbank librosa's
+ * mfcc uses by default).  out [total_frames][3 * n_mfcc]: mfcc | delta | delta2, each block
+ * z-normalised per utterance.  delta follows the librosa 0.5.x FIR implementation (see oracle). */
+size_t st_mfcc_ws(int n_utts, int64_t total_frames, int n_mels, int n_mfcc);
+int st_mfcc_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
+                const float* mel_basis, int n_mels, int n_mfcc, int n_fft, int hop,
+                const int64_t* frame_offsets, int64_t total_frames, float* out, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 /* ---- helpers -------------------------------------------------------------------------- */
 int st_fill_f32(float* dst, float value, size_t n, void* stream);
 /* zero the halo rows of a padded NWC tensor (needed when a buffer is re-described for a new shape) */

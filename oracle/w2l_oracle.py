@@ -127,6 +127,50 @@ def calc_power_spectrogram(audio_data, samplerate, n_mels=128, n_fft=512, hop_le
   return normalize(power_to_db(S)).T
 
 
+def dct_basis(n_mfcc, n_mels):
+  """librosa.filters.dct (0.5/0.6) == orthonormal DCT-II rows 0..n_mfcc-1 (scipy.fftpack.dct(type=2,
+  norm='ortho') in later releases)."""
+  basis = np.empty((n_mfcc, n_mels))
+  basis[0, :] = 1.0 / math.sqrt(n_mels)
+  samples = np.arange(1, 2 * n_mels, 2) * math.pi / (2.0 * n_mels)
+  for i in range(1, n_mfcc):
+    basis[i, :] = np.cos(i * samples) * math.sqrt(2.0 / n_mels)
+  return basis
+
+
+def delta_lfilter(data, width=9, order=1):
+  """librosa.feature.delta of the 0.5.x line the reference was written against (requirements.txt:5
+  ``librosa>=0.5.0``; preprocessing.py:78-79): edge-pad by ``width`` on the time axis, run the FIR
+  window [4..-4]/60 as a causal filter from rest ``order`` times over the PADDED signal, then cut
+  [-5-T : -5].  For order 1 this is the usual regression delta with clamped edges; for order 2 the filter's
+  zero initial state leaks into the first three frames (a quirk of that release, restated on purpose).
+  PARITY UNPINNED (librosa >= 0.6.1 switched to a Savitzky-Golay filter)."""
+  data = np.asarray(data, dtype=np.float64)
+  half = 1 + width // 2
+  window = np.arange(half - 1.0, -half, -1.0)
+  window /= np.sum(window ** 2)
+  T = data.shape[-1]
+  x = np.pad(data, [(0, 0)] * (data.ndim - 1) + [(width, width)], mode='edge')
+  for _ in range(order):
+    y = np.zeros_like(x)
+    for k, wk in enumerate(window):              # y[n] = sum_k w[k] x[n-k], x[<0] = 0
+      y[..., k:] += wk * x[..., :x.shape[-1] - k]
+    x = y
+  return x[..., x.shape[-1] - half - T:x.shape[-1] - half]
+
+
+def calc_mfccs(audio_data, samplerate, n_mfcc=13, n_fft=512, hop_length=160, n_mels=128):
+  """preprocessing.py:61-84 -> [time, 3 * n_mfcc]: librosa.feature.mfcc (= DCT-II of
+  power_to_db(melspectrogram(n_mels=128), ref=1.0, top_db=80)), its delta and delta-delta, each block
+  z-normalised on its own."""
+  S = mel_filterbank(samplerate, n_fft, n_mels) @ stft_power(audio_data, n_fft, hop_length)
+  log_spec = 10.0 * np.log10(np.maximum(1e-10, S))
+  log_spec = np.maximum(log_spec, log_spec.max() - 80.0)
+  mfcc = dct_basis(n_mfcc, n_mels) @ log_spec
+  return np.concatenate((normalize(mfcc), normalize(delta_lfilter(mfcc)),
+                         normalize(delta_lfilter(mfcc, order=2))), axis=0).T
+
+
 # ----------------------------------------------------------------------------------------
 # batch assembly  (speecht/speech_input.py:27-69)
 # ----------------------------------------------------------------------------------------

@@ -65,6 +65,9 @@ _SIGNATURES = {
     'st_comm_destroy': (c_int, [c_void_p]),
     'st_allreduce_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_allreduce_buckets_f32': (c_int, [c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_int, c_void_p]),
+    'st_mfcc_ws': (c_size_t, [c_int, c_int64, c_int, c_int]),
+    'st_mfcc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                            c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_fill_f32': (c_int, [c_void_p, c_float, c_size_t, c_void_p]),
     'st_zero_halos_f32': (c_int, [_T3P, c_void_p]),
 }

@@ -194,6 +194,120 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict
   for (long i = lo + threadIdx.x; i < hi; i += 256) dst[i] = (to_db(src[i], ref_db) - meanf) * inv_std;
 }
 
+// ---- MFCC + delta + delta-delta (preprocessing.py:61-84) --------------------------------------------
+// librosa.feature.mfcc = DCT-II (orthonormal) of power_to_db(mel power, ref = 1.0, top_db = 80);
+// librosa.feature.delta (0.5.x: FIR [4..-4]/60 run causally from rest over the edge-padded signal, once or
+// twice); each of the three [n_mfcc, T] blocks is z-normalised on its own.  Reuses mel_ranges / mel_frame.
+constexpr int MAX_MFCC = 32;
+
+// one wave per frame: dB of the mel bins in registers, n_mfcc cosine projections, wave reduction
+__global__ __launch_bounds__(256) void mfcc_dct_kernel(const float* __restrict__ melpow,
+                                                       const long* __restrict__ sample_off,
+                                                       const long* __restrict__ frame_off, int n_mels, int n_mfcc,
+                                                       int hop, const unsigned* __restrict__ umax,
+                                                       float* __restrict__ coef) {
+  const int u = blockIdx.y;
+  const int frames = 1 + (int)(sample_off[u + 1] - sample_off[u]) / hop;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= frames) return;
+  const int lane = threadIdx.x & 63;
+  const float floor_db = 10.f * log10f(fmaxf(1e-10f, __uint_as_float(umax[u]))) - 80.f;
+  const float* src = melpow + (frame_off[u] + t) * (long)n_mels;
+  float db[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = lane + 64 * j;
+    db[j] = m < n_mels ? fmaxf(10.f * log10f(fmaxf(1e-10f, src[m])), floor_db) : 0.f;
+  }
+  const float inv2n = 0.5f / (float)n_mels;
+  for (int c = 0; c < n_mfcc; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = fmaf(db[j], cospif((float)(c * (2 * (lane + 64 * j) + 1)) * inv2n), acc);
+    acc = st::wave_sum(acc);
+    if (lane == 0) coef[(frame_off[u] + t) * (long)n_mfcc + c] = acc * (c ? sqrtf(2.f / n_mels) : rsqrtf((float)n_mels));
+  }
+}
+
+// x edge-padded by 9 frames on both sides; index j of the padded axis, zero before it starts (filter at rest)
+__device__ __forceinline__ float mfcc_padded(const float* __restrict__ x, int n_mfcc, int frames, int c, int j) {
+  return j < 0 ? 0.f : x[(long)min(max(j - 9, 0), frames - 1) * n_mfcc + c];
+}
+__device__ __forceinline__ float mfcc_delta1(const float* __restrict__ x, int n_mfcc, int frames, int c, int j) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc = fmaf((float)(4 - k) * (1.f / 60.f), mfcc_padded(x, n_mfcc, frames, c, j - k), acc);
+  return j < 0 ? 0.f : acc;
+}
+
+__global__ __launch_bounds__(256) void mfcc_delta_kernel(const float* __restrict__ coef,
+                                                         const long* __restrict__ sample_off,
+                                                         const long* __restrict__ frame_off, int n_mfcc, int hop,
+                                                         float* __restrict__ d1, float* __restrict__ d2,
+                                                         double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int u = blockIdx.y;
+  const int frames = 1 + (int)(sample_off[u + 1] - sample_off[u]) / hop;
+  const long count = (long)frames * n_mfcc;
+  const float* x = coef + frame_off[u] * (long)n_mfcc;
+  const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  const long lo = blockIdx.x * per, hi = min(count, lo + per);
+  double s[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int t = (int)(i / n_mfcc), c = (int)(i - (long)t * n_mfcc);
+    const float v0 = x[i];
+    const float v1 = mfcc_delta1(x, n_mfcc, frames, c, 13 + t);
+    float v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v2 = fmaf((float)(4 - k) * (1.f / 60.f), mfcc_delta1(x, n_mfcc, frames, c, 13 + t - k), v2);
+    d1[frame_off[u] * (long)n_mfcc + i] = v1;
+    d2[frame_off[u] * (long)n_mfcc + i] = v2;
+    s[0] += v0; ss[0] += (double)v0 * v0;
+    s[1] += v1; ss[1] += (double)v1 * v1;
+    s[2] += v2; ss[2] += (double)v2 * v2;
+  }
+  for (int b = 0; b < 3; ++b) {
+    const double a = block_sum_d(s[b], red), q = block_sum_d(ss[b], red);
+    if (threadIdx.x == 0) {
+      double* dst = partial + (((long)u * 3 + b) * STAT_CHUNKS + blockIdx.x) * 2;
+      dst[0] = a;
+      dst[1] = q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mfcc_finish_kernel(const float* __restrict__ coef, const float* __restrict__ d1,
+                                                          const float* __restrict__ d2,
+                                                          const long* __restrict__ sample_off,
+                                                          const long* __restrict__ frame_off, int n_mfcc, int hop,
+                                                          const double* __restrict__ partial, float* __restrict__ out) {
+  __shared__ float mean_s[3], inv_s[3];
+  const int u = blockIdx.y;
+  const int frames = 1 + (int)(sample_off[u + 1] - sample_off[u]) / hop;
+  const long count = (long)frames * n_mfcc;
+  if (threadIdx.x < 3) {
+    double s = 0.0, ss = 0.0;
+    for (int c = 0; c < STAT_CHUNKS; ++c) {
+      s += partial[(((long)u * 3 + threadIdx.x) * STAT_CHUNKS + c) * 2];
+      ss += partial[(((long)u * 3 + threadIdx.x) * STAT_CHUNKS + c) * 2 + 1];
+    }
+    const double mean = s / (double)count;
+    mean_s[threadIdx.x] = (float)mean;
+    inv_s[threadIdx.x] = (float)(1.0 / sqrt(fmax(ss / (double)count - mean * mean, 0.0)));
+  }
+  __syncthreads();
+  const long base = frame_off[u] * (long)n_mfcc;
+  const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  const long lo = blockIdx.x * per, hi = min(count, lo + per);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const long t = i / n_mfcc, c = i - t * n_mfcc;
+    float* row = out + (frame_off[u] + t) * (long)(3 * n_mfcc);
+    row[c] = (coef[base + i] - mean_s[0]) * inv_s[0];
+    row[n_mfcc + c] = (d1[base + i] - mean_s[1]) * inv_s[1];
+    row[2 * n_mfcc + c] = (d2[base + i] - mean_s[2]) * inv_s[2];
+  }
+}
+
 size_t pow_bytes(int64_t total_frames, int n_mels) { return st::round_up((size_t)total_frames * n_mels * sizeof(float), 256); }
 
 }  // namespace
@@ -238,6 +352,54 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
   hipLaunchKernelGGL(mel_finish_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, melpow, soff, foff, n_mels, hop,
                      umax, partial, out);
   return st::check_launch("melspec");
+}
+
+size_t st_mfcc_ws(int n_utts, int64_t total_frames, int n_mels, int n_mfcc) {
+  if (n_utts <= 0 || total_frames <= 0 || n_mels <= 0 || n_mfcc <= 0) return 0;
+  return pow_bytes(total_frames, n_mels) + st::round_up((size_t)n_utts * 4, 256) +
+         st::round_up((size_t)n_mels * 2 * sizeof(int), 256) + 3 * pow_bytes(total_frames, n_mfcc) +
+         (size_t)n_utts * 3 * STAT_CHUNKS * 2 * sizeof(double);
+}
+
+int st_mfcc_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
+                const float* mel_basis, int n_mels, int n_mfcc, int n_fft, int hop, const int64_t* frame_offsets,
+                int64_t total_frames, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(audio && sample_offsets && mel_basis && frame_offsets && out && workspace, "mfcc: null argument");
+  ST_REQUIRE(n_fft == NFFT, "mfcc: only n_fft = 512 (the reference default, preprocessing.py:61) is built");
+  ST_REQUIRE(n_utts > 0 && n_mels > 0 && n_mels <= 256 && n_mfcc > 0 && n_mfcc <= MAX_MFCC && n_mfcc <= n_mels &&
+                 hop > 0 && max_samples > NFFT / 2 && total_frames > 0,
+             "mfcc: bad shape");
+  ST_REQUIRE(workspace_bytes >= st_mfcc_ws(n_utts, total_frames, n_mels, n_mfcc), "mfcc: workspace too small");
+  hipStream_t s = st::as_stream(stream);
+  char* w = reinterpret_cast<char*>(workspace);
+  float* melpow = reinterpret_cast<float*>(w);
+  w += pow_bytes(total_frames, n_mels);
+  unsigned* umax = reinterpret_cast<unsigned*>(w);
+  w += st::round_up((size_t)n_utts * 4, 256);
+  int* ranges = reinterpret_cast<int*>(w);
+  w += st::round_up((size_t)n_mels * 2 * sizeof(int), 256);
+  float* coef = reinterpret_cast<float*>(w);
+  float* d1 = reinterpret_cast<float*>(w + pow_bytes(total_frames, n_mfcc));
+  float* d2 = reinterpret_cast<float*>(w + 2 * pow_bytes(total_frames, n_mfcc));
+  w += 3 * pow_bytes(total_frames, n_mfcc);
+  double* partial = reinterpret_cast<double*>(w);
+  if (hipMemsetAsync(umax, 0, (size_t)n_utts * 4, s) != hipSuccess) {
+    st::set_error("mfcc: memset failed");
+    return ST_ELAUNCH;
+  }
+  const long* soff = reinterpret_cast<const long*>(sample_offsets);
+  const long* foff = reinterpret_cast<const long*>(frame_offsets);
+  const unsigned max_frames = (unsigned)(1 + max_samples / hop);
+  hipLaunchKernelGGL(mel_ranges_kernel, dim3(st::ceil_div(n_mels, 64)), dim3(64), 0, s, mel_basis, n_mels, ranges);
+  hipLaunchKernelGGL(mel_frame_kernel, dim3(st::ceil_div((int)max_frames, FPB), n_utts), dim3(256), 0, s, audio, soff,
+                     mel_basis, ranges, n_mels, hop, foff, melpow, umax);
+  hipLaunchKernelGGL(mfcc_dct_kernel, dim3(st::ceil_div((int)max_frames, 4), n_utts), dim3(256), 0, s, melpow, soff, foff,
+                     n_mels, n_mfcc, hop, umax, coef);
+  hipLaunchKernelGGL(mfcc_delta_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, coef, soff, foff, n_mfcc, hop, d1, d2,
+                     partial);
+  hipLaunchKernelGGL(mfcc_finish_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, coef, d1, d2, soff, foff, n_mfcc, hop,
+                     partial, out);
+  return st::check_launch("mfcc");
 }
 
 }  // extern "C"

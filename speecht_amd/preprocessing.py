@@ -78,6 +78,38 @@ def calc_power_spectrogram(audio_data, samplerate, n_mels=128, n_fft=512, hop_le
   return calc_power_spectrogram_batch([audio_data], samplerate, n_mels, n_fft, hop_length)[0]
 
 
+def calc_mfccs_batch(audio_list, samplerate, n_mfcc=13, n_fft=512, hop_length=160, device='cuda:0'):
+  """MFCC + delta + delta-delta features for several utterances in one launch sequence; returns a list
+  of [time, 3 * n_mfcc] float32 arrays (each block z-normalised per utterance)."""
+  import torch
+  from . import _lib
+  n_mels = 128                                   # librosa.feature.mfcc's melspectrogram default
+  dev = torch.device(device)
+  lens = np.array([len(a) for a in audio_list], dtype=np.int64)
+  if lens.min() <= n_fft // 2:
+    raise ValueError('utterances must be longer than n_fft/2 samples (reflect padding)')
+  s_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+  f_off = np.concatenate([[0], np.cumsum(1 + lens // hop_length)]).astype(np.int64)
+  total = int(f_off[-1])
+  audio = torch.as_tensor(np.concatenate([np.asarray(a, dtype=np.float32) for a in audio_list])).to(dev)
+  basis = torch.as_tensor(mel_filterbank(float(samplerate), n_fft, n_mels).astype(np.float32)).contiguous().to(dev)
+  d_soff, d_foff = torch.as_tensor(s_off).to(dev), torch.as_tensor(f_off).to(dev)
+  out = torch.empty(total * 3 * n_mfcc, dtype=torch.float32, device=dev)
+  ws_bytes = _lib.load().st_mfcc_ws(len(audio_list), total, n_mels, n_mfcc)
+  ws = torch.empty(ws_bytes // 4 + 64, dtype=torch.float32, device=dev)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  _lib.call('st_mfcc_f32', P(audio), P(d_soff), len(audio_list), int(lens.max()), P(basis), n_mels, n_mfcc, n_fft,
+            hop_length, P(d_foff), total, P(out), P(ws), ws.numel() * 4,
+            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+  host = out.view(total, 3 * n_mfcc).cpu().numpy()
+  return [host[f_off[i]:f_off[i + 1]] for i in range(len(audio_list))]
+
+
+def calc_mfccs(audio_data, samplerate, n_mfcc=13, n_fft=512, hop_length=160):
+  """Same contract as the reference (preprocessing.py:61-84): [time, 3 * n_mfcc]."""
+  return calc_mfccs_batch([audio_data], samplerate, n_mfcc, n_fft, hop_length)[0]
+
+
 def iglob_recursive(directory, file_pattern):
   for root, _, names in os.walk(directory):
     for name in fnmatch.filter(names, file_pattern):
@@ -137,6 +169,8 @@ class SpeechCorpusReader:
       rates = {sr for _, sr in loaded}
       if preprocess_fnc == calc_power_spectrogram and len(rates) == 1:
         feats = calc_power_spectrogram_batch([a for a, _ in loaded], rates.pop())
+      elif preprocess_fnc == calc_mfccs and len(rates) == 1:
+        feats = calc_mfccs_batch([a for a, _ in loaded], rates.pop())
       else:
         feats = [preprocess_fnc(a, sr) for a, sr in loaded]
       for f, feat in zip(chunk, feats):
@@ -201,7 +235,7 @@ class Preprocessing:
     if self.flags.feature_type == 'power':
       preprocess_fnc = calc_power_spectrogram
     elif self.flags.feature_type == 'mfcc':
-      raise NotImplementedError('MFCC features (preprocessing.py:61-84) are not on the accelerated path; use --power')
+      preprocess_fnc = calc_mfccs
     else:
       raise ValueError('Feature type must be mfcc or power.')
     preprocess_all = not (self.flags.train_only or self.flags.test_only or self.flags.dev_only)

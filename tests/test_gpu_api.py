@@ -162,6 +162,14 @@ def test_cli_preprocess_train_evaluate(dev, tmp_path):
   out = r.stdout
   assert 'validation average loss' in out and out.count('expected: ') == 4 and 'Global statistics' in out
   assert "expected: hello world it's" in out and 'LED: ' in out and 'WER: ' in out
+  # beam search instead of greedy (extension flag), and the MFCC feature type end to end
+  r = run(['evaluate', '--step-count', '1', '--no-save', '--beam-width', '8'] + common)
+  assert r.returncode == 0 and r.stdout.count('decoded: ') == 4, r.stdout + r.stderr
+  r = run(['preprocess', '--mfcc', '--test-only'] + common)
+  assert r.returncode == 0, r.stdout + r.stderr
+  mf = np.load(str(data / 'preprocessed' / 'test' / 'spk-test-0001.npz'))['audio_fragments']
+  samples, rate = load_audio(str(data / 'test' / 'spk-test-0001.wav'))
+  assert mf.shape == (201, 39) and np.max(np.abs(mf - O.calc_mfccs(samples.astype(np.float64), rate))) < 2e-3
   r = run(['evaluate', '--step-count', '1', '--run-name', 'missing', '--data-dir', str(data),
            '--train-dir', str(tmp_path / 'train'), '--log-dir', str(tmp_path / 'log'), '--batch-size', '4'])
   assert r.returncode != 0 and 'No checkpoint for evaluation found' in r.stderr

@@ -313,6 +313,22 @@ def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
     assert np.max(np.abs(feats[0] - gold)) < 1e-3
 
 
+def test_mfcc_vs_oracle(dev):
+  """calc_mfccs (preprocessing.py:61-84): 13 MFCC + delta + delta-delta, each block z-normalised; ragged
+  batch.  Tolerance 2e-3 absolute on unit-variance features (fp32 FFT/log10/DCT vs float64; the delta-delta
+  block divides small numbers by a small std)."""
+  from speecht_amd.preprocessing import calc_mfccs, calc_mfccs_batch
+  sr = 16000
+  audio = [O.synthetic_audio(7, 16000 + 77), O.synthetic_audio(8, 32000), O.synthetic_audio(9, 5003),
+           (0.3 * np.sin(2 * np.pi * 440.0 * np.arange(12345) / sr) + 0.01 * O.synthetic_audio(3, 12345)).astype(np.float32)]
+  feats = calc_mfccs_batch(audio, sr)
+  for a, f in zip(audio, feats):
+    ref = O.calc_mfccs(a, sr)
+    assert f.shape == ref.shape == (1 + len(a) // 160, 39)
+    assert np.max(np.abs(f - ref)) < 2e-3
+  np.testing.assert_array_equal(calc_mfccs(audio[0], sr), feats[0])
+
+
 def test_shape_switching_reuses_buffers_exactly(dev):
   """Real batches change (B, max_T) every step: buffers are re-described, halos re-zeroed.  Results
   after switching shapes must be bit-identical to a fresh engine's."""

@@ -59,3 +59,37 @@ def test_calc_power_spectrogram_shape_and_stats():
   f = O.calc_power_spectrogram(y, 16000, n_mels=80)
   assert f.shape == (201, 80)
   assert abs(f.mean()) < 1e-12 and f.std() == pytest.approx(1.0)
+
+
+def test_delta_matches_librosa05_lfilter_formulation():
+  """oracle.delta_lfilter vs the librosa 0.5.x recipe written with scipy.signal.lfilter (edge pad by 9,
+  FIR [4..-4]/60 from rest, ``order`` passes over the padded axis, cut [-5-T:-5])."""
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((13, 50))
+  window = np.arange(4.0, -5.0, -1.0)
+  window /= np.sum(window ** 2)
+  for order in (1, 2):
+    d = np.pad(x, [(0, 0), (9, 9)], mode='edge')
+    for _ in range(order):
+      d = scipy.signal.lfilter(window, 1, d, axis=-1)
+    np.testing.assert_allclose(O.delta_lfilter(x, order=order), d[:, -5 - 50:-5], atol=1e-14)
+  # order 1 is the textbook regression delta with clamped edges
+  t = 20
+  ref = sum(k * (x[:, t + k] - x[:, t - k]) for k in range(1, 5)) / 60.0
+  np.testing.assert_allclose(O.delta_lfilter(x)[:, t], ref, atol=1e-14)
+  assert np.allclose(O.delta_lfilter(np.ones((2, 30))), 0.0)
+
+
+def test_dct_basis_is_orthonormal_dct2():
+  import scipy.fftpack
+  rng = np.random.default_rng(1)
+  S = rng.standard_normal((128, 7))
+  np.testing.assert_allclose(O.dct_basis(13, 128) @ S, scipy.fftpack.dct(S, axis=0, type=2, norm='ortho')[:13], atol=1e-12)
+
+
+def test_calc_mfccs_shape_and_block_normalisation():
+  f = O.calc_mfccs(O.synthetic_audio(0, 16000), 16000)
+  assert f.shape == (101, 39)
+  for b in range(3):
+    blk = f[:, 13 * b:13 * (b + 1)]
+    assert abs(blk.mean()) < 1e-12 and abs(blk.std() - 1.0) < 1e-12

@@ -194,7 +194,7 @@ def test_levenshtein():
 
 
 def test_bf16_three_way_split_is_exact_and_six_terms_suffice():
-  """Numerical model of the experimental bf16x6 path (csrc/conv_bf16x6.hip): every fp32 value is the
+  """Numerical model of the experimental bf16x6 path (csrc/conv_bf16.hip): every fp32 value is the
   exact sum of three bf16 pieces, and the six largest cross terms reproduce an fp32 dot product at
   least as accurately as an fp32 FMA chain."""
   def bf16_rn(x):

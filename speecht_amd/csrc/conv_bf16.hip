@@ -158,27 +158,35 @@ struct X6Params {
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
   int tiles_m, tiles_n, chunk;
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+  int pp_map;                            // ping-pong: how waves are dealt to the two groups (experiment knob)
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
 // three planes of both operands (1 KiB DMA pieces), so a stage costs 6 * (64 / rows-per-piece)
 // DMA instructions per wave: 12 for <128, 2x2, BK 32>, 6 for <256, 2x4, BK 16>.
-template <int BT, int WM, int WN, int BK, int NP>
+// ST = LDS ring depth: stages kt+1 .. kt+ST-1 are in flight while stage kt feeds the matrix pipe; a wave
+// waits with a counted s_waitcnt (its own oldest stage) before the per-stage barrier, not vmcnt(0).
+// PP = ping-pong: the waves form two groups (one wave of each per SIMD) that run half a stage out of phase --
+// while one group feeds the matrix pipe the other reads its fragments of the next stage from LDS and issues
+// DMA, two barriers per stage.  Without it all waves leave the stage barrier together, burst-read LDS, and the
+// matrix pipe idles for the whole burst.
+template <int BT, int WM, int WN, int BK, int NP, int ST = 2, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) {
   constexpr int NW = WM * WN;
   constexpr int BM = BT, BN = BT;
-  static_assert(BT == 32 * NW && (BK == 16 || BK == 32 || BK == 64) && (NP == 1 || NP == 3), "tile config");
+  static_assert(BT % (32 * NW) == 0 && (BK == 16 || BK == 32 || BK == 64) && (NP == 1 || NP == 3) && ST >= 2, "tile config");
+  constexpr int RW = BT / NW;                        // rows of each operand a wave stages
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   constexpr int KS = BK / 16;                        // MFMA k-steps per stage
   constexpr int SLOTS = BK / 8;                      // 16-byte slots per row
   constexpr int RPB = 128 / BK;                      // rows per 256-byte bank span
   constexpr int RPP = 512 / BK;                      // rows per 1-KiB DMA piece
-  constexpr int PPW = 32 / RPP;                      // pieces per wave, plane and operand
+  constexpr int PPW = RW / RPP;                      // pieces per wave, plane and operand
   constexpr int PL = BM * BK;                        // elements per plane tile
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NP * PL * 2 + 12 * BM];
+  __shared__ __attribute__((aligned(16))) unsigned short smem[ST * NP * PL * 2 + 12 * BM];
   unsigned short* const As = smem;                   // [buf][plane][BM][BK]
-  unsigned short* const Bs = smem + 2 * NP * PL;
-  long* const a_off = reinterpret_cast<long*>(smem + 4 * NP * PL);
+  unsigned short* const Bs = smem + ST * NP * PL;
+  long* const a_off = reinterpret_cast<long*>(smem + 2 * ST * NP * PL);
   long* const c_off = a_off + BM;
   long* const m_off = c_off + BM;
 
@@ -195,13 +203,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  if (tid < BM) {
-    int m = m0 + tid;
+  for (int t = tid; t < BM; t += 64 * NW) {
+    int m = m0 + t;
     bool valid = m < p.M;
     int mm = valid ? m : p.M - 1;
-    a_off[tid] = p.amap.off(mm);
-    c_off[tid] = valid ? p.cmap.off(mm) : -1;
-    m_off[tid] = (p.mask || p.mask_b) ? p.mmap.off(mm) : 0;
+    a_off[t] = p.amap.off(mm);
+    c_off[t] = valid ? p.cmap.off(mm) : -1;
+    m_off[t] = (p.mask || p.mask_b) ? p.mmap.off(mm) : 0;
   }
   __syncthreads();
 
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   int slot8[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int r = wave * 32 + i * RPP + prow;
+    const int r = wave * RW + i * RPP + prow;
     asrc[i] = p.A + a_off[r];
     slot8[i] = (pslot ^ ((r / RPB) % SLOTS)) * 8;
     bsrc[i] = p.B + (long)min(n0 + r, p.Np - 1) * p.Kp;
@@ -223,10 +231,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     const int op = pc / (NP * PPW), pl = (pc / PPW) % NP, i = pc % PPW;
     if (op == 0) {
       const __bf16* g = asrc[i] + pl * p.a_plane + min(k0 + slot8[i], ktail);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (buf * NP + pl) * PL + (wave * 32 + i * RPP) * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (buf * NP + pl) * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
     } else {
       const __bf16* g = bsrc[i] + pl * p.b_plane + min(k0 + slot8[i], p.Kp - 8);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (buf * NP + pl) * PL + (wave * 32 + i * RPP) * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (buf * NP + pl) * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
     }
   };
 
@@ -259,24 +267,106 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   const int per_split = (units + p.splits - 1) / p.splits;
   const int unit0 = split * per_split;
   const int nk = max(min(per_split, units - unit0), 0) * (tap_inner ? p.taps : 1);
-  int tap = 0, chunk = unit0;
+  int tap = 0, chunk = unit0;            // compute cursor
+  int itap = 0, ichunk = unit0;          // DMA issue cursor (ST-1 stages ahead)
   auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
   auto tile_ks = [&](int t, int c) {
     const int valid = tap_inner ? p.cp - c * BK : p.Kvalid - c * BK;
     return valid >= BK ? KS : (valid + 15) / 16;
   };
+  auto advance = [&](int& t, int& c) {
+    if (tap_inner) { if (++t == p.taps) { t = 0; ++c; } } else { ++c; }
+  };
+  // every wave issues N_DMA pieces per stage and they retire in order, so "my stage kt+1 has landed" is
+  // vmcnt <= (ST-2) * N_DMA while ST-1 stages are in flight; in the tail (nothing new issued) wait for all
+  auto stage_sync = [&](bool full_ring) {
+    if (ST > 2 && full_ring) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((ST - 2) * N_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  static_assert((ST - 2) * N_DMA < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
-  for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, tile_k0(tap, chunk), 0);
-  __syncthreads();
+  for (int sgi = 0; sgi < ST - 1; ++sgi) {
+    if (sgi < nk) {
+      const int k0 = tile_k0(itap, ichunk);
+#pragma unroll
+      for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, k0, sgi);
+      advance(itap, ichunk);
+    }
+  }
+  stage_sync(nk >= ST - 1);
 
-  int cur = 0;
+  int cur = 0, fill = ST - 1;            // ring slots: being consumed / being filled
+  auto mfma_terms = [&](bf16x8 (&af)[KS][NP][MT], bf16x8 (&bf)[KS][NP][NT], int ks) {
+    constexpr int TERMS = NP == 3 ? 6 : 1;
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) {               // smallest terms first
+      constexpr int TA[6] = {NP - 1, 0, NP / 2, NP / 2, 0, 0}, TB[6] = {0, NP - 1, NP / 2, 0, NP / 2, 0};
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][TB[t]][n], af[ks][TA[t]][i], acc[i][n], 0, 0, 0);
+    }
+  };
+  if constexpr (PP) {
+    static_assert(ST >= 3 && NW % 2 == 0, "ping-pong needs a ring of 3 and an even number of waves");
+    const int grp = p.pp_map == 1 ? (wave & 1) : (p.pp_map == 2 ? ((wave >> 1) & 1) : wave / (NW / 2));
+    auto phase_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_stage = [&](bool full_ring) {          // my pieces of the next stage have landed
+      if (full_ring) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * N_DMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (grp == 1) phase_barrier();                   // group 1 runs one phase behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nks = tile_ks(tap, chunk);
+      advance(tap, chunk);
+      const bool more = kt + ST - 1 < nk;
+      const int nk0 = tile_k0(itap, ichunk);
+      if (more) advance(itap, ichunk);
+      const unsigned short* as = As + cur * NP * PL;
+      const unsigned short* bs = Bs + cur * NP * PL;
+      bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
+      // ---- read phase (the other group is in its MFMA phase)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int pl = NP - 1; pl >= 0; --pl) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[ks][pl][i] = *reinterpret_cast<const bf16x8*>(as + pl * PL + a_frag[ks] + i * 32 * BK);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[ks][pl][n] = *reinterpret_cast<const bf16x8*>(bs + pl * PL + b_frag[ks] + n * 32 * BK);
+        }
+      }
+      if (more) {                                    // slot `fill` was last read one phase ago by group 1
+#pragma unroll
+        for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, nk0, fill);
+      }
+      if (grp == 1) wait_stage(more);                // this barrier is group 0's end-of-stage barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      phase_barrier();
+      // ---- MFMA phase: nothing but the matrix instructions (the other group reads / issues DMA)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (ks < nks) mfma_terms(af, bf, ks);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) wait_stage(more);
+      phase_barrier();
+      cur = cur + 1 == ST ? 0 : cur + 1;
+      fill = fill + 1 == ST ? 0 : fill + 1;
+    }
+    if (grp == 0) phase_barrier();                   // every wave executes the same number of barriers
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const int nks = tile_ks(tap, chunk);
-    int ntap = tap, nchunk = chunk;
-    if (tap_inner) { if (++ntap == p.taps) { ntap = 0; ++nchunk; } } else { ++nchunk; }
-    const bool more = kt + 1 < nk;
-    const int nk0 = tile_k0(ntap, nchunk);
-    tap = ntap; chunk = nchunk;
+    advance(tap, chunk);
+    const bool more = kt + ST - 1 < nk;
+    const int nk0 = tile_k0(itap, ichunk);
+    if (more) advance(itap, ichunk);
     const unsigned short* as = As + cur * NP * PL;
     const unsigned short* bs = Bs + cur * NP * PL;
     bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
@@ -294,26 +384,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     for (int ks = 0; ks < KS; ++ks) {
       if (more) {
 #pragma unroll
-        for (int pc = ks * (N_DMA / KS); pc < (ks + 1) * (N_DMA / KS); ++pc) dma_piece(pc, nk0, cur ^ 1);
+        for (int pc = ks * (N_DMA / KS); pc < (ks + 1) * (N_DMA / KS); ++pc) dma_piece(pc, nk0, fill);
       }
       if (ks + 1 < KS) read_frags(ks + 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks < nks) {
-        constexpr int TERMS = NP == 3 ? 6 : 1;
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) {           // smallest terms first
-          constexpr int TA[6] = {NP - 1, 0, NP / 2, NP / 2, 0, 0}, TB[6] = {0, NP - 1, NP / 2, 0, NP / 2, 0};
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][TB[t]][n], af[ks][TA[t]][i], acc[i][n], 0, 0, 0);
-        }
-      }
+      if (ks < nks) mfma_terms(af, bf, ks);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    cur ^= 1;
+    stage_sync(more);
+    cur = cur + 1 == ST ? 0 : cur + 1;
+    fill = fill + 1 == ST ? 0 : fill + 1;
+  }
   }
 
   // epilogue.  The MFMAs above were issued with the operands swapped (filter fragment first), so the
@@ -442,6 +523,8 @@ template <int NP>
 int launch_gemm(X6Params& p, hipStream_t s) {
   static const int big = getenv("ST_X6_TILE") ? atoi(getenv("ST_X6_TILE")) : 256;
   if (p.splits < 1) p.splits = 1;
+  static const int pp_map = getenv("ST_PP_MAP") ? atoi(getenv("ST_PP_MAP")) : 0;
+  p.pp_map = pp_map;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
   const int BT = (big == 256 && fits256 && (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192) ? 256 : 128;
   p.tiles_m = st::ceil_div(p.M, BT);
@@ -449,15 +532,34 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
   if constexpr (NP == 3) {
-    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3>), grid, dim3(512), 0, s, p);
+    static const int ring = getenv("ST_X6_RING") ? atoi(getenv("ST_X6_RING")) : 33;   // 33 = ring of 3 + ping-pong
+    if (BT == 256 && ring == 33) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3, true>), grid, dim3(512), 0, s, p);
+    else if (BT == 256 && ring == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3>), grid, dim3(512), 0, s, p);
+    else if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3>), grid, dim3(512), 0, s, p);
+    else if (big == 16 && ring == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 16, 3, 3>), grid, dim3(256), 0, s, p);
     else if (big == 16) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 16, 3>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 3>), grid, dim3(256), 0, s, p);
   } else {
-    static const int bk = getenv("ST_BF16_BK") ? atoi(getenv("ST_BF16_BK")) : 64;
-    if (BT == 256 && bk == 64) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 64, 1>), grid, dim3(512), 0, s, p);
-    else if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1>), grid, dim3(512), 0, s, p);
-    else if (bk == 64) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 64, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 1>), grid, dim3(256), 0, s, p);
+    // ST_BF16_CFG256 / ST_BF16_CFG128 = <BK><ST>[4 = four big waves] pick stage depth / ring length
+    static const int cfg256 = getenv("ST_BF16_CFG256") ? atoi(getenv("ST_BF16_CFG256")) : 3249;   // BK 32, ring 4, ping-pong
+    static const int cfg128 = getenv("ST_BF16_CFG128") ? atoi(getenv("ST_BF16_CFG128")) : 644;
+#define ST_CASE(T, W1, W2, K, R)                                                                              \
+  hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, 1, R>), grid, dim3(64 * W1 * W2), 0, s, p)
+    if (BT == 256) {
+      if (cfg256 == 3249) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1, 4, true>), grid, dim3(512), 0, s, p);
+      else if (cfg256 == 324) ST_CASE(256, 2, 4, 32, 4);
+      else if (cfg256 == 323) ST_CASE(256, 2, 4, 32, 3);
+      else if (cfg256 == 6424) ST_CASE(256, 2, 2, 64, 2);
+      else if (cfg256 == 3244) ST_CASE(256, 2, 2, 32, 4);
+      else ST_CASE(256, 2, 4, 64, 2);
+    } else {
+      if (cfg128 == 642) ST_CASE(128, 2, 2, 64, 2);
+      else if (cfg128 == 643) ST_CASE(128, 2, 2, 64, 3);
+      else if (cfg128 == 324) ST_CASE(128, 2, 2, 32, 4);
+      else if (cfg128 == 326) ST_CASE(128, 2, 2, 32, 6);
+      else ST_CASE(128, 2, 2, 64, 4);
+    }
+#undef ST_CASE
   }
   return st::check_launch("gemm_nn_bf16");
 }

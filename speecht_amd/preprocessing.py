@@ -154,6 +154,16 @@ class SpeechCorpusReader:
       name += '-power'
     return self._data_directory + '/' + name + '/' + sub_directory
 
+  def generate_samples(self, directory, preprocess_fnc, audio_loader=None, pattern='*.flac'):
+    """Generator of (audio_id, audio_fragments, transcript) straight from the audio files, without the
+    cache (preprocessing.py:180-197).  ``audio_loader`` as in ``store_samples``; defaults to the bundled
+    wav/npy decoder."""
+    loader = audio_loader or load_audio
+    for path in iglob_recursive(self._data_directory + '/' + directory, pattern):
+      samples, rate = loader(path)
+      audio_id = self._extract_audio_id(path)
+      yield audio_id, preprocess_fnc(samples, rate), self._transcript_dict[audio_id]
+
   def store_samples(self, directory, preprocess_fnc, audio_loader=None, pattern='*.flac', batch=32):
     """Preprocess every audio file of ``<data>/<directory>`` and cache it as .npz.  The device
     extractor processes ``batch`` utterances per launch instead of the reference's process pool

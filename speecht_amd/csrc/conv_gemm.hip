@@ -47,7 +47,8 @@ struct NNParams {
   const float* bias;                 // EPI 0
   int M, Kvalid, Kp, n_store, relu;
   int taps, cp;                      // filter width and channel pitch of A (k = tap * cp + channel)
-  int tiles_m, tiles_n, chunk;       // XCD-aware tile order
+  int tiles_m, tiles_n, chunk;       // XCD-aware tile order: 8 XCDs as a gm x gn grid over the tile grid,
+  int gm, tm_per, tn_per;            // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per)
   int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
   int splits, steps_per_split;       // split-K over blockIdx.y: raw partial tiles go to `slab`
   float* slab;                       // [splits][M][Np]
@@ -111,13 +112,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   long* const c_off = a_off + BM;
   long* const m_off = c_off + BM;
 
-  // XCD-aware order: block b runs on XCD b%8; give each XCD one contiguous chunk of the
-  // panel-major tile list so the CUs sharing an L2 stream the same filter panel together.
+  // XCD-aware order: block b runs on XCD b%8, and every XCD has its own L2.  The 8 XCDs are laid over the
+  // tile grid as gm x gn rectangles (chosen by the host to minimise  A-bytes * gn + B-bytes * gm, i.e. how
+  // often each operand is fetched into some L2); inside its rectangle an XCD walks panel-major so that
+  // the CUs sharing the L2 stream the same filter panel together.
   const int bid = blockIdx.x;
-  const int idx = (bid & 7) * p.chunk + (bid >> 3);
-  if ((bid >> 3) >= p.chunk || idx >= p.tiles_m * p.tiles_n) return;
-  const int tile_n = idx / p.tiles_m;
-  const int tile_m = idx - tile_n * p.tiles_m;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int xm = xcd % p.gm, xn = xcd / p.gm;
+  const int ln = local / p.tm_per, lm = local - ln * p.tm_per;
+  const int tile_m = xm * p.tm_per + lm, tile_n = xn * p.tn_per + ln;
+  if (local >= p.chunk || tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
@@ -700,8 +704,26 @@ template <int BM, int BN, int WMW, int WNW>
 void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.tiles_m = st::ceil_div(p.M, BM);
   p.tiles_n = p.Np / BN;
-  const int total = p.tiles_m * p.tiles_n;
-  p.chunk = st::ceil_div(total, 8);
+  {
+    // operand bytes an XCD's L2 has to pull in: the activation rows of its M range (once per N column group)
+    // and the filter panel of its N range (once per M row group)
+    const double a_bytes = (double)p.M * p.cp * 4.0, b_bytes = (double)p.Kp * p.Np * 4.0;
+    static const int forced_gm = getenv("ST_XCD_GM") ? atoi(getenv("ST_XCD_GM")) : 0;
+    double best = 0.0;
+    p.gm = 1;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+      const int gn = 8 / gm;
+      if (gm > p.tiles_m || gn > p.tiles_n) continue;
+      const int slots = st::ceil_div(p.tiles_m, gm) * st::ceil_div(p.tiles_n, gn) * 8;
+      const double cost = (a_bytes * gn + b_bytes * gm) * ((double)slots / (p.tiles_m * p.tiles_n));   // idle slots cost time
+      if (best == 0.0 || cost < best || gm == forced_gm) { best = gm == forced_gm ? -1.0 : cost; p.gm = gm; }
+      if (gm == forced_gm) break;
+    }
+    if (8 / p.gm > p.tiles_n) p.gm = 8;                       // fewer than 8/gm filter panels: stack the XCDs along M
+    p.tm_per = st::ceil_div(p.tiles_m, p.gm);
+    p.tn_per = st::ceil_div(p.tiles_n, 8 / p.gm);
+    p.chunk = p.tm_per * p.tn_per;
+  }
   if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0>), grid, block, 0, s, p);

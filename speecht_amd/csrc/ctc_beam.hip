@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   }
 
   int cur = 0, nb = 1;
+  double offset = 0.0;                   // log-probability of the current best entry (wave-uniform)
   if (lane == 0) {
     BeamSet& s = sets[0];
     s.hash[0] = kRootHash; s.parent_hash[0] = 0; s.len[0] = 0; s.last[0] = -1; s.node[0] = 0;
@@ -225,22 +226,27 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       }
     }
     __syncthreads();
-    // (5) materialise the surviving entries, best first
+    // (5) materialise the surviving entries, best first.  Scores are kept RELATIVE to the best entry (its
+    // total becomes 0) with the running offset in double: after 1500 frames the absolute log-probabilities
+    // are O(-3000), where fp32 resolves only 2e-4 and near-ties at the beam boundary would be decided by
+    // rounding; relative scores stay O(10) for the whole utterance.
+    const float top = n_new > 0 ? sel_v[0] : 0.f;
+    offset += (double)top;
     if (lane < n_new) {
       int k = sel_k[lane];
       int slot = k / C, c = k - slot * C;
       if (c == blank) {
         N.hash[lane] = S.hash[slot]; N.parent_hash[lane] = S.parent_hash[slot];
         N.len[lane] = S.len[slot]; N.last[lane] = S.last[slot]; N.node[lane] = S.node[slot];
-        N.pb[lane] = stay_pb[slot]; N.pl[lane] = stay_pl[slot];
+        N.pb[lane] = stay_pb[slot] - top; N.pl[lane] = stay_pl[slot] - top;
       } else {
         int id = 1 + t * W + lane;
         nodes[id] = make_int2(S.node[slot], c);
         N.hash[lane] = child_hash(S.hash[slot], c); N.parent_hash[lane] = S.hash[slot];
         N.len[lane] = S.len[slot] + 1; N.last[lane] = c; N.node[lane] = id;
-        N.pb[lane] = -INFINITY; N.pl[lane] = sel_v[lane];
+        N.pb[lane] = -INFINITY; N.pl[lane] = sel_v[lane] - top;
       }
-      N.total[lane] = sel_v[lane];
+      N.total[lane] = sel_v[lane] - top;
     }
     nb = n_new;
     cur ^= 1;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     const BeamSet& S = sets[cur];
     int n = min(S.len[0], max_out);
     out_lens[b] = S.len[0];
-    out_logp[b] = S.total[0];
+    out_logp[b] = (float)((double)S.total[0] + offset);
     int id = S.node[0];
     for (int i = S.len[0] - 1; i >= 0; --i) {
       int2 nd = nodes[id];

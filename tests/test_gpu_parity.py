@@ -204,6 +204,24 @@ def test_beam_search_matches_oracle(dev, beam):
     assert ids[4] == [11] * 100                          # repeats separated by blanks survive (200 frames)
 
 
+def test_beam_search_long_form(dev):
+  """Config 5 length (30 s -> T' = 1501), beam 16, labels on almost every frame: absolute log-probabilities
+  reach -3000, where fp32 could no longer order near-ties -- the kernel keeps scores relative to the best
+  entry (double offset), so the label sequences still match the float64 oracle exactly."""
+  rng = np.random.default_rng(77)
+  T, B, C = 1501, 2, 29
+  logits = (rng.standard_normal((T, B, C)) * 3.0).astype(np.float32)
+  lens = np.array([1501, 1203])
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits, (1, 0, 2))))
+  eng.ctc_lens = torch.as_tensor(lens.astype(np.int32)).to(dev)
+  ids, logp = eng.beam_search_decode(16)
+  ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, 16)
+  assert ids == ref_ids
+  np.testing.assert_allclose(logp, ref_logp, rtol=1e-5)
+
+
 def test_beam_search_rejects_bad_arguments(dev):
   eng = make_engine([(1, 1, 16, 29, False)], dev)
   eng.load_batch(np.zeros((2, 9, 16)), [9, 9])

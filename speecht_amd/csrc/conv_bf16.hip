@@ -158,7 +158,6 @@ struct X6Params {
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
   int tiles_m, tiles_n, chunk;
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
-  int pp_map;                            // ping-pong: how waves are dealt to the two groups (experiment knob)
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   };
   if constexpr (PP) {
     static_assert(ST >= 3 && NW % 2 == 0, "ping-pong needs a ring of 3 and an even number of waves");
-    const int grp = p.pp_map == 1 ? (wave & 1) : (p.pp_map == 2 ? ((wave >> 1) & 1) : wave / (NW / 2));
+    const int grp = wave / (NW / 2);               // waves i and i + NW/2 share a SIMD: one of each group per SIMD
     auto phase_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
@@ -519,47 +518,28 @@ __global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restr
   if (threadIdx.x == 0) out[blockIdx.x] = part[0];
 }
 
+// Tile / pipeline choice (measured on config-2 shapes):
+//   wide problems  -> 256 x 256 tile, 8 waves, LDS ring + ping-pong wave groups
+//                     (NP = 3: 16-deep stages, ring of 3; NP = 1: 32-deep stages, ring of 4)
+//   everything else -> 128 x 128 tile, 4 waves (NP = 3: 32-deep stages, 2 slots; NP = 1: 64-deep, ring of 4)
+// ST_BF16_TILE=128 forces the small tile (perf experiments).
 template <int NP>
 int launch_gemm(X6Params& p, hipStream_t s) {
-  static const int big = getenv("ST_X6_TILE") ? atoi(getenv("ST_X6_TILE")) : 256;
+  static const int forced_tile = getenv("ST_BF16_TILE") ? atoi(getenv("ST_BF16_TILE")) : 0;
   if (p.splits < 1) p.splits = 1;
-  static const int pp_map = getenv("ST_PP_MAP") ? atoi(getenv("ST_PP_MAP")) : 0;
-  p.pp_map = pp_map;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
-  const int BT = (big == 256 && fits256 && (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192) ? 256 : 128;
+  const bool wide = (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192;
+  const int BT = (forced_tile != 128 && fits256 && wide) ? 256 : 128;
   p.tiles_m = st::ceil_div(p.M, BT);
   p.tiles_n = st::ceil_div(p.Np, BT);
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
   if constexpr (NP == 3) {
-    static const int ring = getenv("ST_X6_RING") ? atoi(getenv("ST_X6_RING")) : 33;   // 33 = ring of 3 + ping-pong
-    if (BT == 256 && ring == 33) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3, true>), grid, dim3(512), 0, s, p);
-    else if (BT == 256 && ring == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3>), grid, dim3(512), 0, s, p);
-    else if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3>), grid, dim3(512), 0, s, p);
-    else if (big == 16 && ring == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 16, 3, 3>), grid, dim3(256), 0, s, p);
-    else if (big == 16) hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 16, 3>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 3>), grid, dim3(256), 0, s, p);
+    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 3, 2>), grid, dim3(256), 0, s, p);
   } else {
-    // ST_BF16_CFG256 / ST_BF16_CFG128 = <BK><ST>[4 = four big waves] pick stage depth / ring length
-    static const int cfg256 = getenv("ST_BF16_CFG256") ? atoi(getenv("ST_BF16_CFG256")) : 3249;   // BK 32, ring 4, ping-pong
-    static const int cfg128 = getenv("ST_BF16_CFG128") ? atoi(getenv("ST_BF16_CFG128")) : 644;
-#define ST_CASE(T, W1, W2, K, R)                                                                              \
-  hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, 1, R>), grid, dim3(64 * W1 * W2), 0, s, p)
-    if (BT == 256) {
-      if (cfg256 == 3249) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1, 4, true>), grid, dim3(512), 0, s, p);
-      else if (cfg256 == 324) ST_CASE(256, 2, 4, 32, 4);
-      else if (cfg256 == 323) ST_CASE(256, 2, 4, 32, 3);
-      else if (cfg256 == 6424) ST_CASE(256, 2, 2, 64, 2);
-      else if (cfg256 == 3244) ST_CASE(256, 2, 2, 32, 4);
-      else ST_CASE(256, 2, 4, 64, 2);
-    } else {
-      if (cfg128 == 642) ST_CASE(128, 2, 2, 64, 2);
-      else if (cfg128 == 643) ST_CASE(128, 2, 2, 64, 3);
-      else if (cfg128 == 324) ST_CASE(128, 2, 2, 32, 4);
-      else if (cfg128 == 326) ST_CASE(128, 2, 2, 32, 6);
-      else ST_CASE(128, 2, 2, 64, 4);
-    }
-#undef ST_CASE
+    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1, 4, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 64, 1, 4>), grid, dim3(256), 0, s, p);
   }
   return st::check_launch("gemm_nn_bf16");
 }

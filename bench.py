@@ -252,6 +252,7 @@ def main():
       for key, mode, dtype, note in alts:
         alt = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
         alt.params.copy_(eng.params)
+        alt.mark_weights_changed()
         alt.load_batch(x, seq_lens)
         alt.set_labels(labels)
         for _ in range(args.warmup):

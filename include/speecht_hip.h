@@ -148,7 +148,7 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
  * tensors: every entry point takes the st_tensor3 for the geometry (its `base` is ignored) and a
  * separate pointer to the bf16 data.  Filters stay fp32 masters (packed layout above) with a
  * transposed bf16 copy [n_pad][k_pad] made by st_filters_bf16 (k_pad, n_pad from st_packed_dims;
- * the back-prop operand is the same conversion of st_filters_flip_transpose_f32's output).
+ * the back-prop operand comes from st_filters_bwd_bf16).
  * Accumulation, bias, ReLU, the logits of the last layer, CTC, clip and Adam are fp32.
  *   forward : y = relu?(conv(x) + bias) -> y_bf16 and/or y_f32 (either may be NULL)
  *   bwd-data: dx = conv^T(dz) * [act > 0]  (stride-1 layers; act = the layer input, NULL = no mask)
@@ -156,6 +156,10 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
  *             stride 1 or 2; workspace from st_conv1d_bwd_filter_bf16_ws. */
 int st_cast_bf16(const float* src, size_t n, void* dst, void* stream);
 int st_filters_bf16(const float* packed, int k_pad, int n_pad, void* wt, void* stream);
+/* back-prop operand [n_pad(cin)][k_pad(width*cout_pitch)] (zero-initialised by the caller) straight from
+ * the packed filters: out[c][(W-1-w)*cout_pitch + o] = packed[w*cin_pitch + c][o] */
+int st_filters_bwd_bf16(const float* packed, int width, int cin, int cout, int cin_pitch, int cout_pitch,
+                        void* wtt, void* stream);
 int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16,
                            const float* bias, int width, int stride, int pad_left, int relu,
                            const st_tensor3* y, void* y_bf16, float* y_f32, void* stream);

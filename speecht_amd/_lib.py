@@ -51,6 +51,7 @@ _SIGNATURES = {
                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_cast_bf16': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     'st_filters_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'st_filters_bwd_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_conv1d_nwc_fwd_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p,
                                        c_void_p, c_void_p]),
     'st_conv1d_bwd_data_bf16_ws': (c_size_t, [_T3P, _T3P, c_int]),

@@ -117,18 +117,50 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int rows, int row0,
                                                              int step, int t_pitch, int c_pitch, int c_rows, int tq,
                                                              unsigned short* __restrict__ dst) {
-  __shared__ unsigned short tile[32][34];
+  // 64 frames x 64 channels per workgroup, 8-byte global accesses on both sides
+  typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+  __shared__ unsigned short tile[64][66];
   const int b = blockIdx.z;
-  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
   const unsigned short* s = src + ((long)b * t_pitch + row0) * c_pitch;
-  for (int r = ty; r < 32; r += 8)
-    tile[r][tx] = (j0 + r < rows && c0 + tx < c_pitch) ? s[(long)(j0 + r) * step * c_pitch + c0 + tx] : (unsigned short)0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 16 + r16, c = c0 + q * 4;
+    u16x4 v = {0, 0, 0, 0};
+    if (j0 + r < rows && c < c_pitch) v = *reinterpret_cast<const u16x4*>(s + (long)(j0 + r) * step * c_pitch + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[r][q * 4 + e] = v[e];
+  }
   __syncthreads();
   const long row_len = (long)gridDim.z * tq;
-  for (int r = ty; r < 32; r += 8) {
-    const int c = c0 + r, j = j0 + tx;
-    if (c < c_rows && j < tq) dst[(size_t)c * row_len + (size_t)b * tq + j] = tile[tx][r];   // zeros outside the source
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = c0 + it * 16 + r16, j = j0 + q * 4;
+    if (c < c_rows && j < tq) {                       // zeros outside the source
+      u16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tile[q * 4 + e][it * 16 + r16];
+      *reinterpret_cast<u16x4*>(dst + (size_t)c * row_len + (size_t)b * tq + j) = v;
+    }
+  }
+}
+
+// back-prop operand of the bf16 path straight from the packed fp32 filters: the flipped/transposed filter
+// stored reduction-contiguous is a row copy,  out[c][(W-1-w) * cout_pitch + o] = packed[w * cin_pitch + c][o]
+__global__ __launch_bounds__(256) void filters_bwd_bf16_kernel(const float* __restrict__ packed, int width, int cin,
+                                                               int cin_pitch, int cout_pitch, int n_pad, int kt_pad,
+                                                               __bf16* __restrict__ out) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int q4 = cout_pitch / 4;
+  const long total = (long)width * cin * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int o = (int)(i % q4) * 4;
+    const long wc = i / q4;
+    const int c = (int)(wc % cin), w = (int)(wc / cin);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(packed + ((long)w * cin_pitch + c) * n_pad + o);
+    *reinterpret_cast<bf16x4*>(out + (long)c * kt_pad + (long)(width - 1 - w) * cout_pitch + o) =
+        bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   }
 }
 
@@ -785,6 +817,20 @@ int st_filters_bf16(const float* packed, int k_pad, int n_pad, void* wt, void* s
   return st::check_launch("filters_bf16");
 }
 
+int st_filters_bwd_bf16(const float* packed, int width, int cin, int cout, int cin_pitch, int cout_pitch, void* wtt,
+                        void* stream) {
+  ST_REQUIRE(packed && wtt && width >= 1 && cin >= 1 && cout >= 1 && cin_pitch >= cin && cout_pitch >= cout &&
+                 cout_pitch % 16 == 0 && cin_pitch % 16 == 0,
+             "st_filters_bwd_bf16: bad args");
+  const int n_pad = npad_of(cout);                                   // column pitch of the packed filters
+  const int kt_pad = (int)st::round_up((size_t)width * cout_pitch, 32);
+  const long total = (long)width * cin * (cout_pitch / 4);
+  hipLaunchKernelGGL(filters_bwd_bf16_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                     st::as_stream(stream), packed, width, cin, cin_pitch, cout_pitch, n_pad, kt_pad,
+                     reinterpret_cast<__bf16*>(wtt));
+  return st::check_launch("filters_bwd_bf16");
+}
+
 int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16, const float* bias, int width,
                            int stride, int pad_left, int relu, const st_tensor3* y, void* y_bf16, float* y_f32,
                            void* stream) {
@@ -850,7 +896,7 @@ int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const
   // reduction-major copies (every element of [c][b*tq + j] is written: zeros where the source has no row)
   for (int ph = 0; ph < stride; ++ph) {
     const int rows = st::ceil_div(x->t_pitch - first - ph, stride);
-    dim3 grid(w.tq / 32, st::ceil_div(x->c_pitch, 32), x->batch);
+    dim3 grid(st::ceil_div(w.tq, 64), st::ceil_div(x->c_pitch, 64), x->batch);
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x_bf16),
                        rows, first + ph, stride, x->t_pitch, x->c_pitch, x->c_pitch, w.tq, xt + ph * w.xt_phase_elems);
     if (hipMemsetAsync(xt + ph * w.xt_phase_elems + (size_t)x->c_pitch * w.red, 0, 4096 * 2, s) != hipSuccess) {
@@ -859,7 +905,7 @@ int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const
     }
   }
   {
-    dim3 grid(w.tq / 32, st::ceil_div(w.n_pad, 32), dz->batch);
+    dim3 grid(st::ceil_div(w.tq, 64), st::ceil_div(w.n_pad, 64), dz->batch);
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(dz_bf16),
                        dz->frames, dz->halo, 1, dz->t_pitch, dz->c_pitch, w.n_pad, w.tq, dzt);
   }

@@ -161,6 +161,13 @@ class Wav2LetterEngine:
     torch.cuda.synchronize(self.device)
     self._packed_t_fresh = False
     self._wplanes_fresh = False
+    self._wtplanes_fresh = False
+
+  def mark_weights_changed(self):
+    """Call after writing ``self.params`` directly: derived operand copies are rebuilt on next use."""
+    self._packed_t_fresh = False
+    self._wplanes_fresh = False
+    self._wtplanes_fresh = False
 
   def _unpack(self, flat):
     out = []
@@ -255,7 +262,8 @@ class Wav2LetterEngine:
   def _refresh_bf16_filters(self, transposed):
     for i, l in enumerate(self.layers):
       if transposed and i > 0:
-        call('st_filters_bf16', self._ptr(self.packed_t[i]), l.kt_pad, l.nt_pad, self._ptr(self.WTb[i]), self.stream_ptr)
+        call('st_filters_bwd_bf16', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
+             l.cout_pitch, self._ptr(self.WTb[i]), self.stream_ptr)
       elif not transposed:
         call('st_filters_bf16', self._ptr(self._slice(self.params, i)[0]), l.k_pad, l.n_pad, self._ptr(self.Wb[i]),
              self.stream_ptr)
@@ -418,10 +426,10 @@ class Wav2LetterEngine:
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
     called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce)."""
     s = self.stream_ptr
-    if not self._packed_t_fresh:
-      self.refresh_packed_t()
     if self.conv_mode == 'bf16':
       return self._backward_bf16(on_layer_done)
+    if not self._packed_t_fresh:
+      self.refresh_packed_t()
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
@@ -464,6 +472,7 @@ class Wav2LetterEngine:
          self._ptr(self.stats), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
     self._packed_t_fresh = False
     self._wplanes_fresh = False
+    self._wtplanes_fresh = False
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

@@ -101,8 +101,7 @@ class _Saver:
       eng.adam_m.copy_(torch.as_tensor(ck['adam_m']).to(dev))
       eng.adam_v.copy_(torch.as_tensor(ck['adam_v']).to(dev))
       eng.step_count = int(ck['global_step'])
-      eng._packed_t_fresh = False
-      eng._wplanes_fresh = False
+      eng.mark_weights_changed()
       self.model.global_step.value = int(ck['global_step'])
       if hasattr(self.model, 'learning_rate'):
         self.model.learning_rate.value = float(ck['learning_rate'])

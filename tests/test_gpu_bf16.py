@@ -166,3 +166,32 @@ def test_bf16_entry_points_reject_bad_arguments(dev):
   with pytest.raises(_lib.SpeechtHipError, match='workspace'):
     _lib.call('st_conv1d_nwc_bwd_filter_bf16', eng.X[0].ref, eng._ptr(eng.Xb[0]), eng.dZ[0].ref, eng._ptr(eng.dZb[0]),
               7, 1, 3, eng._ptr(eng.grads), eng._ptr(eng.grads), None, 0, None)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x6', 'bf16'])
+def test_second_step_uses_updated_weights(dev, mode):
+  """Every derived copy of the filters (flipped operand for back-prop, bf16 copies, split planes) must be
+  rebuilt after an Adam step: step 2 of a running engine equals step 1 of a fresh engine that was handed the
+  updated weights."""
+  case = WL.small_train_case()
+
+  def one_step(eng):
+    eng.load_batch(case['x'], case['seq_lens'])
+    eng.set_labels(case['labels'])
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / 3)
+    eng.backward()
+    return eng.loss.cpu().numpy().copy(), eng.get_grads()
+
+  a = engine(case['layers'], dev, mode)
+  a.set_weights(case['params'])
+  one_step(a)
+  a.apply_update(lr=1e-2)                      # a large step so that stale operands would show
+  loss_a, grads_a = one_step(a)
+  b = engine(case['layers'], dev, mode)
+  b.set_weights(a.get_weights())
+  loss_b, grads_b = one_step(b)
+  np.testing.assert_array_equal(loss_a, loss_b)
+  for (fa, ba), (fb, bb) in zip(grads_a, grads_b):
+    np.testing.assert_array_equal(fa, fb)
+    np.testing.assert_array_equal(ba, bb)

@@ -68,7 +68,7 @@ void run(const char* name, int blocks, int iters) {
 }
 
 // fp32 matrix instruction of the default path (v_mfma_f32_32x32x2_f32), random operands
-template <int THREADS>
+template <int THREADS, int NACC = 8>
 __global__ __launch_bounds__(THREADS) void mfma_loop_f32(float* out, const float* __restrict__ rnd, int iters) {
   f32x16 acc[8];
   for (int a = 0; a < 8; ++a)
@@ -79,13 +79,14 @@ __global__ __launch_bounds__(THREADS) void mfma_loop_f32(float* out, const float
 #pragma unroll
     for (int rep = 0; rep < 6; ++rep)
 #pragma unroll
-      for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[(rep + a) % 6], y[(rep * 5 + a) % 6], acc[a], 0, 0, 0);
+      for (int a = 0; a < 8; ++a) acc[a % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[(rep + a) % 6], y[(rep * 5 + a) % 6], acc[a % NACC], 0, 0, 0);
   }
   float s = 0.f;
   for (int a = 0; a < 8; ++a) s += acc[a][0];
   if (s == 12345.f) out[0] = s;
 }
 
+template <int THREADS, int NACC>
 void run_f32(const char* name, int blocks, int iters) {
   float *out, *rnd;
   hipMalloc(&out, 4);
@@ -98,12 +99,12 @@ void run_f32(const char* name, int blocks, int iters) {
   hipEventCreate(&a); hipEventCreate(&b);
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(a);
-    hipLaunchKernelGGL(mfma_loop_f32<512>, dim3(blocks), dim3(512), 0, 0, out, rnd, iters);
+    hipLaunchKernelGGL((mfma_loop_f32<THREADS, NACC>), dim3(blocks), dim3(THREADS), 0, 0, out, rnd, iters);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
-    const double mfmas = (double)blocks * 8 * iters * 48.0;
+    const double mfmas = (double)blocks * (THREADS / 64) * iters * 48.0;
     if (rep) printf("%s: %.3f ms, %.1f TFLOP/s\n", name, ms, mfmas * 4096.0 / (ms * 1e-3) / 1e12);
   }
 }
@@ -137,7 +138,11 @@ void run_random(const char* name, int blocks, int iters) {
 }
 
 int main() {
-  run_f32("fp32 32x32x2, random operands, 2 waves/SIMD", 256, 10000);
+  run_f32<512, 8>("fp32 32x32x2, random operands, 2 waves/SIMD, 8 accumulators", 256, 5000);
+  run_f32<256, 8>("fp32 32x32x2, random operands, 1 wave/SIMD, 8 accumulators", 256, 10000);
+  run_f32<256, 4>("fp32 32x32x2, random operands, 1 wave/SIMD, 4 accumulators", 256, 10000);
+  run_f32<512, 4>("fp32 32x32x2, random operands, 2 waves/SIMD, 4 accumulators", 256, 5000);
+  run_f32<256, 2>("fp32 32x32x2, random operands, 1 wave/SIMD, 2 accumulators", 256, 10000);
   run_random<256>("random operands, 1 wave/SIMD ", 256, 20000);
   run_random<512>("random operands, 2 waves/SIMD", 256, 10000);
   run_random<256>("random operands, 1 wave/SIMD, long", 256, 200000);

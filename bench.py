@@ -105,11 +105,12 @@ def measure_mel(dev, batch, seconds, n_mels, reps=5):
   """calc_power_spectrogram (preprocessing.py:36-58) on `batch` resident 16 kHz clips: the reference
   runs it offline (speecht-cli preprocess), so it is reported beside, not inside, the step metric."""
   import ctypes
-  from oracle.w2l_oracle import synthetic_audio       # deterministic clips only (SURVEY 8(d))
   from speecht_amd import _lib
   from speecht_amd.preprocessing import mel_filterbank
   n = int(seconds * 16000)
-  audio = torch.as_tensor(np.concatenate([synthetic_audio(i, n) for i in range(batch)])).to(dev)
+  # deterministic clips of SURVEY 8(d): clip(0.1 * N(0,1), -1, 1), rng seeded 1234 + utterance index
+  clips = [np.clip(0.1 * np.random.default_rng(1234 + i).standard_normal(n), -1.0, 1.0).astype(np.float32) for i in range(batch)]
+  audio = torch.as_tensor(np.concatenate(clips)).to(dev)
   frames = 1 + n // 160
   s_off = torch.arange(batch + 1, dtype=torch.int64, device=dev) * n
   f_off = torch.arange(batch + 1, dtype=torch.int64, device=dev) * frames

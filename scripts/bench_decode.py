@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 5 on one GPU: 30 s long-form utterances (T = 3001 -> T' = 1501), batch 16 per GPU,
 forward + CTC decode.  Times forward, greedy decode and the LM-free prefix beam search (beam 16 by
-default) separately with HIP events on resident inputs, and checks the beam result of two utterances
-against the oracle."""
+default) separately with HIP events on resident inputs (parity of the decoders is pinned in
+tests/test_gpu_parity.py, not here)."""
 import argparse
 import json
 import os
@@ -12,7 +12,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import w2l_oracle as O              # noqa: E402  (checker only)
 from speecht_amd.engine import Wav2LetterEngine  # noqa: E402
 from tests import workloads as WL                # noqa: E402
 
@@ -50,14 +49,10 @@ def main():
   t_greedy = timed(lambda: eng.greedy_decode(), args.reps)
   t_beam = timed(lambda: eng.beam_search_decode(args.beam), args.reps)
   ids, logp = eng.beam_search_decode(args.beam)
-  logits = eng.X[-1].interior().cpu().numpy().astype(np.float64)[:2]
-  ref_ids, ref_logp = O.ctc_beam_search_decode(np.transpose(logits, (1, 0, 2)), [frames // 2] * 2, args.beam)   # the path decodes seq_len // 2 frames
-  ok = ids[:2] == ref_ids
-  logp_err = float(np.max(np.abs(logp[:2] - ref_logp) / np.abs(ref_logp)))
   out = {'workload': 'configs[4]: batch {} of {:g} s, T\'={}, beam {}'.format(args.batch, args.seconds, eng.t_out, args.beam),
          'forward_ms': round(t_fwd, 3), 'greedy_ms_incl_d2h': round(t_greedy, 3),
          'beam_ms_incl_d2h': round(t_beam, 3), 'utt_per_s_forward_plus_beam': round(args.batch / (t_fwd + t_beam) * 1e3, 1),
-         'mean_decoded_len': float(np.mean([len(i) for i in ids])), 'oracle_ids_match_first2': bool(ok), 'oracle_logp_rel_err': logp_err}
+         'mean_decoded_len': float(np.mean([len(i) for i in ids]))}
   print(json.dumps(out))
 
 

@@ -195,3 +195,28 @@ def test_second_step_uses_updated_weights(dev, mode):
   for (fa, ba), (fb, bb) in zip(grads_a, grads_b):
     np.testing.assert_array_equal(fa, fb)
     np.testing.assert_array_equal(ba, bb)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x6'])
+def test_training_reduces_loss_like_fp32(dev, mode):
+  """40 Adam steps on one small batch: the loss curve of the alternative arithmetic tracks the fp32 path
+  (same start, same end within 3 % for bf16 activations, 0.1 % for the fp32-accurate split)."""
+  case = WL.small_train_case()
+  curves = {}
+  for m in ('fp32', mode):
+    eng = engine(case['layers'], dev, m)
+    eng.set_weights(case['params'])
+    eng.load_batch(case['x'], case['seq_lens'])
+    eng.set_labels(case['labels'])
+    losses = []
+    for _ in range(40):
+      eng.forward()
+      eng.ctc_loss_grad(1.0 / 3)
+      eng.backward()
+      eng.apply_update(lr=1e-3)
+      losses.append(float(eng.loss.mean()))
+    curves[m] = np.array(losses)
+  ref, got = curves['fp32'], curves[mode]
+  assert ref[-1] < 0.7 * ref[0] and got[-1] < 0.7 * got[0]
+  tol = 3e-2 if mode == 'bf16' else 1e-3
+  assert abs(got[0] - ref[0]) <= tol * ref[0] and abs(got[-1] - ref[-1]) <= tol * ref[-1], (ref[[0, -1]], got[[0, -1]])

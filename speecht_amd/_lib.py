@@ -80,7 +80,9 @@ _EXPERIMENTAL = {
     'st_exp_split3_transpose_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'st_exp_conv1d_fwd_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P,
                                          c_void_p, c_void_p]),
-    'st_exp_conv1d_bwd_data_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p]),
+    'st_exp_conv1d_bwd_data_bf16x6_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_exp_conv1d_bwd_data_bf16x6': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p, c_size_t,
+                                              c_void_p]),
     'st_exp_transpose_split3_bf16': (c_int, [_T3P, c_int, c_int, c_int, c_size_t, c_void_p, c_void_p]),
     'st_exp_conv1d_bwd_filter_bf16x6': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -507,11 +507,15 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
-// second half of a split convolution: out = [mask] relu?(sum_s slabs[s] + bias) -> bf16 padded NWC tensor
+// second half of a split convolution: v = [mask] relu?(sum_s slabs[s] + bias) -> the padded NWC output as NP
+// bf16 planes and/or fp32
+template <int NP>
 __global__ __launch_bounds__(256) void slab_epilogue_kernel(const float* __restrict__ slabs, int n_slabs, long slab_stride,
                                                             int M, int Np, int n_store, const float* __restrict__ bias,
-                                                            int relu, const __bf16* __restrict__ mask_b, RowMapB mmap,
-                                                            RowMapB cmap, __bf16* __restrict__ out) {
+                                                            int relu, const float* __restrict__ mask_f,
+                                                            const __bf16* __restrict__ mask_b, RowMapB mmap, RowMapB cmap,
+                                                            __bf16* __restrict__ out, size_t c_plane,
+                                                            float* __restrict__ out_f) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int q = n_store / 4;                                     // n_store is a multiple of 16
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)M * q; idx += (long)gridDim.x * 256) {
@@ -519,15 +523,36 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const float* __restr
     f32x4 a = *reinterpret_cast<const f32x4*>(slabs + (long)m * Np + c);
     for (int s = 1; s < n_slabs; ++s) a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + (long)m * Np + c);
     if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
-    bf16x4 keep{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
-    if (mask_b) keep = *reinterpret_cast<const bf16x4*>(mask_b + mmap.off(m) + c);
-    bf16x4 o;
+    f32x4 keep{1.f, 1.f, 1.f, 1.f};
+    if (mask_f) keep = *reinterpret_cast<const f32x4*>(mask_f + mmap.off(m) + c);
+    if (mask_b) {
+      const bf16x4 kb = *reinterpret_cast<const bf16x4*>(mask_b + mmap.off(m) + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) keep[e] = (float)kb[e];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v = relu ? fmaxf(a[e], 0.f) : a[e];
-      o[e] = (__bf16)((float)keep[e] > 0.f ? v : 0.f);
+      const float v = relu ? fmaxf(a[e], 0.f) : a[e];
+      a[e] = keep[e] > 0.f ? v : 0.f;
     }
-    *reinterpret_cast<bf16x4*>(out + cmap.off(m) + c) = o;
+    const long o = cmap.off(m) + c;
+    if (out_f) *reinterpret_cast<f32x4*>(out_f + o) = a;
+    if (out) {
+      if constexpr (NP == 1) {
+        *reinterpret_cast<bf16x4*>(out + o) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+      } else {
+        bf16x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 sh, sm, sl;
+          split3(a[e], sh, sm, sl);
+          ph[e] = sh; pm[e] = sm; pl[e] = sl;
+        }
+        *reinterpret_cast<bf16x4*>(out + o) = ph;
+        *reinterpret_cast<bf16x4*>(out + c_plane + o) = pm;
+        *reinterpret_cast<bf16x4*>(out + 2 * c_plane + o) = pl;
+      }
+    }
   }
 }
 
@@ -648,10 +673,12 @@ int conv_bwd_data(const st_tensor3* dz, const void* dz_planes, const void* wt_pl
   p.taps = width;
   p.cp = dz->c_pitch;
   if (splits <= 1) return launch_gemm<NP>(p, s);
-  // split: fp32 partial sums [split][M][Np], then one pass that sums, masks and writes the bf16 tensor
+  // split: fp32 partial sums [split][M][Np], then one pass that sums, masks and writes the output tensor(s)
   const RowMapB out_map = p.cmap, mask_map = p.mmap;
   const __bf16* mask_b = p.mask_b;
+  const float* mask_f = p.mask;
   __bf16* out = p.Cp;
+  float* out_f = p.C;
   p.C = slabs; p.Cp = nullptr; p.mask = nullptr; p.mask_b = nullptr;
   p.cmap = RowMapB{};
   p.cmap.frames = p.M;
@@ -660,8 +687,9 @@ int conv_bwd_data(const st_tensor3* dz, const void* dz_planes, const void* wt_pl
   p.slab_stride = (long)p.M * p.Np;
   if (int e = launch_gemm<NP>(p, s)) return e;
   const long work = (long)p.M * (p.n_store / 4);
-  hipLaunchKernelGGL(slab_epilogue_kernel, dim3((unsigned)std::min<long>((work + 255) / 256, 4096)), dim3(256), 0, s, slabs,
-                     splits, p.slab_stride, p.M, p.Np, p.n_store, (const float*)nullptr, 0, mask_b, mask_map, out_map, out);
+  hipLaunchKernelGGL(slab_epilogue_kernel<NP>, dim3((unsigned)std::min<long>((work + 255) / 256, 4096)), dim3(256), 0, s,
+                     slabs, splits, p.slab_stride, p.M, p.Np, p.n_store, (const float*)nullptr, 0, mask_f, mask_b, mask_map,
+                     out_map, out, p.c_plane, out_f);
   return st::check_launch("slab_epilogue");
 }
 
@@ -767,15 +795,24 @@ int st_exp_conv1d_fwd_bf16x6(const st_tensor3* x, const void* x_planes, const vo
 
 // back-prop to the layer input on the bf16x6 path (stride-1 layers): dz planes x planes of the
 // flipped/transposed filter operand; act (nullable) is the ReLU mask source
+size_t st_exp_conv1d_bwd_data_bf16x6_ws(const st_tensor3* dz, const st_tensor3* dx, int width) {
+  if (!dz || !dx) return 0;
+  const int splits = bwd_data_splits(*dz, *dx, width);
+  return splits > 1 ? (size_t)splits * dx->batch * dx->frames * npad_of(dx->channels) * sizeof(float) : 0;
+}
+
 int st_exp_conv1d_bwd_data_bf16x6(const st_tensor3* dz, const void* dz_planes, const void* wt_planes, int width,
                                   int pad_left, const st_tensor3* act, const st_tensor3* dx, void* dx_planes,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(dz && dx && dz_planes && wt_planes && dx->base, "conv bwd bf16x6: null argument");
   const int lead = width - 1 - pad_left;
   ST_REQUIRE(lead >= 0 && dz->halo >= lead && dz->frames == dx->frames && dz->batch == dx->batch, "conv bwd bf16x6: bad geometry");
   ST_REQUIRE(npad_of(dx->channels) % 128 == 0, "conv bwd bf16x6: n_pad must be a multiple of 128");
+  // few output tiles and a long reduction (back-prop through L8): split over channel chunks when a workspace is given
+  int splits = bwd_data_splits(*dz, *dx, width);
+  if (!workspace || workspace_bytes < st_exp_conv1d_bwd_data_bf16x6_ws(dz, dx, width)) splits = 1;
   return conv_bwd_data<3>(dz, dz_planes, wt_planes, width, pad_left, act, act ? act->base : nullptr, nullptr, dx,
-                          dx->base, dx_planes, st::as_stream(stream));
+                          dx->base, dx_planes, st::as_stream(stream), splits, reinterpret_cast<float*>(workspace));
 }
 
 // planes [c_rows][batch * tq] of a padded tensor, rows [row0, row0 + rows) of every utterance

@@ -231,6 +231,9 @@ class Wav2LetterEngine:
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
     ws = max([ws] + [lib.st_conv1d_bwd_data_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
+    if self.conv_mode == 'bf16x6':
+      ws = max([ws] + [lib.st_exp_conv1d_bwd_data_bf16x6_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
+                       for i, l in enumerate(self.layers) if i > 0])
     self.wgrad_ws, _ = self._storage.view('wgrad_ws', ws // 4 + 64)
     self.loss = self._storage.view('loss', batch)[0][:batch]
     self.ctc_status = self._storage.view('ctc_status', batch, torch.int32)[0][:batch]
@@ -455,7 +458,7 @@ class Wav2LetterEngine:
           call('st_exp_split3_bf16', self._ptr(self.dZ[i].buf), self.dZ[i].buf.numel(), self._ptr(self.dZp[i]), s)
         dxp = self._ptr(self.dZp[i - 1]) if self._x6_bwd(i - 1) else None
         call('st_exp_conv1d_bwd_data_bf16x6', self.dZ[i].ref, self._ptr(self.dZp[i]), self._ptr(self.WTp[i]), l.width,
-             self.geo[i][2], act, self.dZ[i - 1].ref, dxp, s)
+             self.geo[i][2], act, self.dZ[i - 1].ref, dxp, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         act = self.X[i].ref if self.layers[i - 1].relu else None

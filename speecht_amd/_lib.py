@@ -74,7 +74,7 @@ _SIGNATURES = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
-# experimental entry points (csrc/conv_bf16.hip): not part of include/speecht_hip.h yet
+# experimental entry points (csrc/conv_bf16.hip), declared in include/speecht_hip_experimental.h
 _EXPERIMENTAL = {
     'st_exp_split3_bf16': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     'st_exp_split3_transpose_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -57,6 +57,9 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), name
   assert declared == set(_lib.EXPORTED_SYMBOLS)
+  exp = open(os.path.join(ROOT, 'include', 'speecht_hip_experimental.h')).read()
+  exp = set(re.findall(r'\b(st_exp_[a-z0-9_]+)\s*\(', re.sub(r'/\*.*?\*/', '', exp, flags=re.S)))
+  assert exp == set(_lib._EXPERIMENTAL) and all(hasattr(lib, n) for n in exp)
   assert _lib.load().st_version() >= 100
 
 

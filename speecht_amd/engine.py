@@ -359,7 +359,13 @@ class Wav2LetterEngine:
 
   # ---- the path ----------------------------------------------------------------------------
   def load_batch(self, inputs, seq_lens):
-    """inputs: [B, T, input_size] (numpy or torch, any float dtype); seq_lens: [B] unpadded frames."""
+    """inputs: [B, T, input_size] (numpy or torch, any float dtype, or a ``speech_input.StagedBatch`` that the
+    input pipeline already copied to the device); seq_lens: [B] unpadded frames."""
+    if hasattr(inputs, 'event') and hasattr(inputs, 'tensor'):
+      stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+      stream.wait_event(inputs.event)              # H2D ran on the pipeline's copy stream
+      inputs.tensor.record_stream(stream)          # keep the allocator from recycling it under the copy below
+      inputs = inputs.tensor
     x = torch.as_tensor(inputs)
     B, T, C = x.shape
     assert C == self.layers[0].cin, 'input_size mismatch'

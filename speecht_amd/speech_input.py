@@ -15,6 +15,15 @@ import numpy as np
 SparseTensorValue = collections.namedtuple('SparseTensorValue', ['indices', 'values', 'dense_shape'])
 
 
+class StagedBatch:
+  """A padded input batch that already lives in device memory: ``tensor`` [B, max_T, C] float32 and the
+  event recorded on the copy stream after its H2D transfer (the consumer's stream waits on it)."""
+
+  def __init__(self, tensor, event):
+    self.tensor, self.event = tensor, event
+    self.shape = tuple(tensor.shape)
+
+
 class OutOfRangeError(Exception):
   """End-of-data signal, the role tf.errors.OutOfRangeError plays in training.py:92 / evaluation.py:109."""
 
@@ -128,6 +137,7 @@ class InputBatchLoader(BaseInputLoader):
   speech_input.py:169-179) and ``max_steps`` caps the batches produced."""
 
   CAPACITY = 100
+  DEVICE_PREFETCH = 3          # batches staged in HBM ahead of the consumer (copy stream, own thread)
 
   def __init__(self, input_size, batch_size, data_generator_creator, max_steps=None):
     super().__init__(input_size)
@@ -140,6 +150,8 @@ class InputBatchLoader(BaseInputLoader):
     self._queue = queue.Queue(maxsize=self.CAPACITY)
     self._closed = threading.Event()
     self._lock = threading.Lock()
+    self._staged = None          # queue of device-resident batches once a stager thread runs
+    self._staged_closed = threading.Event()
 
   def get_inputs(self):
     return self.inputs, self.sequence_lengths, self.labels
@@ -176,12 +188,53 @@ class InputBatchLoader(BaseInputLoader):
       t.start()
       coord.register_thread(t)
       threads.append(t)
+    device = getattr(sess, 'device', None)
+    if device is not None and getattr(device, 'type', None) == 'cuda':
+      # the H2D copy of batch k+1.. overlaps the kernels of batch k (separate HIP stream, own thread)
+      self._staged = queue.Queue(maxsize=self.DEVICE_PREFETCH)
+      t = threading.Thread(target=self._stage, args=(device, coord), daemon=True)
+      t.start()
+      coord.register_thread(t)
+      threads.append(t)
     return threads
 
-  def dequeue(self):
+  def _dequeue_host(self):
     while True:
       try:
         return self._queue.get(timeout=0.05)
       except queue.Empty:
         if self._closed.is_set() and self._queue.empty():
+          raise OutOfRangeError('input queue is closed and has insufficient elements')
+
+  def _stage(self, device, coord):
+    import torch
+    stream = torch.cuda.Stream(device)
+    try:
+      while not coord.should_stop():
+        try:
+          inputs, seq_lens, labels = self._dequeue_host()
+        except OutOfRangeError:
+          break
+        with torch.cuda.stream(stream):
+          tensor = torch.as_tensor(inputs).to(device)          # staged copy; the GIL is released meanwhile
+          event = torch.cuda.Event()
+          event.record(stream)
+        item = (StagedBatch(tensor, event), seq_lens, labels)
+        while not coord.should_stop():
+          try:
+            self._staged.put(item, timeout=0.1)
+            break
+          except queue.Full:
+            continue
+    finally:
+      self._staged_closed.set()
+
+  def dequeue(self):
+    if self._staged is None:
+      return self._dequeue_host()
+    while True:
+      try:
+        return self._staged.get(timeout=0.05)
+      except queue.Empty:
+        if self._staged_closed.is_set() and self._staged.empty():
           raise OutOfRangeError('input queue is closed and has insufficient elements')

@@ -7,8 +7,9 @@
 // Mapping: ONE wavefront per utterance (the recursion is sequential in time, utterances are the
 // parallel axis).  Everything that lives across frames -- the beam entries -- sits in LDS, double
 // buffered; a frame is: log-softmax of the 29 logits (wave reduce), parent matching (W^2 hash compares
-// spread over the lanes), one sortable 64-bit key per candidate (W*C of them, lane-strided, in registers),
-// and W rounds of a wave-wide arg-max on the DPP network where only the winning lane refreshes its local best.  Prefix identity is a
+// spread over the lanes), one sortable 32-bit score per candidate (W*C of them, lane-strided, in registers),
+// and W rounds of a wave-wide maximum on the DPP network (ballot + find-first names the winner) where only the
+// winning lane refreshes its local best.  Prefix identity is a
 // 64-bit mixed hash + length (the trie TF keeps in host memory would be a pointer chase per candidate);
 // the emitted labels are recorded as (parent node, label) pairs in a per-utterance pool whose slot is a
 // pure function of (frame, rank), so there are no atomics and the result is deterministic.
@@ -57,23 +58,18 @@ template <int CTRL, int ROW_MASK, bool ZERO_INVALID>
 __device__ __forceinline__ int dpp_i32(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, ZERO_INVALID);
 }
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
-  int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-  unsigned long long o = ((unsigned long long)(unsigned)dpp_i32<CTRL, 0xf, false>(hi, hi) << 32) |
-                         (unsigned)dpp_i32<CTRL, 0xf, false>(lo, lo);          // invalid source lane -> own value
-  return o > v ? o : v;
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define ST_STEP(CTRL) v = max(v, (unsigned)dpp_i32<CTRL, 0xf, false>((int)v, (int)v))   /* invalid source lane -> own value */
+  ST_STEP(0x111); ST_STEP(0x112); ST_STEP(0x114); ST_STEP(0x118);   // row_shr 1, 2, 4, 8: lane 15 of a row = row maximum
+  ST_STEP(0x142); ST_STEP(0x143);                                   // row_bcast 15, 31: lane 63 = wave maximum
+#undef ST_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = dpp_max_u64<0x111>(v);   // row_shr:1
-  v = dpp_max_u64<0x112>(v);   // row_shr:2
-  v = dpp_max_u64<0x114>(v);   // row_shr:4
-  v = dpp_max_u64<0x118>(v);   // row_shr:8   -> lane 15 of every row holds the row maximum
-  v = dpp_max_u64<0x142>(v);   // row_bcast:15
-  v = dpp_max_u64<0x143>(v);   // row_bcast:31 -> lane 63 holds the wave maximum
-  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define ST_STEP(CTRL) v = min(v, (unsigned)dpp_i32<CTRL, 0xf, false>((int)v, (int)v))
+  ST_STEP(0x111); ST_STEP(0x112); ST_STEP(0x114); ST_STEP(0x118); ST_STEP(0x142); ST_STEP(0x143);
+#undef ST_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
 #define ST_STEP(CTRL) v = fmaxf(v, __int_as_float(dpp_i32<CTRL, 0xf, false>(__float_as_int(v), __float_as_int(v))))
@@ -89,17 +85,14 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// candidate key: larger total first, then smaller candidate index; unique per candidate
-__device__ __forceinline__ unsigned long long make_key(float v, int k) {
-  unsigned bits = (unsigned)__float_as_int(v);
-  unsigned ord = bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-  return ((unsigned long long)ord << 32) | (0xFFFFFFFFu - (unsigned)k);
+// monotone map float -> unsigned (larger float, larger integer) and back
+__device__ __forceinline__ unsigned order_bits(float v) {
+  const unsigned bits = (unsigned)__float_as_int(v);
+  return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
-constexpr unsigned kOrdNegInf = 0x007FFFFFu;      // make_key(-inf, .) >> 32
-__device__ __forceinline__ float key_value(unsigned long long key) {
-  unsigned ord = (unsigned)(key >> 32);
-  unsigned bits = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-  return __int_as_float((int)bits);
+constexpr unsigned kOrdNegInf = 0x007FFFFFu;      // order_bits(-inf)
+__device__ __forceinline__ float order_value(unsigned ord) {
+  return __int_as_float((int)(ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu)));
 }
 
 // CPL = candidates per lane (beam_width * C <= 64 * CPL)
@@ -187,13 +180,14 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       base_s[lane] = make_float2(tot, S.pb[lane]);
     }
     __syncthreads();
-    // (3) one key per candidate, in registers
-    unsigned long long key[CPL];
-    unsigned long long best = 0ull;
+    // (3) one sortable 32-bit score per candidate, in registers (candidate index k = lane + 64 j is implicit)
+    unsigned ord[CPL];
+    unsigned best_ord = 0u;                               // 0 is below every real candidate
+    int best_j = 0;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
+    for (int j = CPL - 1; j >= 0; --j) {                  // descending j + ">=": the lowest j wins a tie
       const int slot = cslot[j], c = ccls[j];
-      unsigned long long kj = 0ull;                       // below every real candidate
+      unsigned oj = 0u;
       if (slot < nb) {
         float v;
         if (c == blank) {
@@ -202,26 +196,34 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
           float2 base = base_s[slot];
           v = ((dead[slot] >> c) & 1u) ? -INFINITY : ((S.last[slot] == c) ? base.y : base.x) + lp_s[c];
         }
-        kj = make_key(v, lane + 64 * j);
+        oj = order_bits(v);
       }
-      key[j] = kj;
-      best = kj > best ? kj : best;
+      ord[j] = oj;
+      if (oj >= best_ord) { best_ord = oj; best_j = j; }
     }
-    // (4) up to W rounds of a wave arg-max; the winner's lane retires it and refreshes its local best
+    // (4) up to W rounds: wave maximum of the scores on the DPP network, the winner is the tied lane with the
+    // smallest candidate index (one lane almost always: ballot + find-first; a real tie takes a second
+    // reduction); only the winner's lane retires its candidate and refreshes its local best
     int n_new = 0;
     for (int r = 0; r < W; ++r) {
-      unsigned long long top = wave_max_u64(best);
-      if ((unsigned)(top >> 32) <= kOrdNegInf) break;      // nothing with non-zero probability left
-      const int k = (int)(0xFFFFFFFFu - (unsigned)top);
-      if (lane == 0) { sel_k[r] = k; sel_v[r] = key_value(top); }
+      const unsigned top = wave_max_u32(best_ord);
+      if (top <= kOrdNegInf) break;                        // nothing with non-zero probability left
+      const unsigned long long tied = __ballot(best_ord == top);
+      int owner = __builtin_ctzll(tied);
+      if (__builtin_popcountll(tied) > 1) {
+        const unsigned kmin = wave_min_u32(best_ord == top ? (unsigned)(lane + 64 * best_j) : 0xFFFFFFFFu);
+        owner = (int)(kmin & 63u);
+      }
+      const int jw = __builtin_amdgcn_readlane(best_j, owner);
+      if (lane == 0) { sel_k[r] = owner + 64 * jw; sel_v[r] = order_value(top); }
       n_new = r + 1;
-      if ((k & 63) == lane) {
-        const int jw = k >> 6;
-        best = 0ull;
+      if (lane == owner) {
+        best_ord = 0u;
+        best_j = 0;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          if (j == jw) key[j] = 0ull;
-          best = key[j] > best ? key[j] : best;
+        for (int j = CPL - 1; j >= 0; --j) {
+          if (j == jw) ord[j] = 0u;
+          if (ord[j] >= best_ord) { best_ord = ord[j]; best_j = j; }
         }
       }
     }

@@ -49,7 +49,6 @@ struct NNParams {
   int taps, cp;                      // filter width and channel pitch of A (k = tap * cp + channel)
   int tiles_m, tiles_n, chunk;       // XCD-aware tile order: 8 XCDs as a gm x gn grid over the tile grid,
   int gm, tm_per, tn_per;            // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per)
-  int debug;                         // ablation bits (ST_GEMM_DEBUG env, perf experiments only)
   int splits, steps_per_split;       // split-K over blockIdx.y: raw partial tiles go to `slab`
   float* slab;                       // [splits][M][Np]
 };
@@ -168,12 +167,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     if (pc < A_DMA) {
       // reduction tail: clamp so the read stays inside the row span (values there are unused)
       const float* g = asrc[pc < A_DMA ? pc : 0] + min(k0 + aslot4[pc < A_DMA ? pc : 0], ktail);
-      if (p.debug & 32) g = p.A + lane * 4;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + pc) * 256), 16, 0, 0);
     } else {
       const int i = pc - A_DMA;
       const int krow = min(k0 + (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR, kplast);
-      __builtin_amdgcn_global_load_lds((gptr_t)((p.debug & 32) ? p.Bm + lane * 4 : bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
                                        (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
     }
   };
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     // next tile
     int ntap = tap, nchunk = chunk;
     if (tap_inner) { if (++ntap == p.taps) { ntap = 0; ++nchunk; } } else { ++nchunk; }
-    const bool more = kt + 1 < nk && !(p.debug & 1);
+    const bool more = kt + 1 < nk;
     const int nk0 = tile_k0(ntap, nchunk);
     tap = ntap; chunk = nchunk;
     const float* as = As + cur * A_SZ;
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(p.debug & 4)) __syncthreads();     // also drains this wave's DMA (vmcnt) before anyone reads it
-    if (!(p.debug & 1)) cur ^= 1;
+    __syncthreads();                         // also drains this wave's DMA (vmcnt) before anyone reads it
+    cur ^= 1;
   }
 
   // epilogue: C/D layout of 32x32 MFMA: tile column = lane&31 (-> output column NT*l31 + nt),
@@ -352,7 +350,6 @@ struct TNParams {
   int tiles_k, tiles_n;
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
-  int debug;
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
@@ -485,8 +482,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   const int a_frag = (4 * h) * BKO + wk * WTK + MT * l31;
   const int z_frag = (4 * h) * BN + wn * WTN + NT * l31;
   for (int st = 0; st < nstages; ++st) {
-    const int cur = (p.debug & 1) ? 0 : (st & 1);
-    const bool more = st + 1 < nstages && !(p.debug & 1);
+    const int cur = st & 1;
+    const bool more = st + 1 < nstages;
     const int mb_next = m_begin + (st + 1) * BMR;
     const float* as = As + cur * A_SZ + a_frag;
     const float* zs = Zs + cur * Z_SZ + z_frag;
@@ -516,7 +513,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
     }
     if (more) stage_advance();
     dma_wait_all();
-    if (!(p.debug & 4)) __syncthreads();
+    __syncthreads();
   }
 
   float* out = p.out + (long)split * p.Kp * p.Np;
@@ -724,7 +721,6 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.tn_per = st::ceil_div(p.tiles_n, 8 / p.gm);
     p.chunk = p.tm_per * p.tn_per;
   }
-  if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1>), grid, block, 0, s, p);
@@ -977,7 +973,6 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   p.amap_batches = dz->batch;
   p.adv_b = 32 / dz->frames;
   p.adv_t = 32 % dz->frames;
-  if (const char* e = getenv("ST_GEMM_DEBUG")) p.debug = atoi(e);
   if (p.Np % 128 == 0) {
     p.tiles_n = p.Np / 128;
     hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);

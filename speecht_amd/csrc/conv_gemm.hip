@@ -92,7 +92,9 @@ template <> __device__ __forceinline__ float vget<1>(const float& v, int) { retu
 template <int N> __device__ __forceinline__ void vset(typename FVec<N>::type& v, int i, float x) { v[i] = x; }
 template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
 
-template <int BM, int BN, int WMW, int WNW, int EPI>
+// FAST: every k-tile is whole (channel pitch and reduction length multiples of 32), so the DMA source of a
+// piece is a per-lane pointer plus the uniform k0 -- no clamps, one 64-bit add per piece.
+template <int BM, int BN, int WMW, int WNW, int EPI, bool FAST = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   constexpr bool SGB = true;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
@@ -163,16 +165,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // (The scalar-base inline-asm DMA of the filter-gradient kernel measured SLOWER here, 123 vs 128
   // TF/s: the per-piece address math is already only a min + 64-bit add, and the asm statements
   // block hipcc's own interleave.)
+  const float* aptr[A_DMA];
+  const float* bptr[B_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) aptr[i] = asrc[i] + aslot4[i];
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i) bptr[i] = bsrc[i] + (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.Np;
   auto dma_piece = [&](int pc, int k0, int buf) {
     if (pc < A_DMA) {
+      const int i = pc < A_DMA ? pc : 0;
       // reduction tail: clamp so the read stays inside the row span (values there are unused)
-      const float* g = asrc[pc < A_DMA ? pc : 0] + min(k0 + aslot4[pc < A_DMA ? pc : 0], ktail);
+      const float* g = FAST ? aptr[i] + k0 : asrc[i] + min(k0 + aslot4[i], ktail);
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SZ + (wave * A_DMA + pc) * 256), 16, 0, 0);
     } else {
-      const int i = pc - A_DMA;
+      const int i = pc - A_DMA < B_DMA ? pc - A_DMA : 0;
       const int krow = min(k0 + (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR, kplast);
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i < B_DMA ? i : 0] + (long)krow * p.Np),
-                                       (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
+      const float* g = FAST ? bptr[i] + (long)k0 * p.Np : bsrc[i] + (long)krow * p.Np;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
     }
   };
   auto dma = [&](int k0, int buf) {
@@ -697,7 +706,7 @@ int nn_splits(int M, int Np, int Kp) {
   return splits;
 }
 
-template <int BM, int BN, int WMW, int WNW>
+template <int BM, int BN, int WMW, int WNW, bool FAST = false>
 void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.tiles_m = st::ceil_div(p.M, BM);
   p.tiles_n = p.Np / BN;
@@ -722,8 +731,8 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.chunk = p.tm_per * p.tn_per;
   }
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
-  if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1>), grid, block, 0, s, p);
+  if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
   if (p.splits > 1) {
     const int rows_per_block = std::max(1, 256 / (p.n_store / 4));
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(st::ceil_div(p.M, rows_per_block)), dim3(256), 0, s, p, epi);
@@ -737,6 +746,8 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
+    else if ((tiles128 >= 192 || p.splits > 1) && p.cp % 32 == 0 && p.Kvalid % 32 == 0 && !getenv("ST_NO_FAST"))
+      launch_nn<128, 128, 2, 2, true>(p, epi, s);                                      // whole k-tiles only: unclamped DMA addresses
     else if (tiles128 >= 192 || p.splits > 1) launch_nn<128, 128, 2, 2>(p, epi, s);   // >= 3/4 of the CUs busy
     else launch_nn<64, 128, 2, 2>(p, epi, s);
   } else if (p.Np == 64) {

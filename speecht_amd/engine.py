@@ -25,6 +25,13 @@ def _round_up(a, b):
   return (a + b - 1) // b * b
 
 
+def channel_pitch(channels):
+  """Channel pitch of a padded NWC tensor: a multiple of 16 floats (the kernels' requirement); wide tensors
+  round to 32 so that every 32-deep k-tile of the convolutions is whole (2000 -> 2016: the GEMM kernels then
+  take their unclamped-address variant), narrow ones (80-mel input, 29 logits) keep the cheaper multiple of 16."""
+  return _round_up(channels, 32 if channels > 128 else 16)
+
+
 def same_padding(t_in, width, stride):
   """tf.nn.conv1d 'SAME' (speech_model.py:155): extra zero goes to the right."""
   t_out = -(-t_in // stride)
@@ -38,14 +45,14 @@ class DevTensor3:
   def __init__(self, storage, batch, frames, channels, halo_l, halo_r):
     self.batch, self.frames, self.channels = batch, frames, channels
     self.halo = halo_l
-    self.c_pitch = _round_up(channels, 16)
+    self.c_pitch = channel_pitch(channels)
     self.t_pitch = halo_l + frames + halo_r
     self.buf = storage[:batch * self.t_pitch * self.c_pitch]
     self.desc = Tensor3(self.buf.data_ptr(), batch, frames, channels, halo_l, self.t_pitch, self.c_pitch)
 
   @staticmethod
   def numel(batch, frames, channels, halo_l, halo_r):
-    return batch * (halo_l + frames + halo_r) * _round_up(channels, 16)
+    return batch * (halo_l + frames + halo_r) * channel_pitch(channels)
 
   @property
   def ref(self):
@@ -80,8 +87,8 @@ class _Storage:
 class LayerSpec:
   def __init__(self, width, stride, cin, cout, relu):
     self.width, self.stride, self.cin, self.cout, self.relu = width, stride, cin, cout, relu
-    self.cin_pitch = _round_up(cin, 16)
-    self.cout_pitch = _round_up(cout, 16)
+    self.cin_pitch = channel_pitch(cin)
+    self.cout_pitch = channel_pitch(cout)
     kv, kp, npad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     call('st_packed_dims', width, self.cin_pitch, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
     self.k_valid, self.k_pad, self.n_pad = kv.value, kp.value, npad.value

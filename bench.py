@@ -53,17 +53,18 @@ def train_step(eng, x_dev, reducer, lr, global_batch):
   eng.apply_update(lr)
 
 
-DOMINANT = 'gemm_nn_kernel<128,128,2,2,0>'
+DOMINANT = 'gemm_nn_kernel<128,128,2,2,0,true>'
 
 
 def measure_dominant_kernel(eng, batch, reps=10):
-  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0>: the forward
-  convolution of every layer whose packed width is a multiple of 128 (L0..L9 = 99.8 % of the forward
-  MACs; 10 launches per step, the same launches rocprofv3 --stats averages).  Events are recorded on
+  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0,true>: the forward
+  convolution of every layer whose packed width is a multiple of 128 and whose k-tiles are all whole
+  (L1..L9 = 95.8 % of the forward MACs; 9 launches per step, the same launches rocprofv3 --stats averages;
+  L0's 80-channel input takes the clamped-address variant of the same kernel).  Events are recorded on
   the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
   from speecht_amd._lib import call
   flops = conv_flops(eng, batch)
-  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0]
+  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0 and l.cin_pitch % 32 == 0]
   if not wide:
     return None
   s = eng.stream_ptr

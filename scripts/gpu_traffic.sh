@@ -17,11 +17,11 @@ root = os.environ['GRAFT_REPO_ROOT']
 vals = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(os.path.join(root, 'gpurun_out/traffic', c, '**', '*counter_collection.csv'), recursive=True)
-    rows = [r for r in csv.DictReader(open(f[0])) if 'gemm_nn_kernel<128, 128, 2, 2, 0>' in r['Kernel_Name'] and r['Counter_Name'] == c]
+    rows = [r for r in csv.DictReader(open(f[0])) if 'gemm_nn_kernel<128, 128, 2, 2, 0, true>' in r['Kernel_Name'] and r['Counter_Name'] == c]
     vals[c] = (sum(float(r['Counter_Value']) for r in rows) / len(rows), len(rows))
 fetch = vals['FETCH_SIZE'][0] * 1024 * 2      # gfx950 correction (MI355X_MICROARCH.md, HBM section)
 write = vals['WRITE_SIZE'][0] * 1024
-out = dict(kernel='gemm_nn_kernel<128,128,2,2,0>', launches=vals['FETCH_SIZE'][1],
+out = dict(kernel='gemm_nn_kernel<128,128,2,2,0,true>', launches=vals['FETCH_SIZE'][1],
            fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, bytes_per_launch=fetch + write,
            note='FETCH_SIZE x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE x 1024, averaged over all launches of the symbol')
 json.dump(out, open(os.path.join(root, 'gpurun_out/traffic/traffic.json'), 'w'), indent=1)

@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "st_common.h"
 
 namespace {
@@ -228,17 +230,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   dma(tile_k0(tap, chunk), 0);
   __syncthreads();
 
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int nq = tile_nq(tap, chunk);
+  // One k-tile.  CUR (LDS slot) and MORE (is there a next tile to stage) are compile-time: in the FAST
+  // variant the steady-state loop below is then one basic block per pair of tiles -- no uniform branches
+  // cutting hipcc's MFMA / ds_read / DMA interleave, LDS addresses folded into instruction offsets.
+  auto stage = [&](auto cur_c, auto more_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr bool MORE = decltype(more_c)::value;
+    const int nq = FAST ? 4 : tile_nq(tap, chunk);
     // next tile
     int ntap = tap, nchunk = chunk;
     if (tap_inner) { if (++ntap == p.taps) { ntap = 0; ++nchunk; } } else { ++nchunk; }
-    const bool more = kt + 1 < nk;
     const int nk0 = tile_k0(ntap, nchunk);
     tap = ntap; chunk = nchunk;
-    const float* as = As + cur * A_SZ;
-    const float* bs = Bs + cur * B_SZ + b_frag;
+    const float* as = As + CUR * A_SZ;
+    const float* bs = Bs + CUR * B_SZ + b_frag;
     // Software-pipelined fragment reads: the reads of k-quad q+1 are issued BEFORE the 16 MFMAs of
     // quad q (sched_barrier pins the order; hipcc otherwise sinks the reads behind the MFMAs to
     // save registers and then stalls on LDS latency four times per tile).
@@ -257,9 +262,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
       // instructions stalls the wave's issue long enough to drain the matrix pipe, two (~60 cycles
       // each) hide in the shadow of the MFMAs in flight.  (One per 4 MFMAs with more sched_barriers
       // measured slower: the pinning then also blocks hipcc's own ds_read/MFMA interleave.)
-      if (more) {
+      if (MORE) {
 #pragma unroll
-        for (int pc = q; pc < N_DMA; pc += 4) dma_piece(pc, nk0, cur ^ 1);
+        for (int pc = q; pc < N_DMA; pc += 4) dma_piece(pc, nk0, CUR ^ 1);
       }
       if (q < 3) read_frags(q + 1);
       if (q < nq) {
@@ -290,7 +295,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                         // also drains this wave's DMA (vmcnt) before anyone reads it
-    cur ^= 1;
+  };
+  using std::integral_constant;
+  using std::true_type;
+  using std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {             // steady state: both tiles have a successor
+    stage(integral_constant<int, 0>{}, true_type{});
+    stage(integral_constant<int, 1>{}, true_type{});
+  }
+  if (kt + 2 == nk) {
+    stage(integral_constant<int, 0>{}, true_type{});
+    stage(integral_constant<int, 1>{}, false_type{});
+  } else if (kt + 1 == nk) {
+    stage(integral_constant<int, 0>{}, false_type{});
   }
 
   // epilogue: C/D layout of 32x32 MFMA: tile column = lane&31 (-> output column NT*l31 + nt),

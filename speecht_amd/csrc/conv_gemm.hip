@@ -537,7 +537,6 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
       if constexpr (MODE == 2) issue_slice(q, mb_next, CUR ^ 1, std::true_type{});
       if constexpr (MODE == 1) issue_slice(q, mb_next, CUR ^ 1, std::false_type{});
       if (q < 3) read_frags(q + 1);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -545,6 +544,13 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<MT>(af[q][j], i), vget<NT>(zf[q][j], n), acc[i][n], 0, 0, 0);
+      // interleave request: one fragment read behind each of the first eight MFMAs of the quad
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MODE >= 1) stage_advance();

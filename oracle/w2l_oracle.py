@@ -348,6 +348,8 @@ def ctc_loss_and_grad(logits_tm, labels, seq_lens):
     if L + repeats > Tb:
       raise ValueError('Not enough time for target transition sequence '
                        '(required: {}, available: {})'.format(L + repeats, Tb))
+    if Tb == 0:                                       # no frames: only the empty labelling is possible, p = 1
+      continue
     U = 2 * L + 1
     ext = np.full(U, blank, dtype=np.int64)
     ext[1::2] = lab

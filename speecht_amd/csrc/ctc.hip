@@ -129,12 +129,13 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
   int rep = 0;
   for (int i = 1 + lane; i < L; i += 64) rep += lab[i] == lab[i - 1];
   rep = (int)st::wave_sum((float)rep);
-  const bool bad = Tb < 1 || Tb > T || L + rep > Tb || U > UP;
+  const bool bad = Tb < 0 || Tb > T || L + rep > Tb || U > UP;
   if (bad) {
     if (!is_beta && lane == 0) status[b] = 1;
     return;
   }
   if (!is_beta && lane == 0) status[b] = 0;
+  if (Tb == 0) return;      // no frames and (checked above) an empty label: p = 1, nothing to recurse over
 
   int coff[KPL];          // class column of each state (LDS float offset inside an emission row)
   bool valid[KPL], skip[KPL];
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   }
   __syncthreads();
 
-  double logp2 = 0.0;   // log2 p(l|x)
-  if (!bad) {
+  double logp2 = 0.0;   // log2 p(l|x); stays 0 (p = 1) for an utterance without frames
+  if (!bad && Tb > 0) {
     const float* al = alpha + ((long)b * T + (Tb - 1)) * UP;
     logp2 = aoff[(long)b * T + Tb - 1] + (double)lse2_b2(al[sidx(U - 1)], U > 1 ? al[sidx(U - 2)] : NEG_INF);
   }

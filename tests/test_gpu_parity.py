@@ -409,3 +409,36 @@ def test_bucketed_inference_matches_oracle_per_bucket(dev):
     ref_ids, _ = O.ctc_greedy_decode(O.wav2letter_forward(x, params, layers), seq // 2)
     assert [ids[i] for i in idx] == ref_ids
   assert text[0] == O.ids_to_sentence(ids[0])
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x6'])
+@pytest.mark.parametrize('frames', [[1], [7, 3, 5], [48, 47, 2, 31, 96]])
+def test_odd_shapes_mfcc_width(dev, mode, frames):
+  """39-feature (MFCC) input, channel counts that are not multiples of 16, utterances shorter than the
+  filters (1 frame: everything but one tap is padding), B = 1: logits, loss and every gradient against the
+  oracle.  Labels are kept short enough for T' = ceil(T/2) // ... frames (empty where nothing fits)."""
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(39, width=24, fc=40)
+  params = WL.xavier_params(layers, seed=3)
+  rng = np.random.default_rng(len(frames))
+  T = max(frames)
+  x = np.zeros((len(frames), T, 39))
+  for b, t in enumerate(frames):
+    x[b, :t] = rng.standard_normal((t, 39))
+  labels = [list(rng.integers(0, 28, max(0, (t // 2) // 3))) for t in frames]
+  eng = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
+  eng.set_weights(params)
+  eng.load_batch(x, frames)
+  eng.set_labels(labels)
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / len(frames))
+  eng.backward()
+  eng.check_ctc_status()
+  ref = O.train_step(x, np.asarray(frames), labels, params, layers, None, update=False)
+  logits = eng.logits_time_major().cpu().numpy()
+  assert logits.shape == ref['logits'].shape
+  assert np.max(np.abs(logits - ref['logits'])) < 1e-4
+  np.testing.assert_allclose(eng.loss.cpu().numpy(), ref['loss'], rtol=1e-4, atol=1e-5)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref['grads'])):
+    assert rel_err(gF, rF) < 3e-4 or np.max(np.abs(rF)) < 1e-12, i
+    assert rel_err(gb, rb) < 3e-4 or np.max(np.abs(rb)) < 1e-12, i

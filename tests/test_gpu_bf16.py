@@ -220,3 +220,32 @@ def test_training_reduces_loss_like_fp32(dev, mode):
   assert ref[-1] < 0.7 * ref[0] and got[-1] < 0.7 * got[0]
   tol = 3e-2 if mode == 'bf16' else 1e-3
   assert abs(got[0] - ref[0]) <= tol * ref[0] and abs(got[-1] - ref[-1]) <= tol * ref[-1], (ref[[0, -1]], got[[0, -1]])
+
+
+@pytest.mark.parametrize('frames', [[1], [7, 3, 5], [48, 47, 2, 31, 96]])
+def test_odd_shapes_bf16(dev, frames):
+  """39-feature input, channel counts that are not multiples of 16, utterances shorter than the filters, B = 1
+  in the bf16-activation mode, against the oracle's bf16 storage model."""
+  layers = WL.w2l_layers(39, width=24, fc=40)
+  params = WL.xavier_params(layers, seed=3)
+  rng = np.random.default_rng(len(frames))
+  x = np.zeros((len(frames), max(frames), 39))
+  for b, t in enumerate(frames):
+    x[b, :t] = rng.standard_normal((t, 39))
+  labels = [list(rng.integers(0, 28, max(0, (t // 2) // 3))) for t in frames]
+  eng = engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, frames)
+  eng.set_labels(labels)
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / len(frames))
+  eng.backward()
+  eng.check_ctc_status()
+  ref = O.train_step(x, np.asarray(frames), labels, params, layers, None, update=False, store=O.bf16_round)
+  mx, mean = scaled_err(eng.logits_time_major().cpu().numpy(), ref['logits'])
+  assert mx < 8 * ULP and mean < 0.5 * ULP, (mx, mean)
+  np.testing.assert_allclose(eng.loss.cpu().numpy(), ref['loss'], rtol=5e-3, atol=1e-4)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref['grads'])):
+    if np.max(np.abs(rF)) > 1e-12:
+      assert scaled_err(gF, rF)[0] < 16 * ULP, i
+      assert scaled_err(gb, rb)[0] < 16 * ULP, i

@@ -5,7 +5,7 @@ arithmetic op of the path is a call into libspeecht_hip.so through ``_lib`` (no 
 
 HBM layout (DESIGN.md "Data layout"):
   * activations X[i] / gradients dZ[i]: padded NWC ``st_tensor3`` buffers, zero halos sized for
-    the consuming convolution, channel pitch rounded to 16 floats;
+    the consuming convolution, channel pitch rounded to 16 floats (32 for wide tensors, ``channel_pitch``);
   * parameters, gradients, Adam m/v: four flat fp32 buffers with identical layout
     [F0 | b0 | F1 | b1 | ...], filters in the packed GEMM layout [k_pad][n_pad] -- so the
     gradient all-reduce and clip+Adam each see one contiguous buffer.

@@ -336,13 +336,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   for (int n = 0; n < NT; ++n) vset<NT>(bv, n, (EPI == 0 && p.bias && col_ok) ? p.bias[col0 + n] : 0.f);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    // Back-prop: gather the ReLU mask of the 16 rows first, branch-free (m_off is valid for every tile row).
+    // Loads interleaved with the stores below are serialised by the compiler -- for all it knows the output
+    // aliases the mask source -- and each then exposes a full memory latency.
+    bvec mk[16];
+    if (EPI == 1 && p.mask) {
+      const int colc = col_ok ? col0 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        mk[r] = *reinterpret_cast<const bvec*>(p.mask + m_off[row] + colc);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const long co = c_off[row];
       if (co >= 0 && col_ok) {
-        bvec out, mk;
-        if (EPI == 1 && p.mask) mk = *reinterpret_cast<const bvec*>(p.mask + m_off[row] + col0);
+        bvec out;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           float v = acc[i][n][r];
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
             v += vget<NT>(bv, n);
             if (p.relu) v = fmaxf(v, 0.f);
           } else if (p.mask) {
-            v = vget<NT>(mk, n) > 0.f ? v : 0.f;
+            v = vget<NT>(mk[r], n) > 0.f ? v : 0.f;
           }
           vset<NT>(out, n, v);
         }

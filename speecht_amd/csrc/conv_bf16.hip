@@ -201,7 +201,9 @@ struct X6Params {
 // while one group feeds the matrix pipe the other reads its fragments of the next stage from LDS and issues
 // DMA, two barriers per stage.  Without it all waves leave the stage barrier together, burst-read LDS, and the
 // matrix pipe idles for the whole burst.
-template <int BT, int WM, int WN, int BK, int NP, int ST = 2, bool PP = false>
+// FAST = every reduction stage is whole (channel pitch / reduction length a multiple of BK): DMA sources are a
+// per-lane pointer plus the uniform k0 (no clamps) and every stage runs all its MFMA k-steps (no tail test).
+template <int BT, int WM, int WN, int BK, int NP, int ST = 2, bool PP = false, bool FAST = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) {
   constexpr int NW = WM * WN;
   constexpr int BM = BT, BN = BT;
@@ -258,13 +260,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   }
   const int ktail = p.Kvalid - 8;
   constexpr int N_DMA = 2 * NP * PPW;
+  const __bf16* aptr[NP][PPW];
+  const __bf16* bptr[NP][PPW];
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      aptr[pl][i] = asrc[i] + pl * p.a_plane + slot8[i];
+      bptr[pl][i] = bsrc[i] + pl * p.b_plane + slot8[i];
+    }
   auto dma_piece = [&](int pc, int k0, int buf) {        // pc -> (operand, plane, i)
     const int op = pc / (NP * PPW), pl = (pc / PPW) % NP, i = pc % PPW;
     if (op == 0) {
-      const __bf16* g = asrc[i] + pl * p.a_plane + min(k0 + slot8[i], ktail);
+      const __bf16* g = FAST ? aptr[pl][i] + k0 : asrc[i] + pl * p.a_plane + min(k0 + slot8[i], ktail);
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (buf * NP + pl) * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
     } else {
-      const __bf16* g = bsrc[i] + pl * p.b_plane + min(k0 + slot8[i], p.Kp - 8);
+      const __bf16* g = FAST ? bptr[pl][i] + k0 : bsrc[i] + pl * p.b_plane + min(k0 + slot8[i], p.Kp - 8);
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (buf * NP + pl) * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
     }
   };
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     };
     if (grp == 1) phase_barrier();                   // group 1 runs one phase behind
     for (int kt = 0; kt < nk; ++kt) {
-      const int nks = tile_ks(tap, chunk);
+      const int nks = FAST ? KS : tile_ks(tap, chunk);
       advance(tap, chunk);
       const bool more = kt + ST - 1 < nk;
       const int nk0 = tile_k0(itap, ichunk);
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     if (grp == 0) phase_barrier();                   // every wave executes the same number of barriers
   } else {
   for (int kt = 0; kt < nk; ++kt) {
-    const int nks = tile_ks(tap, chunk);
+    const int nks = FAST ? KS : tile_ks(tap, chunk);
     advance(tap, chunk);
     const bool more = kt + ST - 1 < nk;
     const int nk0 = tile_k0(itap, ichunk);
@@ -591,13 +602,20 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   p.tiles_n = st::ceil_div(p.Np, BT);
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
+  const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
+#define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
+  do {                                                                                                         \
+    if (whole(K)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, true>), grid, dim3(64 * W1 * W2), 0, s, p);   \
+    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, false>), grid, dim3(64 * W1 * W2), 0, s, p);          \
+  } while (0)
   if constexpr (NP == 3) {
-    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 16, 3, 3, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 32, 3, 2>), grid, dim3(256), 0, s, p);
+    if (BT == 256) ST_LAUNCH(256, 2, 4, 16, 3, 3, true);
+    else ST_LAUNCH(128, 2, 2, 32, 3, 2, false);
   } else {
-    if (BT == 256) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 4, 32, 1, 4, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<128, 2, 2, 64, 1, 4>), grid, dim3(256), 0, s, p);
+    if (BT == 256) ST_LAUNCH(256, 2, 4, 32, 1, 4, true);
+    else ST_LAUNCH(128, 2, 2, 64, 1, 4, false);
   }
+#undef ST_LAUNCH
   return st::check_launch("gemm_nn_bf16");
 }
 

@@ -408,11 +408,13 @@ class Wav2LetterEngine:
     return self.X[-1].interior().permute(1, 0, 2)
 
   def set_labels(self, label_list):
-    ids = np.fromiter((v for l in label_list for v in l), dtype=np.int32)
+    lens = [len(l) for l in label_list]
     offs = np.zeros(len(label_list) + 1, dtype=np.int32)
-    offs[1:] = np.cumsum([len(l) for l in label_list])
-    self.max_label_len = int(max([len(l) for l in label_list] + [0]))
-    self.label_ids = torch.as_tensor(np.concatenate([ids, np.zeros(1, np.int32)])).to(self.device, non_blocking=True)
+    offs[1:] = np.cumsum(lens)
+    self.max_label_len = int(max(lens + [0]))
+    # CSR ids (+1 pad entry so that the buffer is never empty); array-per-utterance inputs stay in numpy
+    ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
+    self.label_ids = torch.as_tensor(ids).to(self.device, non_blocking=True)
     self.label_offs = torch.as_tensor(offs).to(self.device, non_blocking=True)
 
   def ctc_loss_grad(self, grad_scale):

@@ -97,11 +97,17 @@ class BaseInputLoader:
 
 
 def sparse_to_label_lists(labels):
-  """SparseTensorValue -> list of per-utterance id lists (row-major indices)."""
-  out = [[] for _ in range(int(labels.dense_shape[0]))]
-  for (b, _), v in zip(labels.indices, labels.values):
-    out[int(b)].append(int(v))
-  return out
+  """SparseTensorValue -> one int array of label ids per utterance (vectorised: a batch of 32 ten-second
+  utterances carries ~5 000 label entries and this runs on the critical path of every step)."""
+  batch = int(labels.dense_shape[0])
+  indices = np.asarray(labels.indices).reshape(-1, 2)
+  values = np.asarray(labels.values)
+  rows, pos = indices[:, 0], indices[:, 1]
+  if rows.size and (np.any(np.diff(rows) < 0) or np.any((np.diff(rows) == 0) & (np.diff(pos) < 0))):
+    order = np.lexsort((pos, rows))                  # canonical row-major order
+    rows, values = rows[order], values[order]
+  counts = np.bincount(rows.astype(np.int64), minlength=batch)[:batch] if rows.size else np.zeros(batch, np.int64)
+  return np.split(values, np.cumsum(counts)[:-1]) if batch else []
 
 
 class SingleInputLoader(BaseInputLoader):

@@ -28,7 +28,11 @@ def test_batch_and_label_layout_matches_oracle():
   np.testing.assert_array_equal(sp.indices, idx)
   np.testing.assert_array_equal(sp.values, vals)
   np.testing.assert_array_equal(sp.dense_shape, shape)       # dense_shape uses the INPUT max_time
-  assert sparse_to_label_lists(sp) == labels
+  assert [a.tolist() for a in sparse_to_label_lists(sp)] == labels
+  # unsorted sparse entries are brought to row-major order first
+  perm = np.random.default_rng(0).permutation(len(sp.values))
+  shuffled = type(sp)(sp.indices[perm], sp.values[perm], sp.dense_shape)
+  assert [a.tolist() for a in sparse_to_label_lists(shuffled)] == labels
 
 
 def test_input_batch_loader_drops_partial_batch_and_signals_end():

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   __shared__ int parent_of[kMaxBeam];
   __shared__ unsigned dead[kMaxBeam];
   __shared__ int sel_k[kMaxBeam];
+  __shared__ unsigned long long surv[64];         // compacted survivor keys of the fast selection
   __shared__ float sel_v[kMaxBeam];
 
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -201,11 +202,52 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       ord[j] = oj;
       if (oj >= best_ord) { best_ord = oj; best_j = j; }
     }
-    // (4) up to W rounds: wave maximum of the scores on the DPP network, the winner is the tied lane with the
-    // smallest candidate index (one lane almost always: ballot + find-first; a real tie takes a second
-    // reduction); only the winner's lane retires its candidate and refreshes its local best
+    // (4) selection of the W best candidates, best first.
+    // Fast path (threshold + rank): the W-th largest LANE maximum is a lower bound of the W-th largest
+    // candidate, so only candidates at or above it ("survivors", a few dozen at most in practice) can be
+    // selected; they are compacted into LDS in candidate order and every survivor finds its rank by counting the
+    // survivors ahead of it (keys are unique: score, then smaller candidate index).  All of it is wave-parallel;
+    // the sequential rounds below remain as the fallback for more than 64 survivors (flat posteriors, wide beams).
     int n_new = 0;
-    for (int r = 0; r < W; ++r) {
+    bool selected = false;
+    if (CPL <= 16) {
+      int ahead = 0;                                      // lanes whose maximum precedes mine (ties: lower lane)
+#pragma unroll 16
+      for (int i = 0; i < 64; ++i) {
+        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)best_ord, i);
+        ahead += (o > best_ord) || (o == best_ord && i < lane);
+      }
+      const int live_lanes = __builtin_popcountll(__ballot(best_ord > kOrdNegInf));
+      unsigned thr = kOrdNegInf + 1u;                     // fewer than W live lanes: every live candidate survives
+      if (live_lanes >= W) thr = (unsigned)__builtin_amdgcn_readlane((int)best_ord, __builtin_ctzll(__ballot(ahead == W - 1)));
+      int base = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {                     // compaction in candidate order k = lane + 64 j
+        const bool keep = ord[j] >= thr && ord[j] > kOrdNegInf;
+        const unsigned long long m = __ballot(keep);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep && pos < 64) surv[pos] = ((unsigned long long)ord[j] << 32) | (0xFFFFFFFFu - (unsigned)(lane + 64 * j));
+        base += __builtin_popcountll(m);
+      }
+      if (base <= 64) {
+        selected = true;
+        n_new = min(base, W);
+        __syncthreads();
+        if (lane < base) {
+          const unsigned long long mine = surv[lane];
+          int rank = 0;
+          for (int t2 = 0; t2 < base; ++t2) rank += surv[t2] > mine;
+          if (rank < W) {
+            sel_k[rank] = (int)(0xFFFFFFFFu - (unsigned)mine);
+            sel_v[rank] = order_value((unsigned)(mine >> 32));
+          }
+        }
+      }
+    }
+    // Fallback: up to W rounds -- wave maximum of the scores on the DPP network, the winner is the tied lane
+    // with the smallest candidate index (one lane almost always: ballot + find-first; a real tie takes a second
+    // reduction); only the winner's lane retires its candidate and refreshes its local best
+    for (int r = 0; !selected && r < W; ++r) {
       const unsigned top = wave_max_u32(best_ord);
       if (top <= kOrdNegInf) break;                        // nothing with non-zero probability left
       const unsigned long long tied = __ballot(best_ord == top);

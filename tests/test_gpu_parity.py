@@ -222,6 +222,25 @@ def test_beam_search_long_form(dev):
   np.testing.assert_allclose(logp, ref_logp, rtol=1e-5)
 
 
+def test_beam_search_massive_ties(dev):
+  """All-equal logits: hundreds of candidates tie exactly, more than the 64 survivors the wave-parallel
+  selection holds, so the sequential rounds take over.  Exact ties are ordered by candidate index, which makes
+  the result well defined: deterministic across runs and equal to the oracle's (whose float64 sums tie too)."""
+  T, B, C = 40, 2, 29
+  logits = np.zeros((T, B, C), dtype=np.float32)
+  lens = np.array([40, 17])
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits, (1, 0, 2))))
+  eng.ctc_lens = torch.as_tensor(lens.astype(np.int32)).to(dev)
+  ids1, logp1 = eng.beam_search_decode(16)
+  ids2, logp2 = eng.beam_search_decode(16)
+  assert ids1 == ids2 and np.array_equal(logp1, logp2)
+  assert all(0 <= v < 28 for seq in ids1 for v in seq) and len(ids1[0]) <= 40 and len(ids1[1]) <= 17
+  ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, 16)
+  np.testing.assert_allclose(logp1, ref_logp, rtol=1e-5)
+
+
 def test_beam_search_rejects_bad_arguments(dev):
   eng = make_engine([(1, 1, 16, 29, False)], dev)
   eng.load_batch(np.zeros((2, 9, 16)), [9, 9])

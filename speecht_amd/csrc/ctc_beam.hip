@@ -8,8 +8,9 @@
 // parallel axis).  Everything that lives across frames -- the beam entries -- sits in LDS, double
 // buffered; a frame is: log-softmax of the 29 logits (wave reduce), parent matching (W^2 hash compares
 // spread over the lanes), one sortable 32-bit score per candidate (W*C of them, lane-strided, in registers),
-// and W rounds of a wave-wide maximum on the DPP network (ballot + find-first names the winner) where only the
-// winning lane refreshes its local best.  Prefix identity is a
+// and a wave-parallel selection of the W best: the W-th largest lane maximum bounds the W-th largest
+// candidate from below, the few candidates at or above it are compacted into LDS and ranked by counting
+// (sequential maximum rounds remain for the rare case of more than 64 survivors).  Prefix identity is a
 // 64-bit mixed hash + length (the trie TF keeps in host memory would be a pointer chase per candidate);
 // the emitted labels are recorded as (parent node, label) pairs in a per-utterance pool whose slot is a
 // pure function of (frame, rank), so there are no atomics and the result is deterministic.

@@ -330,6 +330,22 @@ def test_full_width_forward_logits(dev):
   assert ids == ref_ids
 
 
+def test_full_width_forward_logits_128_mel(dev):
+  """The reference's default feature width (n_mels = 128, speecht-cli:53): L0 then has a 128-channel input,
+  whose k-tiles are all whole (the unclamped-address kernel variant), unlike the 80-mel benchmark model."""
+  layers = WL.w2l_layers(128)
+  params = WL.xavier_params(layers, seed=11)
+  x, seq_lens, _ = WL.make_batch([150, 97], 128, seed=5)
+  eng = make_engine(layers, dev)
+  eng.set_weights(params)
+  eng.load_batch(x, seq_lens)
+  eng.forward()
+  logits = eng.logits_time_major().cpu().numpy()
+  ref = O.wav2letter_forward(x, params, layers)
+  assert logits.shape == ref.shape == (75, 2, 29)
+  assert np.max(np.abs(logits - ref)) < 1e-4
+
+
 @pytest.mark.parametrize('n_mels,sr', [(80, 16000), (128, 22050)])
 def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
   """calc_power_spectrogram (preprocessing.py:36-58): ragged batch, odd lengths; the features are

@@ -121,9 +121,8 @@ class SpeechCorpusReader:
   utterance with ``audio_fragments [T, n_feat]`` and ``transcript [L]`` under
   ``<data>/preprocessed[-power]/<split>/`` (preprocessing.py:175-178, 199-206, 243-279).
 
-  Real-audio ingest (FLAC decoding + librosa's 22 050 Hz resampling, preprocessing.py:169) is
-  outside the hot path; ``store_samples`` therefore takes decoded waveforms from a user-supplied
-  ``audio_loader(path) -> (float32 samples, samplerate)``.
+  ``store_samples`` takes decoded waveforms from ``audio_loader(path) -> (float32 samples, samplerate)``;
+  ``load_audio`` below bundles FLAC (with librosa's 22 050 Hz resampling, preprocessing.py:169), wav and npy.
   """
 
   def __init__(self, data_directory):
@@ -169,7 +168,7 @@ class SpeechCorpusReader:
     extractor processes ``batch`` utterances per launch instead of the reference's process pool
     (preprocessing.py:229-241)."""
     if audio_loader is None:
-      raise RuntimeError('no audio decoder is bundled: pass audio_loader(path) -> (samples, samplerate)')
+      audio_loader = load_audio
     out_directory = self._get_directory(preprocess_fnc, directory)
     os.makedirs(out_directory, exist_ok=True)
     files = list(iglob_recursive(self._data_directory + '/' + directory, pattern))
@@ -212,11 +211,15 @@ class SpeechCorpusReader:
 def load_audio(path):
   """Decode an audio file to (float32 mono samples in [-1, 1], samplerate).
 
-  Bundled decoders: 16-bit PCM ``.wav`` (stdlib ``wave``) and raw ``.npy`` arrays (assumed 16 kHz).
-  FLAC decoding and librosa's implicit 22 050 Hz ``kaiser_best`` resampling (preprocessing.py:169)
-  are real-audio ingest, outside the hot path: convert LibriSpeech to wav first.
+  Bundled decoders: ``.flac`` (audio_io: FLAC decoding + librosa's implicit 22 050 Hz ``kaiser_best``
+  resampling, i.e. ``librosa.load(path)`` of preprocessing.py:169), 16-bit PCM ``.wav`` (stdlib ``wave``,
+  native rate) and raw ``.npy`` arrays (assumed 16 kHz).
   """
   ext = os.path.splitext(path)[1].lower()
+  if ext == '.flac':
+    # what the reference does for LibriSpeech: librosa.load(path) -> mono, resampled to 22 050 Hz
+    from . import audio_io
+    return audio_io.librosa_load(path)
   if ext == '.npy':
     return np.load(path).astype(np.float32), 16000
   if ext == '.wav':
@@ -235,7 +238,7 @@ class Preprocessing:
   """`speecht-cli preprocess` (preprocessing.py:282-311).  Corpus download (corpus.py) is network
   I/O and out of scope: the audio must already be under <data_dir>/{train,test,dev}."""
 
-  AUDIO_PATTERNS = ('*.wav', '*.npy')
+  AUDIO_PATTERNS = ('*.flac', '*.wav', '*.npy')
 
   def __init__(self, flags):
     self.flags = flags

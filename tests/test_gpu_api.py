@@ -193,3 +193,29 @@ def test_library_rccl_allreduce_single_rank(dev):
   torch.cuda.synchronize()
   assert torch.equal(flat, before)
   red.comm.close()
+
+
+def test_flac_corpus_store_and_load_like_the_reference_fixture(dev, tmp_path, golden_dir):
+  """The reference's corpus-reader test (speecht/tests/test_speechCorpusReader.py:40-73) on its own fixture:
+  a LibriSpeech FLAC + transcript file under <data>/train -> store_samples -> load_samples.  The audio takes
+  librosa.load's route (decode, 22 050 Hz kaiser_best), features are checked against the oracle."""
+  import shutil
+  from speecht_amd import preprocessing
+  data = tmp_path / 'data'
+  (data / 'train').mkdir(parents=True)
+  for name in ('1089-134686-0037.flac', '1089-134686.trans.txt'):
+    shutil.copy(os.path.join(golden_dir, name), str(data / 'train' / name))
+  reader = preprocessing.SpeechCorpusReader(str(data))
+  reader.store_samples('train', preprocessing.calc_power_spectrogram)
+  samples = list(reader.load_samples('train', feature_type='power'))
+  assert len(samples) == 1
+  feats, transcript = samples[0]
+  audio, rate = preprocessing.load_audio(str(data / 'train' / '1089-134686-0037.flac'))
+  assert audio.shape == (114881,) and rate == 22050                     # test_speechCorpusReader.py:45
+  ref = O.calc_power_spectrogram(audio.astype(np.float64), rate, n_mels=128)
+  assert feats.shape == ref.shape == (1 + 114881 // 160, 128)
+  assert np.max(np.abs(feats - ref)) < 1e-3
+  line = [l for l in open(os.path.join(golden_dir, '1089-134686.trans.txt')) if l.startswith('1089-134686-0037 ')][0]
+  assert transcript.tolist() == O.sentence_to_ids(line.split(' ', 1)[1].strip().lower())
+  ids = [audio_id for audio_id, _, _ in reader.generate_samples('train', preprocessing.calc_power_spectrogram)]
+  assert ids == ['1089-134686-0037']

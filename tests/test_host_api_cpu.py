@@ -197,3 +197,28 @@ def test_data_parallel_allreduce_equals_single_rank_gloo(tmp_path):
   outs = [p.communicate(timeout=240)[0].decode() for p in procs]
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o)
+
+
+def test_flac_ingest_matches_the_references_fixture_expectations(golden_dir):
+  """The reference's only numeric pin on this path: ``librosa.load`` of its LibriSpeech fixture has shape
+  (114881,) (speecht/tests/test_speechCorpusReader.py:45).  The FLAC decoder is pinned bit-exactly by the MD5
+  signature inside the file (decode_flac verifies it), the resampler by the output length, a pure tone and
+  agreement with scipy's polyphase resampler."""
+  import scipy.signal
+  from speecht_amd import audio_io
+  from speecht_amd.preprocessing import load_audio
+  path = os.path.join(golden_dir, '1089-134686-0037.flac')
+  samples, rate, bps = audio_io.decode_flac(path)                # raises if the MD5 does not match
+  assert samples.shape == (83360, 1) and rate == 16000 and bps == 16
+  y, sr = load_audio(path)
+  assert y.shape == (114881,) and sr == 22050 and y.dtype == np.float32
+  native = samples[:, 0] / 32768.0
+  poly = scipy.signal.resample_poly(native, 441, 320)
+  n = min(len(poly), len(y))
+  assert np.corrcoef(y[:n], poly[:n])[0, 1] > 0.9999
+  tone = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0)
+  z = audio_io.resample_kaiser_best(tone, 16000, 22050)
+  assert len(z) == 22050
+  assert np.max(np.abs(z - np.sin(2 * np.pi * 1000.0 * np.arange(22050) / 22050.0))[200:-200]) < 1e-6
+  with pytest.raises(audio_io.FlacError):
+    audio_io.decode_flac(b'fLaC' + bytes(60))

@@ -239,6 +239,9 @@ def main():
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
     if out['roofline'] and os.path.exists(traffic_file):
       out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
+    util_file = os.path.join(ROOT, 'profiles', 'mfma_util.json')
+    if out['roofline'] and os.path.exists(util_file):      # PMC pass (scripts/gpu_mfma_util.sh), padded work included
+      out['roofline']['mfma_busy_pmc'] = json.load(open(util_file)).get('gemm_nn_kernel<128, 128, 2, 2, 0, true>', {}).get('mfma_busy_frac_at_2p4ghz')
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:

@@ -746,16 +746,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(NNParams p, int ep
   *reinterpret_cast<f32x4*>(p.C + p.cmap.off(m) + c4) = v;
 }
 
-// split-K policy.  Measured on MI355X (L8 back-prop to the input: M 16032, K 64000, N 256 -> 252
-// tiles of 128x128): no split 4.31 ms, 2 splits 4.32 ms, 4 splits 4.39 ms, 64x128 tiles 4.62 ms.
-// One 128x128 workgroup per CU already keeps the matrix pipe as busy as two, so splitting K buys
-// nothing; the machinery stays for shapes with far fewer tiles than CUs (ST_GEMM_SPLITS forces it).
+// Split-K policy for C = A * B with few output tiles and a long reduction (back-prop through L8: 252 tiles of
+// 128x128 on 256 CUs, K = 64 512).  With about one workgroup per CU every SIMD holds a single wave and
+// nothing overlaps its barriers; two K-halves give two co-resident workgroups per CU and, with the lean loop
+// of today, 3.99 -> 3.75 ms (128.7 -> 136.8 TFLOP/s) including the slab epilogue; 3 splits leave a ragged round
+// (4.74 ms), 4 splits 3.87 ms.  (The first version of this kernel measured no gain: 4.31 vs 4.32 ms.)
 int nn_splits(int M, int Np, int Kp) {
   static const int forced = getenv("ST_GEMM_SPLITS") ? atoi(getenv("ST_GEMM_SPLITS")) : 0;
   if (Np % 128) return 1;
   const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
   const int nk = Kp / BK;
-  int splits = forced ? forced : (tiles128 < 64 && nk >= 256 ? (int)std::min<long>(8, 256 / tiles128) : 1);
+  int splits = forced ? forced
+                      : (tiles128 < 64 && nk >= 256 ? (int)std::min<long>(8, 256 / tiles128)
+                                                     : (tiles128 > 128 && tiles128 <= 320 && nk >= 512 ? 2 : 1));
   while (splits > 1 && nk / splits < 64) --splits;
   return splits;
 }

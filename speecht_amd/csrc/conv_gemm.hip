@@ -474,9 +474,9 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   int stt = min(m_begin, p.M - 1) - sb * p.amap.frames;
 
   // slice `sl` (0..3) of the stage starting at row mb -> LDS buffer buf
-  auto is_plain = [&](int mb) { return !tiny && stt + BMR <= p.amap.frames && mb + BMR <= m_end; };
-  auto issue_slice = [&](int sl, int mb, int buf, auto plain_c) {
-    if constexpr (decltype(plain_c)::value) {
+  auto issue_slice = [&](int sl, int mb, int buf) {
+    const bool plain = !tiny && stt + BMR <= p.amap.frames && mb + BMR <= m_end;
+    if (plain) {
       const char* sa = reinterpret_cast<const char*>(p.A + ((long)sb * p.amap.batch_stride + p.amap.row0 + (long)stt * p.amap.row_stride));
       const char* sz = reinterpret_cast<const char*>(p.Z + ((long)sb * p.zmap.batch_stride + p.zmap.row0 + (long)stt * p.zmap.row_stride));
 #pragma unroll
@@ -510,13 +510,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   };
 
   if (nstages > 0) {
-    if (is_plain(m_begin)) {
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl) issue_slice(sl, m_begin, 0, std::true_type{});
-    } else {
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) issue_slice(sl, m_begin, 0, std::false_type{});
-    }
+    for (int sl = 0; sl < 4; ++sl) issue_slice(sl, m_begin, 0);
     stage_advance();
   }
   dma_wait_all();
@@ -524,15 +519,12 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
 
   const int a_frag = (4 * h) * BKO + wk * WTK + MT * l31;
   const int z_frag = (4 * h) * BN + wn * WTN + NT * l31;
-  // One stage with its LDS slot (CUR), "is there a next stage" (MODE >= 1) and "can the next stage be
-  // staged with scalar-base pieces" (MODE == 2) fixed at compile time: the stage body is branch-free, the
-  // choice is made once per stage (see gemm_nn_kernel for why that matters).
-  auto stage = [&](auto cur_c, auto mode_c, int st) {
-    constexpr int CUR = decltype(cur_c)::value;
-    constexpr int MODE = decltype(mode_c)::value;
+  for (int st = 0; st < nstages; ++st) {
+    const int cur = st & 1;
+    const bool more = st + 1 < nstages;
     const int mb_next = m_begin + (st + 1) * BMR;
-    const float* as = As + CUR * A_SZ + a_frag;
-    const float* zs = Zs + CUR * Z_SZ + z_frag;
+    const float* as = As + cur * A_SZ + a_frag;
+    const float* zs = Zs + cur * Z_SZ + z_frag;
     avec af[4][4];
     zvec zf[4][4];
     auto read_frags = [&](int q) {
@@ -545,8 +537,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
     read_frags(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if constexpr (MODE == 2) issue_slice(q, mb_next, CUR ^ 1, std::true_type{});
-      if constexpr (MODE == 1) issue_slice(q, mb_next, CUR ^ 1, std::false_type{});
+      if (more) issue_slice(q, mb_next, cur ^ 1);
       if (q < 3) read_frags(q + 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -564,19 +555,9 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (MODE >= 1) stage_advance();
+    if (more) stage_advance();
     dma_wait_all();
     __syncthreads();
-  };
-  auto run = [&](auto cur_c, int st) {
-    using std::integral_constant;
-    if (st + 1 >= nstages) stage(cur_c, integral_constant<int, 0>{}, st);
-    else if (is_plain(m_begin + (st + 1) * BMR)) stage(cur_c, integral_constant<int, 2>{}, st);
-    else stage(cur_c, integral_constant<int, 1>{}, st);
-  };
-  for (int st = 0; st < nstages; st += 2) {
-    run(std::integral_constant<int, 0>{}, st);
-    if (st + 1 < nstages) run(std::integral_constant<int, 1>{}, st + 1);
   }
 
   float* out = p.out + (long)split * p.Kp * p.Np;

@@ -151,7 +151,9 @@ int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts
  * the back-prop operand comes from st_filters_bwd_bf16).
  * Accumulation, bias, ReLU, the logits of the last layer, CTC, clip and Adam are fp32.
  *   forward : y = relu?(conv(x) + bias) -> y_bf16 and/or y_f32 (either may be NULL)
- *   bwd-data: dx = conv^T(dz) * [act > 0]  (stride-1 layers; act = the layer input, NULL = no mask)
+ *   bwd-data: dx = conv^T(dz) * [act > 0]  (stride-1 layers; act = the layer input, NULL = no mask);
+ *             workspace of st_conv1d_bwd_data_bf16_ws bytes (0 for most shapes: only long reductions
+ *             on few output tiles are split into fp32 partial sums)
  *   bwd-filt: dpacked [k_pad][n_pad] (rows < width*c_pitch written) and dbias [n_pad], fp32;
  *             stride 1 or 2; workspace from st_conv1d_bwd_filter_bf16_ws. */
 int st_cast_bf16(const float* src, size_t n, void* dst, void* stream);

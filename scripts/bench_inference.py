@@ -45,6 +45,18 @@ def main():
     out[key] = {'utterances_per_s': round(args.utterances / dt, 1), 'seconds': round(dt, 3),
                 'padding_overhead': round(inference.padding_overhead(frames, buckets), 4),
                 'realtime_factor': round(out['audio_seconds'] / dt, 0)}
+  # single-utterance latency (the SingleInputLoader / live path): eager launch sequence vs the captured HIP graph
+  one = feats[0][:201]                                           # a 2 s utterance
+  eng.load_batch(one[None], [one.shape[0]])
+  for name, fn in (('eager', eng.forward), ('graph', eng.forward_graph)):
+    for _ in range(3):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+      fn()
+      eng.greedy_decode()
+    out.setdefault('single_utterance_2s_latency_ms', {})[name] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
   print(json.dumps(out))
 
 

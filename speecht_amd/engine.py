@@ -72,6 +72,7 @@ class _Storage:
   def __init__(self, device):
     self.device = device
     self.bufs = {}
+    self.generation = 0          # bumped on every (re)allocation: captured graphs hold the old pointers
 
   def view(self, name, numel, dtype=None):
     import torch as _t
@@ -81,6 +82,7 @@ class _Storage:
     if fresh:
       cur = _t.zeros(max(numel, 1), dtype=dtype, device=self.device)
       self.bufs[name] = cur
+      self.generation += 1
     return cur, fresh
 
 
@@ -402,6 +404,38 @@ class Wav2LetterEngine:
       else:
         call('st_conv1d_nwc_fwd_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, s)
+
+  def forward_graph(self):
+    """``forward()`` replayed from a HIP graph: the launch sequence of the current (batch, frames) shape is
+    captured once and replayed with a single launch afterwards -- for small batches (live / single-utterance
+    inference) the eleven kernels are launch-bound and the CPU cost of enqueueing them is the latency.
+    Buffers, weights and the batch are read through the same device pointers on replay, so new inputs
+    (``load_batch`` with the same shape) and in-place weight updates are picked up; a new shape captures anew."""
+    if not hasattr(self, '_graphs'):
+      self._graphs, self._graph_seen = {}, set()
+    if self.conv_mode == 'bf16' and not self._wplanes_fresh:
+      self._refresh_bf16_filters(False)            # derived operands are rebuilt outside the graph
+    if self.conv_mode == 'bf16x6' and not self._wplanes_fresh:
+      self._refresh_wplanes()
+    key = (self._shape, self._storage.generation)
+    graph = self._graphs.get(key)
+    if graph is None:
+      # a shape is captured the second time it shows up: the first pass runs eagerly (it also is the warm-up
+      # -- lazy allocations, env lookups), so a stream of all-different shapes pays nothing for graphs
+      if key not in self._graph_seen:
+        self._graph_seen = {k for k in self._graph_seen if k[1] == self._storage.generation} | {key}
+        return self.forward()
+      self._graphs = {k: g for k, g in self._graphs.items() if k[1] == self._storage.generation}   # drop stale captures
+      torch.cuda.synchronize(self.device)
+      graph = torch.cuda.CUDAGraph()
+      own_stream, self._stream = self._stream, None
+      try:
+        with torch.cuda.graph(graph):              # our C ABI launches on torch's current (capturing) stream
+          self.forward()
+      finally:
+        self._stream = own_stream
+      self._graphs[key] = graph
+    graph.replay()
 
   def logits_time_major(self):
     """[T', B, C] like tf.transpose(outputs, (1, 0, 2)) (speech_model.py:295)."""

@@ -219,3 +219,28 @@ def test_flac_corpus_store_and_load_like_the_reference_fixture(dev, tmp_path, go
   assert transcript.tolist() == O.sentence_to_ids(line.split(' ', 1)[1].strip().lower())
   ids = [audio_id for audio_id, _, _ in reader.generate_samples('train', preprocessing.calc_power_spectrogram)]
   assert ids == ['1089-134686-0037']
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_forward_graph_replays_bit_exactly(dev, mode):
+  """engine.forward_graph(): the captured HIP graph gives bit-identical logits to the eager launch sequence,
+  picks up new inputs of the same shape and in-place weight updates, and re-captures for a new shape."""
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(16, width=40, fc=72)
+  eng = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
+  eng.set_weights(WL.xavier_params(layers, seed=4))
+  for k, frames in enumerate([[50, 41], [50, 41], [33], [50, 41]]):
+    x, seq, _ = WL.make_batch(frames, 16, seed=30 + k)
+    eng.load_batch(x, seq)
+    eng.forward()
+    eager = eng.logits_time_major().clone()
+    eng.X[-1].buf.zero_()
+    eng.forward_graph()
+    assert torch.equal(eng.logits_time_major(), eager), (k, frames)
+  assert len(eng._graphs) >= 1              # [50, 41] came back: captured on its second visit, replayed on the third
+  eng.params.mul_(1.01)                     # in-place update of the masters
+  eng.mark_weights_changed()
+  eng.forward()
+  eager = eng.logits_time_major().clone()
+  eng.forward_graph()
+  assert torch.equal(eng.logits_time_major(), eager)

@@ -68,6 +68,13 @@ int st_filters_flip_transpose_f32(const float* packed, int width, int cin, int c
  * Requires x->halo >= pad_left and enough trailing halo; bias has n_pad floats. */
 int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
                           int stride, int pad_left, int relu, const st_tensor3* y, void* stream);
+/* Same, with a workspace (st_conv1d_fwd_ws bytes; 0 when the shape does not split).  With few output rows
+ * (live / single-utterance inference) the reduction is split over the idle CUs and summed in a fixed
+ * order; without a large enough workspace the call is identical to st_conv1d_nwc_fwd_f32. */
+size_t st_conv1d_fwd_ws(const st_tensor3* x, const st_tensor3* y, int width);
+int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
+                             int stride, int pad_left, int relu, const st_tensor3* y, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),
@@ -165,6 +172,13 @@ int st_filters_bwd_bf16(const float* packed, int width, int cin, int cout, int c
 int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16,
                            const float* bias, int width, int stride, int pad_left, int relu,
                            const st_tensor3* y, void* y_bf16, float* y_f32, void* stream);
+/* same with a workspace (st_conv1d_fwd_bf16_ws bytes): few output rows split the reduction, as in
+ * st_conv1d_nwc_fwd_ws_f32 */
+size_t st_conv1d_fwd_bf16_ws(const st_tensor3* x, const st_tensor3* y, int width);
+int st_conv1d_nwc_fwd_ws_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16,
+                              const float* bias, int width, int stride, int pad_left, int relu,
+                              const st_tensor3* y, void* y_bf16, float* y_f32, void* workspace,
+                              size_t workspace_bytes, void* stream);
 size_t st_conv1d_bwd_data_bf16_ws(const st_tensor3* dz, const st_tensor3* dx, int width);
 int st_conv1d_nwc_bwd_data_bf16(const st_tensor3* dz, const void* dz_bf16, const void* wtt_bf16,
                                 int width, int pad_left, const st_tensor3* act, const void* act_bf16,

@@ -28,6 +28,9 @@ _SIGNATURES = {
     'st_unpack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_filters_flip_transpose_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_conv1d_nwc_fwd_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p]),
+    'st_conv1d_fwd_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_conv1d_nwc_fwd_ws_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p, c_size_t,
+                                          c_void_p]),
     'st_conv1d_bwd_data_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_data_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_bwd_filter_ws': (c_size_t, [_T3P, _T3P, c_int]),
@@ -54,6 +57,9 @@ _SIGNATURES = {
     'st_filters_bwd_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_conv1d_nwc_fwd_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p,
                                        c_void_p, c_void_p]),
+    'st_conv1d_fwd_bf16_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_conv1d_nwc_fwd_ws_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _T3P, c_void_p,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_bwd_data_bf16_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_data_bf16': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, c_void_p, _T3P, c_void_p,
                                             c_void_p, c_size_t, c_void_p]),

@@ -631,7 +631,8 @@ RowMapB map_of(const st_tensor3& t, int first_row, int frame_stride, int frames)
 // ---- shared bodies of the forward / back-prop-to-input / filter-gradient entry points ------------------
 template <int NP>
 int conv_fwd(const st_tensor3* x, const void* x_planes, const void* w_planes, const float* bias, int width, int stride,
-             int pad_left, int relu, const st_tensor3* y, float* y_f32, void* y_planes, hipStream_t s) {
+             int pad_left, int relu, const st_tensor3* y, float* y_f32, void* y_planes, hipStream_t s, int splits = 1,
+             float* slabs = nullptr) {
   X6Params p{};
   p.A = reinterpret_cast<const __bf16*>(x_planes);
   p.a_plane = (size_t)x->batch * x->t_pitch * x->c_pitch;
@@ -651,7 +652,34 @@ int conv_fwd(const st_tensor3* x, const void* x_planes, const void* w_planes, co
   p.relu = relu;
   p.taps = width;
   p.cp = x->c_pitch;
-  return launch_gemm<NP>(p, s);
+  if (splits <= 1) return launch_gemm<NP>(p, s);
+  // few output rows: fp32 partial sums [split][M][Np], then one pass with bias + ReLU into the output tensor(s)
+  const RowMapB out_map = p.cmap;
+  __bf16* out = p.Cp;
+  float* out_f = p.C;
+  p.C = slabs; p.Cp = nullptr; p.bias = nullptr; p.relu = 0;
+  p.cmap = RowMapB{};
+  p.cmap.frames = p.M;
+  p.cmap.row_stride = p.Np;
+  p.splits = splits;
+  p.slab_stride = (long)p.M * p.Np;
+  if (int e = launch_gemm<NP>(p, s)) return e;
+  const long work = (long)p.M * (p.n_store / 4);
+  hipLaunchKernelGGL(slab_epilogue_kernel<NP>, dim3((unsigned)std::min<long>((work + 255) / 256, 4096)), dim3(256), 0, s,
+                     slabs, splits, p.slab_stride, p.M, p.Np, p.n_store, bias, relu, (const float*)nullptr,
+                     (const __bf16*)nullptr, RowMapB{}, out_map, out, p.c_plane, out_f);
+  return st::check_launch("slab_epilogue");
+}
+
+// Forward pass on few output rows (single-utterance inference: 16 tiles on 256 CUs): slices of the reduction on
+// the idle CUs.  Tap-inner convolutions split over 64-channel chunks (every slice walks all taps), 1x1 layers
+// over slices of >= 4 stages.
+int fwd_splits(const st_tensor3& x, const st_tensor3& y, int width) {
+  const long tiles = (long)st::ceil_div(y.batch * y.frames, 128) * st::ceil_div(npad_of(y.channels), 128);
+  if (tiles >= 128 || npad_of(y.channels) % 128) return 1;
+  const int chunks = st::ceil_div(x.c_pitch, 64);
+  const long slices = width > 1 ? chunks : chunks / 4;
+  return (int)std::max(1L, std::min<long>(256 / tiles, slices));
 }
 
 // channel-chunk split of a tap-inner convolution whose tile grid cannot fill the chip (back-prop through L8:
@@ -886,15 +914,31 @@ int st_filters_bwd_bf16(const float* packed, int width, int cin, int cout, int c
   return st::check_launch("filters_bwd_bf16");
 }
 
-int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16, const float* bias, int width,
-                           int stride, int pad_left, int relu, const st_tensor3* y, void* y_bf16, float* y_f32,
-                           void* stream) {
+size_t st_conv1d_fwd_bf16_ws(const st_tensor3* x, const st_tensor3* y, int width) {
+  if (!x || !y) return 0;
+  const int splits = fwd_splits(*x, *y, width);
+  return splits > 1 ? (size_t)splits * y->batch * y->frames * npad_of(y->channels) * sizeof(float) : 0;
+}
+
+int st_conv1d_nwc_fwd_ws_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16, const float* bias, int width,
+                              int stride, int pad_left, int relu, const st_tensor3* y, void* y_bf16, float* y_f32,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(x && y && x_bf16 && wt_bf16 && (y_bf16 || y_f32), "conv fwd bf16: null argument");
   ST_REQUIRE(width >= 1 && stride >= 1 && x->halo >= pad_left && y->frames == st::ceil_div(x->frames, stride) &&
                  x->batch == y->batch && x->c_pitch % 16 == 0 && y->c_pitch % 16 == 0,
              "conv fwd bf16: bad geometry");
   ST_REQUIRE(x->halo - pad_left + (y->frames - 1) * stride + width <= x->t_pitch, "conv fwd bf16: right halo too small");
-  return conv_fwd<1>(x, x_bf16, wt_bf16, bias, width, stride, pad_left, relu, y, y_f32, y_bf16, st::as_stream(stream));
+  int splits = fwd_splits(*x, *y, width);
+  if (!workspace || workspace_bytes < st_conv1d_fwd_bf16_ws(x, y, width)) splits = 1;
+  return conv_fwd<1>(x, x_bf16, wt_bf16, bias, width, stride, pad_left, relu, y, y_f32, y_bf16, st::as_stream(stream),
+                     splits, reinterpret_cast<float*>(workspace));
+}
+
+int st_conv1d_nwc_fwd_bf16(const st_tensor3* x, const void* x_bf16, const void* wt_bf16, const float* bias, int width,
+                           int stride, int pad_left, int relu, const st_tensor3* y, void* y_bf16, float* y_f32,
+                           void* stream) {
+  return st_conv1d_nwc_fwd_ws_bf16(x, x_bf16, wt_bf16, bias, width, stride, pad_left, relu, y, y_bf16, y_f32, nullptr, 0,
+                                   stream);
 }
 
 size_t st_conv1d_bwd_data_bf16_ws(const st_tensor3* dz, const st_tensor3* dx, int width) {

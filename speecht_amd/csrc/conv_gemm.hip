@@ -709,22 +709,22 @@ RowMap make_map(const st_tensor3& t, int first_row, int frame_stride, int frames
 // C[m, :] = epilogue(sum_s slab[s][m][:]) for split-K launches (fixed summation order).
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(NNParams p, int epi) {
   const int cols4 = p.n_store / 4;
-  const int rows_per_block = 256 / cols4 > 0 ? 256 / cols4 : 1;
-  const int c4 = (threadIdx.x % cols4) * 4;
-  const int m = blockIdx.x * rows_per_block + threadIdx.x / cols4;
-  if (m >= p.M || threadIdx.x >= rows_per_block * cols4) return;
-  const float* src = p.slab + (long)m * p.Np + c4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(src);
-  for (int sidx = 1; sidx < p.splits; ++sidx) v += *reinterpret_cast<const f32x4*>(src + (long)sidx * p.M * p.Np);
-  if (epi == 0) {
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
-    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-  } else if (p.mask) {
-    f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + p.mmap.off(m) + c4);
+  const long total = (long)p.M * cols4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / cols4), c4 = (int)(idx % cols4) * 4;
+    const float* src = p.slab + (long)m * p.Np + c4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    for (int sidx = 1; sidx < p.splits; ++sidx) v += *reinterpret_cast<const f32x4*>(src + (long)sidx * p.M * p.Np);
+    if (epi == 0) {
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    } else if (p.mask) {
+      f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + p.mmap.off(m) + c4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(p.C + p.cmap.off(m) + c4) = v;
   }
-  *reinterpret_cast<f32x4*>(p.C + p.cmap.off(m) + c4) = v;
 }
 
 // Split-K policy for C = A * B with few output tiles and a long reduction (back-prop through L8: 252 tiles of
@@ -742,6 +742,21 @@ int nn_splits(int M, int Np, int Kp) {
                                                      : (tiles128 > 128 && tiles128 <= 320 && nk >= 512 ? 2 : 1));
   while (splits > 1 && nk / splits < 64) --splits;
   return splits;
+}
+
+// Forward pass on few output rows (one 2 s utterance: M = 101, so 16 tiles of 128x128 on 256 CUs, each walking
+// the whole reduction alone -- L8's 250 k-tiles are a 0.43 ms serial MFMA chain).  The reduction is cut into
+// slices of >= 4 k-tiles until about one workgroup per CU exists; the raw partial tiles go to slabs that
+// splitk_epilogue_kernel sums in a fixed order before bias + ReLU.  Measured, forward + greedy decode of one
+// 2 s utterance: 1.18 ms unsplit, 0.355 ms with this policy (>= 8 tiles per slice 0.396, >= 2: 0.398, twice
+// the workgroups 0.363).
+int fwd_splits(int M, int Np, int nk) {
+  static const int forced = getenv("ST_FWD_SPLITS") ? atoi(getenv("ST_FWD_SPLITS")) : 0;
+  if (Np % 128) return 1;
+  const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
+  if (forced) return std::max(1, std::min(forced, nk));
+  if (tiles128 >= 128) return 1;
+  return (int)std::max<long>(1, std::min<long>(256 / tiles128, nk / 4));
 }
 
 template <int BM, int BN, int WMW, int WNW, bool FAST = false>
@@ -772,8 +787,9 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
   if (p.splits > 1) {
-    const int rows_per_block = std::max(1, 256 / (p.n_store / 4));
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(st::ceil_div(p.M, rows_per_block)), dim3(256), 0, s, p, epi);
+    const long quads = (long)p.M * (p.n_store / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 4096)), dim3(256), 0, s,
+                       p, epi);
   }
 }
 
@@ -874,8 +890,23 @@ int st_filters_flip_transpose_f32(const float* packed, int width, int cin, int c
   return st::check_launch("flip_transpose");
 }
 
+size_t st_conv1d_fwd_ws(const st_tensor3* x, const st_tensor3* y, int width) {
+  if (!x || !y) return 0;
+  const int np = npad_of(y->channels);
+  const int M = y->batch * y->frames;
+  const int nk = width > 1 ? st::ceil_div(x->c_pitch, BK) * width : st::ceil_div(x->c_pitch, BK);
+  const int splits = fwd_splits(M, np, nk);
+  return splits > 1 ? (size_t)splits * M * np * sizeof(float) : 0;
+}
+
 int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
                           int stride, int pad_left, int relu, const st_tensor3* y, void* stream) {
+  return st_conv1d_nwc_fwd_ws_f32(x, packed, bias, width, stride, pad_left, relu, y, nullptr, 0, stream);
+}
+
+int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
+                             int stride, int pad_left, int relu, const st_tensor3* y, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && packed, "conv fwd: bad tensor descriptor");
   ST_REQUIRE(width > 0 && stride > 0 && pad_left >= 0 && x->batch == y->batch, "conv fwd: bad shape");
   ST_REQUIRE(y->frames == st::ceil_div(x->frames, stride), "conv fwd: y.frames != ceil(x.frames/stride)");
@@ -897,6 +928,14 @@ int st_conv1d_nwc_fwd_f32(const st_tensor3* x, const float* packed, const float*
   p.relu = relu;
   p.taps = width;
   p.cp = x->c_pitch;
+  // few output rows (live / single-utterance inference): spread the reduction over the idle CUs
+  const int nk = p.taps > 1 ? st::ceil_div(p.cp, BK) * p.taps : p.Kp / BK;
+  const int splits = fwd_splits(p.M, p.Np, nk);
+  if (splits > 1 && workspace && workspace_bytes >= (size_t)splits * p.M * p.Np * sizeof(float)) {
+    p.steps_per_split = st::ceil_div(nk, splits);
+    p.splits = st::ceil_div(nk, p.steps_per_split);
+    p.slab = reinterpret_cast<float*>(workspace);
+  }
   return run_nn(p, 0, st::as_stream(stream));
 }
 

@@ -102,8 +102,13 @@ class LayerSpec:
 class Wav2LetterEngine:
   """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
 
-  def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None):
+  def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None, split_small_batches=True):
     _lib.load()
+    # With few output rows (single-utterance / live inference) the forward GEMMs split their reduction over
+    # the otherwise idle CUs (3x lower latency for one 2 s utterance).  The summation order then depends on the
+    # batch size, so an utterance's logits are equal to ~1e-6 rather than bit-identical across batch sizes;
+    # split_small_batches=False keeps the single-pass kernels for every shape (bit-exact batch invariance).
+    self.split_small_batches = bool(split_small_batches)
     # 'fp32': exact-f32 MFMA kernels (default).  'bf16x6': EXPERIMENTAL fp32-accurate split-bf16 path
     # (csrc/conv_bf16.hip, NP = 3) for forward and back-prop-to-input of the wide layers.
     # 'bf16': BASELINE config 4 -- bf16 activations and activation gradients, fp32 masters / accumulation /
@@ -240,6 +245,7 @@ class Wav2LetterEngine:
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
     ws = max([ws] + [lib.st_conv1d_bwd_data_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
+    ws = max([ws] + [lib.st_conv1d_fwd_ws(self.X[i].ref, self.X[i + 1].ref, l.width) for i, l in enumerate(self.layers)])
     if self.conv_mode == 'bf16x6':
       ws = max([ws] + [lib.st_exp_conv1d_bwd_data_bf16x6_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                        for i, l in enumerate(self.layers) if i > 0])
@@ -265,6 +271,8 @@ class Wav2LetterEngine:
              for i, l in enumerate(self.layers))
     ws = max([ws] + [lib.st_conv1d_bwd_data_bf16_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
+    ws = max([ws] + [lib.st_conv1d_fwd_bf16_ws(self.X[i].ref, self.X[i + 1].ref, l.width)
+                     for i, l in enumerate(self.layers)])
     self.wgrad_ws_b, _ = self._storage.view('wgrad_ws_b', ws // 4 + 64)
     if not hasattr(self, 'Wb'):
       z = lambda n: torch.zeros(n, dtype=torch.bfloat16, device=self.device)
@@ -291,9 +299,10 @@ class Wav2LetterEngine:
     call('st_cast_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xb[0]), s)
     for i, l in enumerate(self.layers):
       last = i + 1 == L
-      call('st_conv1d_nwc_fwd_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(self.Wb[i]),
+      call('st_conv1d_nwc_fwd_ws_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(self.Wb[i]),
            self._ptr(self._slice(self.params, i)[1]), l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref,
-           None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None, s)
+           None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None,
+           self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4 if self.split_small_batches else 0, s)
 
   def _backward_bf16(self, on_layer_done):
     s, L = self.stream_ptr, len(self.layers)
@@ -402,8 +411,9 @@ class Wav2LetterEngine:
         call('st_exp_conv1d_fwd_bf16x6', self.X[i].ref, self._ptr(self.Xp[i]), self._ptr(self.Wp[i]), self._ptr(pb),
              l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref, yp, s)
       else:
-        call('st_conv1d_nwc_fwd_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
-             self.geo[i][2], int(l.relu), self.X[i + 1].ref, s)
+        call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
+             self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
+             self.wgrad_ws.numel() * 4 if self.split_small_batches else 0, s)
 
   def forward_graph(self):
     """``forward()`` replayed from a HIP graph: the launch sequence of the current (batch, frames) shape is

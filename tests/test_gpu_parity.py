@@ -77,6 +77,39 @@ def test_conv_fwd_bwd(dev, B, T, W, s, cin, cout, relu):
   assert gsum == pytest.approx(float((gF.astype(np.float64) ** 2).sum() + (gb.astype(np.float64) ** 2).sum()), rel=1e-6)
 
 
+@pytest.mark.parametrize('B,T,W,s,cin,cout', [(1, 101, 32, 1, 250, 2000), (1, 201, 48, 2, 80, 250),
+                                              (3, 90, 7, 1, 250, 250), (1, 5, 1, 1, 2000, 2000)])
+def test_conv_fwd_split_reduction_for_few_rows(dev, B, T, W, s, cin, cout):
+  """Single-utterance shapes leave most CUs without an output tile; the forward then splits the reduction
+  (st_conv1d_nwc_fwd_ws_f32).  Same result as the unsplit launch up to fp32 summation order, same oracle bound,
+  deterministic, and the workspace-less entry point still works."""
+  from speecht_amd import _lib
+  rng = np.random.default_rng(T)
+  x = rng.standard_normal((B, T, cin))
+  F = rng.standard_normal((W, cin, cout)) * (1.0 / math.sqrt(W * cin))
+  b = rng.standard_normal(cout) * 0.1
+  eng = make_engine([(W, s, cin, cout, True)], dev)
+  eng.set_weights([(F, b)])
+  eng.load_batch(x, [T] * B)
+  assert _lib.load().st_conv1d_fwd_ws(eng.X[0].ref, eng.X[1].ref, W) > 0
+  eng.forward()
+  y_split = eng.X[1].buf.clone()
+  eng.forward()
+  assert torch.equal(y_split, eng.X[1].buf)
+  l = eng.layers[0]
+  pf, pb = eng._slice(eng.params, 0)
+  _lib.call('st_conv1d_nwc_fwd_f32', eng.X[0].ref, eng._ptr(pf), eng._ptr(pb), W, s, eng.geo[0][2], 1, eng.X[1].ref,
+            eng.stream_ptr)
+  y_one = eng.X[1].buf.clone()
+  yref = O.conv1d_same_fwd(x, F, b, s, True)
+  scale = max(1.0, float(np.max(np.abs(yref))))
+  assert float((y_split - y_one).abs().max()) < 1e-5 * scale
+  eng.X[1].buf.copy_(y_split)
+  assert np.max(np.abs(eng.X[1].interior().cpu().numpy() - yref)) < 2e-5 * scale
+  full = y_split.view(B, eng.X[1].t_pitch, eng.X[1].c_pitch).cpu().numpy()
+  assert np.all(full[:, :, cout:] == 0)
+
+
 def test_conv_bwd_data_with_relu_mask(dev):
   rng = np.random.default_rng(3)
   layers = [(7, 1, 16, 250, True), (32, 1, 250, 40, True), (1, 1, 40, 29, False)]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 3 on one GPU: inference only (conv stack + CTC greedy decode), variable-length
 utterances (2-15 s, 80-mel), batches of 64 with and without length bucketing.  Wall-clock per pool of
-utterances including the host-side padding, the H2D copy of every batch and the D2H of the decodes."""
+utterances including the host-side padding, the H2D copy of every batch and the D2H of the decodes
+(pipelined across batches by inference.transcribe; the serial loop is timed beside it)."""
 import argparse
 import json
 import os
@@ -32,16 +33,16 @@ def main():
   eng.set_weights(WL.xavier_params(layers, seed=42, bias_range=0.05, dtype=np.float32))
   out = {'workload': 'configs[2]: inference, {} utterances of 2-15 s, batch {}, greedy decode'.format(args.utterances, args.batch),
          'conv_mode': eng.conv_mode, 'audio_seconds': float(samples.sum() / 16000.0)}
-  for bucket in (True, False):
+  for bucket, pipeline in ((True, True), (False, True), (True, False)):
     buckets = inference.make_buckets(frames, args.batch) if bucket else [
         list(range(i, min(i + args.batch, len(feats)))) for i in range(0, len(feats), args.batch)]
-    inference.transcribe(eng, feats[:args.batch], args.batch, bucket)          # warm-up / allocation
+    inference.transcribe(eng, feats, args.batch, bucket, pipeline)          # warm-up: a long-running service's steady state
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ids, _ = inference.transcribe(eng, feats, args.batch, bucket)
+    ids, _ = inference.transcribe(eng, feats, args.batch, bucket, pipeline)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    key = 'bucketed' if bucket else 'arrival_order'
+    key = ('bucketed' if bucket else 'arrival_order') + ('' if pipeline else '_serial_loop')
     out[key] = {'utterances_per_s': round(args.utterances / dt, 1), 'seconds': round(dt, 3),
                 'padding_overhead': round(inference.padding_overhead(frames, buckets), 4),
                 'realtime_factor': round(out['audio_seconds'] / dt, 0)}

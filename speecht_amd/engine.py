@@ -99,6 +99,21 @@ class LayerSpec:
     self.kt_pad, self.nt_pad = kp.value, npad.value
 
 
+class _PendingDecode:
+  """Decoder outputs on their way to pinned host memory (``Wav2LetterEngine.greedy_decode_async``).  The engine
+  alternates between two host slots: read a handle before issuing the second decode after it."""
+
+  def __init__(self, slot, batch, t_out):
+    self._slot, self._batch, self._t_out = slot, batch, t_out
+
+  def result(self):
+    ids_host, lens_host, event = self._slot
+    event.synchronize()
+    lens = lens_host[:self._batch].numpy()
+    ids = ids_host[:self._batch * self._t_out].numpy().reshape(self._batch, self._t_out)
+    return [ids[b, :lens[b]].tolist() for b in range(self._batch)]
+
+
 class Wav2LetterEngine:
   """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
 
@@ -391,7 +406,30 @@ class Wav2LetterEngine:
     self.X[0].interior().copy_(x.to(torch.float32), non_blocking=True)
     self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
     # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
-    self.ctc_lens = torch.as_tensor((self.seq_lens_host // 2).astype(np.int32)).to(self.device, non_blocking=True)
+    self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32))
+
+  def _upload_i32(self, values):
+    """Small int32 host array -> device through a ring of pinned slots.  A hipMemcpyAsync from pageable memory
+    only returns once the stream's earlier kernels have finished, which would stall the thread that enqueues
+    the next batch behind the previous batch's forward; from pinned memory the copy is a stream operation."""
+    if not hasattr(self, '_pin_ring'):
+      self._pin_ring, self._pin_turn = [[None, None] for _ in range(8)], 0
+    slot = self._pin_ring[self._pin_turn % len(self._pin_ring)]
+    self._pin_turn += 1
+    n = int(values.shape[0])
+    if slot[1] is not None:
+      slot[1].synchronize()                        # the copy that last read this slot (8 uploads ago)
+    if slot[0] is None or slot[0].numel() < n:
+      slot[0] = torch.empty(max(n, 1024), dtype=torch.int32, pin_memory=True)
+    slot[0][:n].copy_(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int32)))
+    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    with torch.cuda.stream(stream):
+      dev = torch.empty(n, dtype=torch.int32, device=self.device)
+      dev.copy_(slot[0][:n], non_blocking=True)
+      if slot[1] is None:
+        slot[1] = torch.cuda.Event()
+      slot[1].record(stream)
+    return dev
 
   def forward(self):
     if self.conv_mode == 'bf16':
@@ -458,8 +496,8 @@ class Wav2LetterEngine:
     self.max_label_len = int(max(lens + [0]))
     # CSR ids (+1 pad entry so that the buffer is never empty); array-per-utterance inputs stay in numpy
     ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
-    self.label_ids = torch.as_tensor(ids).to(self.device, non_blocking=True)
-    self.label_offs = torch.as_tensor(offs).to(self.device, non_blocking=True)
+    self.label_ids = self._upload_i32(ids)
+    self.label_offs = self._upload_i32(offs)
 
   def ctc_loss_grad(self, grad_scale):
     B, T = self.X[-1].batch, self.X[-1].frames
@@ -543,6 +581,30 @@ class Wav2LetterEngine:
     lens = self.dec_lens.cpu().numpy()
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
     return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
+
+  def greedy_decode_async(self, merge_repeated=True):
+    """``greedy_decode`` without the host synchronisation: launches the decoder and the D2H copies of its
+    outputs into pinned host buffers and returns a handle; ``handle.result()`` waits for that batch only.  Lets
+    a caller enqueue the next batch's forward before it reads this batch's transcripts (inference.transcribe)."""
+    call('st_ctc_greedy_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(merge_repeated),
+         self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score), self.stream_ptr)
+    B, n = self.dec_lens.numel(), self.dec_ids.numel()
+    if not hasattr(self, '_dec_host'):
+      self._dec_host, self._dec_turn = [None, None], 0
+    self._dec_turn ^= 1
+    slot = self._dec_host[self._dec_turn]
+    if slot is None or slot[0].numel() < n or slot[1].numel() < B:
+      if slot is not None:
+        slot[2].synchronize()                                      # a copy into the old buffers may be in flight
+      slot = [torch.empty(max(n, 1), dtype=torch.int32, pin_memory=True),
+              torch.empty(max(B, 1), dtype=torch.int32, pin_memory=True), torch.cuda.Event()]
+      self._dec_host[self._dec_turn] = slot
+    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    with torch.cuda.stream(stream):
+      slot[0][:n].copy_(self.dec_ids, non_blocking=True)
+      slot[1][:B].copy_(self.dec_lens, non_blocking=True)
+      slot[2].record(stream)
+    return _PendingDecode(slot, B, self.t_out)
 
   def beam_search_decode(self, beam_width=16):
     """LM-free CTC prefix beam search, top path (stock tf.nn.ctc_beam_search_decoder semantics; the

@@ -7,6 +7,9 @@ batch it happens to be in.  Bucketing by length keeps padding -- and therefore w
 work -- small; results for an utterance equal what the reference would produce for the SAME batch
 composition (that is what the tests check), not for an arbitrary one.
 """
+import queue
+import threading
+
 import numpy as np
 
 from . import vocabulary
@@ -25,21 +28,129 @@ def padding_overhead(lengths, buckets):
   return 1.0 - float(lengths.sum()) / padded
 
 
-def transcribe(engine, features, batch_size=64, bucket=True):
-  """features: list of [T_i, input_size] arrays.  Returns (list of id lists, list of strings) in the
-  input order, decoded greedily (speech_model.py:113-115) batch by batch."""
+def _plan(features, batch_size, bucket):
   lengths = [f.shape[0] for f in features]
   buckets = make_buckets(lengths, batch_size) if bucket else [
       list(range(i, min(i + batch_size, len(features)))) for i in range(0, len(features), batch_size)]
+  return lengths, buckets
+
+
+def transcribe(engine, features, batch_size=64, bucket=True, pipeline=True):
+  """features: list of [T_i, input_size] arrays.  Returns (list of id lists, list of strings) in the
+  input order, decoded greedily (speech_model.py:113-115) batch by batch.
+
+  pipeline=True (default) overlaps the three stages of consecutive batches: a stager thread pads batch k+1
+  into pinned host memory and copies it to the device on its own stream while the GPU runs batch k, and the
+  transcripts of batch k are read back (pinned, asynchronous) after batch k+1 has been enqueued.  Same
+  launches on the same data as the serial loop, hence identical ids."""
+  if not features:
+    return [], []
+  lengths, buckets = _plan(features, batch_size, bucket)
   ids_out = [None] * len(features)
-  for idx in buckets:
-    max_t = max(lengths[i] for i in idx)
-    x = np.zeros((len(idx), max_t, features[0].shape[1]), dtype=np.float32)
-    for row, i in enumerate(idx):
-      x[row, :lengths[i]] = features[i]
-    engine.load_batch(x, [lengths[i] for i in idx])
-    engine.forward()
-    ids, _ = engine.greedy_decode()
-    for row, i in enumerate(idx):
-      ids_out[i] = ids[row]
+  if not pipeline:
+    for idx in buckets:
+      max_t = max(lengths[i] for i in idx)
+      x = np.zeros((len(idx), max_t, features[0].shape[1]), dtype=np.float32)
+      for row, i in enumerate(idx):
+        x[row, :lengths[i]] = features[i]
+      engine.load_batch(x, [lengths[i] for i in idx])
+      engine.forward()
+      ids, _ = engine.greedy_decode()
+      for row, i in enumerate(idx):
+        ids_out[i] = ids[row]
+    return ids_out, [vocabulary.ids_to_sentence(s) for s in ids_out]
+
+  stager = _Stager(engine.device, features, lengths, buckets)
+  stager.start()
+  pending = None
+
+  def collect(handle, idx):
+    for row, ids in enumerate(handle.result()):
+      ids_out[idx[row]] = ids
+
+  try:
+    for idx in buckets:
+      staged = stager.get()
+      engine.load_batch(staged, [lengths[i] for i in idx])
+      engine.forward()
+      handle = engine.greedy_decode_async()
+      if pending is not None:
+        collect(*pending)
+      pending = (handle, idx)
+    collect(*pending)
+  finally:
+    stager.close()
   return ids_out, [vocabulary.ids_to_sentence(s) for s in ids_out]
+
+
+_PINNED = {}       # (device, depth) -> ring of pinned staging buffers, grow-only
+
+
+class _Stager(threading.Thread):
+  """Pads batches into a small ring of pinned host buffers and copies them to the device on a private stream,
+  at most ``depth`` batches ahead of the consumer."""
+
+  def __init__(self, device, features, lengths, buckets, depth=2):
+    super().__init__(daemon=True)
+    import torch
+    self.torch = torch
+    self.device, self.features, self.lengths, self.buckets = device, features, lengths, buckets
+    self.queue = queue.Queue(maxsize=depth)
+    self.stream = torch.cuda.Stream(device)
+    # [pinned buffer, event of its last H2D]; the buffers outlive the call (pinning host memory costs
+    # milliseconds and synchronises the device) and are sized for the largest batch of the plan up front
+    self.ring = _PINNED.setdefault((str(device), depth), [[None, None] for _ in range(depth + 2)])
+    width = features[0].shape[1]
+    need = max(len(idx) * max(lengths[i] for i in idx) for idx in buckets) * width
+    for slot in self.ring:
+      if slot[0] is None or slot[0].numel() < need:
+        if slot[1] is not None:
+          slot[1].synchronize()
+        slot[0] = torch.empty(need + need // 4, dtype=torch.float32, pin_memory=True)
+    self.stop = threading.Event()
+
+  def run(self):
+    torch = self.torch
+    from .speech_input import StagedBatch
+    try:
+      width = self.features[0].shape[1]
+      for k, idx in enumerate(self.buckets):
+        if self.stop.is_set():
+          return
+        slot = self.ring[k % len(self.ring)]
+        max_t = max(self.lengths[i] for i in idx)
+        n = len(idx) * max_t * width
+        if slot[1] is not None:
+          slot[1].synchronize()                                   # the copy that last read this buffer is done
+        host = slot[0][:n].view(len(idx), max_t, width)
+        x = host.numpy()
+        for row, i in enumerate(idx):
+          x[row, :self.lengths[i]] = self.features[i]
+          x[row, self.lengths[i]:] = 0.0
+        with torch.cuda.stream(self.stream):
+          dev = torch.empty((len(idx), max_t, width), dtype=torch.float32, device=self.device)
+          dev.copy_(host, non_blocking=True)
+          event = torch.cuda.Event()
+          event.record(self.stream)
+        slot[1] = event
+        self._put(StagedBatch(dev, event))
+    except BaseException as e:                                    # surfaces in the consumer's get()
+      self._put(e)
+
+  def _put(self, item):
+    while not self.stop.is_set():
+      try:
+        self.queue.put(item, timeout=0.1)
+        return
+      except queue.Full:
+        continue
+
+  def get(self):
+    item = self.queue.get()
+    if isinstance(item, BaseException):
+      raise item
+    return item
+
+  def close(self):
+    self.stop.set()
+    self.join(timeout=5.0)

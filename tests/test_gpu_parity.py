@@ -477,6 +477,19 @@ def test_bucketed_inference_matches_oracle_per_bucket(dev):
     ref_ids, _ = O.ctc_greedy_decode(O.wav2letter_forward(x, params, layers), seq // 2)
     assert [ids[i] for i in idx] == ref_ids
   assert text[0] == O.ids_to_sentence(ids[0])
+  # the pipelined default (stager thread, asynchronous read-back) and the serial loop run the same launches
+  for bucket in (True, False):
+    a, _ = transcribe(eng, feats, batch_size=8, bucket=bucket, pipeline=True)
+    b, _ = transcribe(eng, feats, batch_size=8, bucket=bucket, pipeline=False)
+    assert a == b
+  assert transcribe(eng, [], batch_size=8) == ([], [])
+  one, _ = transcribe(eng, feats[:1], batch_size=8)
+  assert one == transcribe(eng, feats[:1], batch_size=8, pipeline=False)[0]
+  # an error in the stager thread (ragged feature width) surfaces in the caller
+  bad = feats[:3] + [np.zeros((50, 17), np.float32)]
+  with pytest.raises(Exception):
+    transcribe(eng, bad, batch_size=2, bucket=False)
+  assert len(transcribe(eng, feats[:4], batch_size=2)[0]) == 4          # and the engine is still usable
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16x6'])

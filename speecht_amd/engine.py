@@ -621,6 +621,25 @@ class Wav2LetterEngine:
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
     return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
 
+  def fetch_losses(self):
+    """Per-utterance CTC losses [B] on the host, after checking the status words: both arrays come back in one
+    pinned, asynchronous copy each and a single event wait (a step's only host synchronisation)."""
+    B = self.loss.numel()
+    if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < B:
+      self._loss_host = (torch.empty(max(B, 64), dtype=torch.float32, pin_memory=True),
+                         torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+    loss_h, status_h, event = self._loss_host
+    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    with torch.cuda.stream(stream):
+      loss_h[:B].copy_(self.loss, non_blocking=True)
+      status_h[:B].copy_(self.ctc_status, non_blocking=True)
+      event.record(stream)
+    event.synchronize()
+    st = status_h[:B].numpy()
+    if st.any():
+      raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))
+    return loss_h[:B].numpy().copy()
+
   def check_ctc_status(self):
     st = self.ctc_status.cpu().numpy()
     if st.any():

@@ -221,8 +221,7 @@ class SpeechModel:
           self._reducer.finish()
         eng.apply_update(self.learning_rate.value, self.max_gradient_norm)
         self.global_step.value += 1
-      eng.check_ctc_status()
-      avg_loss = np.float32(eng.loss.mean().item())
+      avg_loss = np.float32(eng.fetch_losses().mean(dtype=np.float32))     # raises on a CTC status word
       if self._world > 1:
         from .data_parallel import all_reduce_mean_scalar
         avg_loss = np.float32(all_reduce_mean_scalar(float(avg_loss), eng.device))

@@ -178,8 +178,16 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29577')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # test knobs (not used by the driver): ST_SHARE_GPU=1 maps every rank to cuda:0 and ST_DIST_BACKEND=gloo swaps
+    # the transport, so that the world_size > 1 control flow can be exercised on a single-GPU box
+    backend = os.environ.get('ST_DIST_BACKEND', 'nccl')
+    if os.environ.get('ST_SHARE_GPU'):
+      local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
   assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus)
   dev = torch.device('cuda', local_rank)
   torch.cuda.set_device(dev)
@@ -215,6 +223,16 @@ def main():
     elapsed = float(t[0])
   eng.check_ctc_status()
   loss = float(eng.loss.mean())
+  replicas_identical = None
+  if world > 1:
+    # data-parallel invariant: every rank applied the same averaged gradient to the same weights, so the
+    # replicas must still be bit-identical (checked outside the timed region: two small all-reduces)
+    p64 = eng.params.double()
+    digest = torch.stack([p64.sum(), (p64 * p64).sum(), p64[::4097].abs().sum()])
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    replicas_identical = bool(torch.equal(lo, hi))
 
   if rank == 0:
     ms = elapsed / args.steps * 1e3
@@ -228,11 +246,13 @@ def main():
         'data': 'synthetic',
         'config': {'workload': ('configs[3] arithmetic: data-parallel training step, batch {} per GPU of {:g} s synthetic clips, '
                                 '{}-mel, bf16 activations / fp32 CTC' if eng.conv_mode == 'bf16' else
-                                'configs[1]: 1xMI355X training step, batch {} of {:g} s synthetic clips, {}-mel, '
-                                'default Wav2Letter depth, fp32').format(args.batch, args.seconds, args.mels),
+                                'configs[1]: {}xMI355X training step, batch {} per GPU of {:g} s synthetic clips, {}-mel, '
+                                'default Wav2Letter depth, fp32').format(*(([] if eng.conv_mode == 'bf16' else [world]) +
+                                                                           [args.batch, args.seconds, args.mels])),
                    'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world,
                    'allreduce': reducer.transport if reducer else None},
         'final_avg_loss': round(loss, 4),
+        'replicas_identical': replicas_identical,
         'step_tflops_algorithmic': round(step_gflop / ms, 2),
     }
     out['roofline'] = measure_dominant_kernel(eng, args.batch)

@@ -244,3 +244,65 @@ def test_forward_graph_replays_bit_exactly(dev, mode):
   eager = eng.logits_time_major().clone()
   eng.forward_graph()
   assert torch.equal(eng.logits_time_major(), eager)
+
+
+DP_GPU_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ST_ROOT"])
+from tests import workloads as WL
+from speecht_amd.engine import Wav2LetterEngine
+from speecht_amd.data_parallel import GradientAllReducer, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks drive cuda:0
+layers = WL.w2l_layers(16, width=40, fc=72)
+params = WL.xavier_params(layers, seed=3, bias_range=0.05)
+x, seq, labels = WL.make_batch([120, 120, 97, 64, 120, 33], 16, seed=4)      # global batch 6, padded to 120
+lo, hi = shard_range(len(labels), rank, world)
+
+def run(eng, xs, ss, ls, reducer, steps=3):
+  for _ in range(steps):
+    eng.load_batch(xs, ss)
+    eng.set_labels(ls)
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / len(labels))                              # 1 / GLOBAL batch
+    eng.backward(reducer.on_layer_done if reducer else None)
+    if reducer:
+      reducer.finish()
+    eng.apply_update(1e-3, 5.0)
+  torch.cuda.synchronize()
+  return eng.params.clone()
+
+eng = Wav2LetterEngine(layers, device="cuda:0")
+eng.set_weights(params)
+red = GradientAllReducer(eng.grads, eng.layer_ranges)
+mine = run(eng, x[lo:hi], seq[lo:hi], labels[lo:hi], red)
+# replicas bit-identical
+gathered = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(gathered, mine)
+assert all(torch.equal(gathered[0], g) for g in gathered), "replicas diverged"
+# and equal to one process stepping on the whole batch (same mean gradient; fp32 summation order differs)
+solo = Wav2LetterEngine(layers, device="cuda:0")
+solo.set_weights(params)
+ref = run(solo, x, seq, labels, None)
+err = float((mine - ref).abs().max())
+start = Wav2LetterEngine(layers, device="cuda:0"); start.set_weights(params)
+step = float((ref - start.params).abs().max())
+assert step > 1e-3 and err < 2e-3 * step, (err, step)
+dist.destroy_process_group()
+print("rank", rank, "ok", err, step)
+'''
+
+
+def test_data_parallel_two_ranks_on_one_gpu_match_single_process(dev, tmp_path):
+  """world_size 2 (gloo transport, both ranks on cuda:0) through the real kernels: per-layer all-reduce hooked
+  into the backward, three Adam steps -- replicas stay bit-identical and land where a single process stepping on
+  the concatenated batch lands (the same mean gradient up to fp32 summation order)."""
+  script = tmp_path / 'dp_gpu_worker.py'
+  script.write_text(DP_GPU_WORKER)
+  env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29613', WORLD_SIZE='2')
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT) for r in range(2)]
+  outs = [p.communicate(timeout=400)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o)

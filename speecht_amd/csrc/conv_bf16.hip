@@ -113,35 +113,65 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
 
 // bf16 source (bf16-activation mode): dst[c][b * tq + j] = src[b][row0 + step * j][c] for j < rows, c < c_pitch;
 // zero for every other (c < c_rows, j < tq), so the GEMM never meets stale bits.
-// step 2 de-interleaves the frames of a stride-2 layer's input into two phase planes (one launch each).
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int rows, int row0,
-                                                             int step, int t_pitch, int c_pitch, int c_rows, int tq,
-                                                             unsigned short* __restrict__ dst) {
+// step 2 de-interleaves the frames of a stride-2 layer's input into two phase planes (one job each).
+// One launch serves all operands of a filter gradient (the phase planes of x, then dz): the jobs' channel tiles
+// are stacked along blockIdx.y.  zero_tail: 4096 elements behind a plane that shifted taps may read.
+struct TransposeJob {
+  const unsigned short* src;
+  unsigned short* dst;
+  unsigned short* zero_tail;
+  int rows, row0, step, t_pitch, c_pitch, c_rows, y_tiles;
+};
+struct TransposeJobs {
+  TransposeJob job[3];
+  int n, tq;
+  long pitch;                                          // row pitch of the transposed planes, >= batch * tq
+};
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(TransposeJobs js) {
   // 64 frames x 64 channels per workgroup, 8-byte global accesses on both sides
   typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
   __shared__ unsigned short tile[64][66];
+  int ty = blockIdx.y, k = 0;
+  while (k + 1 < js.n && ty >= js.job[k].y_tiles) ty -= js.job[k++].y_tiles;
+  const TransposeJob jb = js.job[k];
+  const int tq = js.tq;
   const int b = blockIdx.z;
-  const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int j0 = blockIdx.x * 64, c0 = ty * 64;
   const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
-  const unsigned short* s = src + ((long)b * t_pitch + row0) * c_pitch;
+  if (jb.zero_tail && blockIdx.x == 0 && ty == 0 && b == 0) {
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    reinterpret_cast<u16x8*>(jb.zero_tail)[threadIdx.x] = z;
+    reinterpret_cast<u16x8*>(jb.zero_tail)[256 + threadIdx.x] = z;
+  }
+  const unsigned short* s = jb.src + ((long)b * jb.t_pitch + jb.row0) * jb.c_pitch;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int r = it * 16 + r16, c = c0 + q * 4;
     u16x4 v = {0, 0, 0, 0};
-    if (j0 + r < rows && c < c_pitch) v = *reinterpret_cast<const u16x4*>(s + (long)(j0 + r) * step * c_pitch + c);
+    if (j0 + r < jb.rows && c < jb.c_pitch) v = *reinterpret_cast<const u16x4*>(s + (long)(j0 + r) * jb.step * jb.c_pitch + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[r][q * 4 + e] = v[e];
   }
   __syncthreads();
-  const long row_len = (long)gridDim.z * tq;
+  const long row_len = js.pitch;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int c = c0 + it * 16 + r16, j = j0 + q * 4;
-    if (c < c_rows && j < tq) {                       // zeros outside the source
+    if (c < jb.c_rows && j < tq) {                    // zeros outside the source
       u16x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = tile[q * 4 + e][it * 16 + r16];
-      *reinterpret_cast<u16x4*>(dst + (size_t)c * row_len + (size_t)b * tq + j) = v;
+      *reinterpret_cast<u16x4*>(jb.dst + (size_t)c * row_len + (size_t)b * tq + j) = v;
+    }
+  }
+  // the pad behind the last utterance of every row (shifted taps read into it)
+  const int pad = (int)(row_len - (long)gridDim.z * tq);
+  if (pad > 0 && blockIdx.x == 0 && b == (int)gridDim.z - 1) {
+    for (int i = threadIdx.x; i < 64 * (pad / 4); i += 256) {
+      const int c = c0 + i / (pad / 4), e = (i % (pad / 4)) * 4;
+      if (c < jb.c_rows) *reinterpret_cast<u16x4*>(jb.dst + (size_t)c * row_len + (size_t)gridDim.z * tq + e) = u16x4{0, 0, 0, 0};
     }
   }
 }
@@ -568,9 +598,10 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const float* __restr
 }
 
 // bias gradient from the reduction-major copy of dz: dbias[n] = sum_r dzt[n][r] (fp32 accumulation)
-__global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restrict__ dzt, long red, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restrict__ dzt, long red, long pitch,
+                                                           float* __restrict__ out) {
   __shared__ float part[256];
-  const __bf16* row = dzt + (size_t)blockIdx.x * red;
+  const __bf16* row = dzt + (size_t)blockIdx.x * pitch;
   float acc = 0.f;
   for (long r = (long)threadIdx.x * 8; r < red; r += 256 * 8) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + r);
@@ -744,23 +775,24 @@ int conv_bwd_data(const st_tensor3* dz, const void* dz_planes, const void* wt_pl
 template <int NP>
 int conv_bwd_filter(const void* xt_planes, size_t xt_plane, long xt_phase_stride, int phases, const void* dzt_planes,
                     int batch, int tq, int width, int cin_pitch, int x_first_row, int cout, float* dpacked, int splits,
-                    float* slabs, hipStream_t s) {
+                    float* slabs, hipStream_t s, long pitch = 0) {
   X6Params p{};
   const long red = (long)batch * tq;                   // reduction length
+  if (pitch == 0) pitch = red;                         // elements between consecutive rows of the transposed operands
   p.A = reinterpret_cast<const __bf16*>(xt_planes);
   p.a_plane = xt_plane;
   p.amap.frames = cin_pitch;                           // output row k = w * cin_pitch + c
   p.amap.batch_stride = 1;                             // a tap shifts the window by one (phase) frame
-  p.amap.row_stride = (int)red;                        // channel c selects the plane row
+  p.amap.row_stride = (int)pitch;                      // channel c selects the plane row
   p.amap.row0 = x_first_row;
   p.amap.phase_shift = phases == 2 ? 1 : 0;
   p.amap.phase_mask = phases - 1;
   p.amap.phase_stride = xt_phase_stride;
   p.Np = npad_of(cout);
   p.Kvalid = (int)red;
-  p.Kp = (int)red;
+  p.Kp = (int)pitch;
   p.B = reinterpret_cast<const __bf16*>(dzt_planes);
-  p.b_plane = (size_t)p.Np * red;
+  p.b_plane = (size_t)p.Np * pitch;
   p.M = width * cin_pitch;
   p.cmap.frames = p.M;
   p.cmap.row_stride = p.Np;
@@ -783,7 +815,7 @@ int conv_bwd_filter(const void* xt_planes, size_t xt_plane, long xt_phase_stride
 // geometry of the filter-gradient workspace of the bf16-activation path
 struct WgradPlan {
   int tq, phases, splits, n_pad;
-  long red;
+  long red, pitch;
   size_t xt_phase_elems, xt_bytes, dzt_bytes, slab_bytes;
 };
 WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int stride, int x_first_row) {
@@ -793,13 +825,15 @@ WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int s
   w.tq = (int)st::round_up(std::max(x_rows, dz.frames), 32);
   w.red = (long)x.batch * w.tq;
   w.n_pad = npad_of(dz.channels);
-  w.xt_phase_elems = (size_t)x.c_pitch * w.red + 4096;           // slack: the last taps read past the last row
+  w.pitch = w.red;      // a padded row pitch (64..520 elements, against power-of-two strides) measured 4-14 % slower
+  w.xt_phase_elems = (size_t)x.c_pitch * w.pitch + 4096;         // slack: the last taps read past the last row
   w.xt_bytes = st::round_up(w.xt_phase_elems * stride * 2, 256);
-  w.dzt_bytes = st::round_up((size_t)w.n_pad * w.red * 2, 256);
+  w.dzt_bytes = st::round_up((size_t)w.n_pad * w.pitch * 2, 256);
   const long M = (long)width * x.c_pitch;
   const long tiles = st::ceil_div((int)M, 128) * (long)st::ceil_div(w.n_pad, 128);
   const int stages = (int)((w.red + 63) / 64);
-  w.splits = tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(st::ceil_div(512, (int)tiles), stages / 8));
+  static const int forced = getenv("ST_BF16_WGRAD_SPLITS") ? atoi(getenv("ST_BF16_WGRAD_SPLITS")) : 0;
+  w.splits = forced ? forced : tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(st::ceil_div(512, (int)tiles), stages / 8));
   w.slab_bytes = w.splits > 1 ? (size_t)w.splits * M * w.n_pad * 4 : 0;
   return w;
 }
@@ -992,27 +1026,36 @@ int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const
   unsigned short* xt = reinterpret_cast<unsigned short*>(workspace);
   unsigned short* dzt = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + w.xt_bytes);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.xt_bytes + w.dzt_bytes);
-  // reduction-major copies (every element of [c][b*tq + j] is written: zeros where the source has no row)
+  // reduction-major copies (every element of [c][b*tq + j] is written: zeros where the source has no row), one launch
+  TransposeJobs js{};
+  js.tq = w.tq;
+  js.pitch = w.pitch;
+  int y_tiles = 0;
   for (int ph = 0; ph < stride; ++ph) {
-    const int rows = st::ceil_div(x->t_pitch - first - ph, stride);
-    dim3 grid(st::ceil_div(w.tq, 64), st::ceil_div(x->c_pitch, 64), x->batch);
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x_bf16),
-                       rows, first + ph, stride, x->t_pitch, x->c_pitch, x->c_pitch, w.tq, xt + ph * w.xt_phase_elems);
-    if (hipMemsetAsync(xt + ph * w.xt_phase_elems + (size_t)x->c_pitch * w.red, 0, 4096 * 2, s) != hipSuccess) {
-      st::set_error("conv bwd-filter bf16: memset failed");
-      return ST_ELAUNCH;
-    }
+    TransposeJob& j = js.job[js.n++];
+    j.src = reinterpret_cast<const unsigned short*>(x_bf16);
+    j.dst = xt + ph * w.xt_phase_elems;
+    j.zero_tail = j.dst + (size_t)x->c_pitch * w.pitch;
+    j.rows = st::ceil_div(x->t_pitch - first - ph, stride);
+    j.row0 = first + ph; j.step = stride; j.t_pitch = x->t_pitch; j.c_pitch = x->c_pitch; j.c_rows = x->c_pitch;
+    j.y_tiles = st::ceil_div(x->c_pitch, 64);
+    y_tiles += j.y_tiles;
   }
   {
-    dim3 grid(st::ceil_div(w.tq, 64), st::ceil_div(w.n_pad, 64), dz->batch);
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(dz_bf16),
-                       dz->frames, dz->halo, 1, dz->t_pitch, dz->c_pitch, w.n_pad, w.tq, dzt);
+    TransposeJob& j = js.job[js.n++];
+    j.src = reinterpret_cast<const unsigned short*>(dz_bf16);
+    j.dst = dzt;
+    j.rows = dz->frames; j.row0 = dz->halo; j.step = 1; j.t_pitch = dz->t_pitch; j.c_pitch = dz->c_pitch; j.c_rows = w.n_pad;
+    j.y_tiles = st::ceil_div(w.n_pad, 64);
+    y_tiles += j.y_tiles;
   }
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(st::ceil_div(w.tq, 64), y_tiles, x->batch), dim3(256), 0, s, js);
   if (int e = st::check_launch("transpose_bf16")) return e;
   if (int e = conv_bwd_filter<1>(xt, 0, (long)w.xt_phase_elems, stride, dzt, x->batch, w.tq, width, x->c_pitch, 0,
-                                 dz->channels, dpacked, w.splits, slabs, s))
+                                 dz->channels, dpacked, w.splits, slabs, s, w.pitch))
     return e;
-  hipLaunchKernelGGL(row_sum_bf16_kernel, dim3(w.n_pad), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dzt), w.red, dbias);
+  hipLaunchKernelGGL(row_sum_bf16_kernel, dim3(w.n_pad), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dzt), w.red, w.pitch,
+                     dbias);
   return st::check_launch("row_sum_bf16");
 }
 

@@ -60,30 +60,31 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=True):
         ids_out[i] = ids[row]
     return ids_out, [vocabulary.ids_to_sentence(s) for s in ids_out]
 
-  stager = _Stager(engine.device, features, lengths, buckets)
-  stager.start()
-  pending = None
-
   def collect(handle, idx):
     for row, ids in enumerate(handle.result()):
       ids_out[idx[row]] = ids
 
-  try:
-    for idx in buckets:
-      staged = stager.get()
-      engine.load_batch(staged, [lengths[i] for i in idx])
-      engine.forward()
-      handle = engine.greedy_decode_async()
-      if pending is not None:
-        collect(*pending)
-      pending = (handle, idx)
-    collect(*pending)
-  finally:
-    stager.close()
+  with _PIPELINE_LOCK:               # the pinned staging ring of a device serves one pipeline at a time
+    stager = _Stager(engine.device, features, lengths, buckets)
+    stager.start()
+    pending = None
+    try:
+      for idx in buckets:
+        staged = stager.get()
+        engine.load_batch(staged, [lengths[i] for i in idx])
+        engine.forward()
+        handle = engine.greedy_decode_async()
+        if pending is not None:
+          collect(*pending)
+        pending = (handle, idx)
+      collect(*pending)
+    finally:
+      stager.close()
   return ids_out, [vocabulary.ids_to_sentence(s) for s in ids_out]
 
 
 _PINNED = {}       # (device, depth) -> ring of pinned staging buffers, grow-only
+_PIPELINE_LOCK = threading.Lock()
 
 
 class _Stager(threading.Thread):

@@ -2,14 +2,17 @@
 """bench.py -- utterances/sec of one Wav2Letter TRAINING step on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without WORLD_SIZE in the environment: re-launches itself under torch.distributed.run, one rank per
+  GPU over RCCL; under an external torch.distributed.run it just joins the job)
 
 Workload (BASELINE.json configs[1]): per GPU a batch of 32 synthetic 10 s @ 16 kHz
 utterances = 1001 frames x 80 mel features (z-normalised synthetic features; the reference
 extracts features offline, preprocessing.py:212-241), 150-character labels, default Wav2Letter
 depth (speech_model.py:275-295), fp32.  One step = batch -> 11-layer conv forward -> CTC loss +
-gradient -> back-prop -> (gradient all-reduce) -> global-norm clip -> TF-Adam, inputs resident in
-HBM.  Weak scaling: every rank processes its own 32 utterances; value = N*32 / max-over-ranks time.
+gradient -> back-prop -> (gradient all-reduce) -> global-norm clip -> TF-Adam.  The timed step also carries what
+SURVEY 8(d) counts into it: the H2D copy of the padded feature batch from pinned host memory (on a copy stream,
+double-buffered, so batch k+1 travels while batch k computes) and the upload of the labels.
+Weak scaling: every rank processes its own 32 utterances; value = N*32 / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, HIP
 event timing) and `cpu_baseline` (the numpy oracle timed on the host cores, N=1 only).
@@ -17,6 +20,8 @@ event timing) and `cpu_baseline` (the numpy oracle timed on the host cores, N=1 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,8 +48,23 @@ def conv_flops(engine, batch):
   return out
 
 
-def train_step(eng, x_dev, reducer, lr, global_batch):
-  eng.X[0].interior().copy_(x_dev)
+class HostFeed:
+  """The input side of a step: pinned host batch -> HBM (async, double-buffered) + label upload."""
+
+  def __init__(self, eng, x, seq_lens, labels):
+    self.eng, self.seq_lens, self.labels = eng, seq_lens, labels
+    self.x_pinned = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).pin_memory()
+    self.staged = eng.stage_host_batch(self.x_pinned)
+
+  def next(self):
+    cur = self.staged
+    self.staged = self.eng.stage_host_batch(self.x_pinned)      # H2D of the next step's batch, behind this step's kernels
+    self.eng.load_batch(cur, self.seq_lens)
+    self.eng.set_labels(self.labels)
+
+
+def train_step(eng, feed, reducer, lr, global_batch):
+  feed.next()
   eng.forward()
   eng.ctc_loss_grad(1.0 / global_batch)
   eng.backward(reducer.on_layer_done if reducer else None)
@@ -154,6 +174,85 @@ def cpu_baseline(n_mels, frames, utts=2, steps=2):
                      'BLAS threads = host cores)'.format(utts, steps))
 
 
+def cpu_baseline_torch(n_mels, frames, batch, budget_s=25.0):
+  """The same training step with torch CPU ops (oneDNN convolutions + native CTC, fp32, all host cores), the
+  fastest CPU formulation available here (TF1 cannot be installed): median of 3 steps after one warm-up step.
+  The batch is the full 32 utterances unless a probe step says three of them would not fit the time budget."""
+  from tests import torch_ref as TR
+  layers = WL.w2l_layers(n_mels)
+  params = WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32)
+  torch.set_num_threads(os.cpu_count())
+  x, sl, labels = WL.make_batch([frames] * batch, n_mels, seed=0)
+  x = x.astype(np.float32)
+  trainer = TR.TorchCpuTrainer(params, layers, lr=1e-4)
+  probe = min(4, batch)
+  trainer.step(x[:probe], sl[:probe], labels[:probe])               # warm-up (thread pool, primitive caches)
+  t0 = time.time()
+  trainer.step(x[:probe], sl[:probe], labels[:probe])
+  per_utt = (time.time() - t0) / probe
+  utts = batch
+  while utts > probe and 4 * utts * per_utt > budget_s:
+    utts //= 2
+  if utts != probe:
+    trainer.step(x[:utts], sl[:utts], labels[:utts])                # warm-up at the timed shape
+  times = []
+  for _ in range(3):
+    t0 = time.time()
+    trainer.step(x[:utts], sl[:utts], labels[:utts])
+    times.append(time.time() - t0)
+  med = sorted(times)[1]
+  return dict(value=round(utts / med, 3), unit='utterances/s', cores=os.cpu_count(), kind='port',
+              sample='batch of {} x 10 s utterances, median of 3 full training steps (forward + CTC + backward + '
+                     'clip + TF-Adam) of tests/torch_ref.py: torch {} CPU ops (oneDNN conv1d, native ctc_loss), fp32, '
+                     '{} threads; CPU restatement of the reference path (TF1 not installable)'.format(
+                         utts, torch.__version__, torch.get_num_threads()),
+              step_seconds=[round(t, 3) for t in times])
+
+
+def parity_on_bench_inputs(eng, x, seq_lens, labels, rows=(0, -1)):
+  """|CTC loss - oracle| and max|logit - oracle| on the bench inputs (BASELINE metric): the device
+  runs forward + CTC on the full batch with the initial weights, the float64 oracle on a 2-utterance slice of the
+  same batch (utterances are independent: nothing is masked, so a row's logits depend on that row only)."""
+  from oracle import w2l_oracle as O
+  rows = [r % len(seq_lens) for r in rows]
+  eng.load_batch(x, seq_lens)
+  eng.set_labels(labels)
+  eng.forward()
+  eng.ctc_loss_grad(1.0 / len(seq_lens))
+  torch.cuda.synchronize()
+  eng.check_ctc_status()
+  got = eng.logits_time_major().cpu().numpy()[:, rows]
+  dec, _ = eng.greedy_decode()
+  params64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in eng.get_weights()]
+  layers = [(l.width, l.stride, l.cin, l.cout, l.relu) for l in eng.layers]
+  ref = O.wav2letter_forward(np.asarray(x, np.float32)[rows].astype(np.float64), params64, layers)
+  loss_ref, _ = O.ctc_loss_and_grad(ref, [labels[r] for r in rows], np.asarray(seq_lens)[rows] // 2)
+  ref_dec, _ = O.ctc_greedy_decode(ref, np.asarray(seq_lens)[rows] // 2)
+  loss_dev = eng.loss.cpu().numpy()[rows].astype(np.float64)
+  return dict(rows=rows, max_logit_err=float(np.max(np.abs(got - ref))),
+              ctc_loss_delta=float(np.max(np.abs(loss_dev - loss_ref))),
+              ctc_loss_delta_rel=float(np.max(np.abs(loss_dev - loss_ref) / np.abs(loss_ref))),
+              ctc_loss_oracle=[round(float(v), 4) for v in loss_ref],
+              greedy_strings_equal=bool([dec[r] for r in rows] == ref_dec),
+              oracle='oracle/w2l_oracle.py float64 on utterances {} of the bench batch, initial weights'.format(rows))
+
+
+def free_port():
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    return sk.getsockname()[1]
+
+
+def self_launch(args):
+  """``python bench.py --gpus N`` with no torch.distributed environment: start N ranks of this script (one per
+  GPU, RCCL) under torch.distributed.run on this node and hand its output through."""
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -171,6 +270,8 @@ def main():
                   help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -197,9 +298,8 @@ def main():
   eng = Wav2LetterEngine(layers, device=dev, conv_mode=args.conv_mode)
   eng.set_weights(WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32))   # same replica everywhere
   x, seq_lens, labels = WL.make_batch([frames] * args.batch, args.mels, seed=100 + rank)
-  eng.load_batch(x, seq_lens)
-  eng.set_labels(labels)
-  x_dev = torch.as_tensor(x, dtype=torch.float32).to(dev)
+  parity = parity_on_bench_inputs(eng, x, seq_lens, labels) if rank == 0 else None
+  feed = HostFeed(eng, x, seq_lens, labels)
   reducer = GradientAllReducer(eng.grads, eng.layer_ranges, force=args.force_allreduce, transport=args.allreduce) if (world > 1 or args.force_allreduce) else None
   global_batch = args.batch * world
   lr = 1e-4
@@ -210,21 +310,28 @@ def main():
     torch.cuda.synchronize()
 
   for _ in range(args.warmup):
-    train_step(eng, x_dev, reducer, lr, global_batch)
+    train_step(eng, feed, reducer, lr, global_batch)
   sync()
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times for the median
   t0 = time.perf_counter()
-  for _ in range(args.steps):
-    train_step(eng, x_dev, reducer, lr, global_batch)
+  marks[0].record()
+  for k in range(args.steps):
+    train_step(eng, feed, reducer, lr, global_batch)
+    marks[k + 1].record()
   sync()
   elapsed = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
+  step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+  median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+  rank_ms = [elapsed / args.steps * 1e3]
   eng.check_ctc_status()
   loss = float(eng.loss.mean())
-  replicas_identical = None
+  replicas_identical, comm = None, None
   if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    rank_ms = [float(e[0]) / args.steps * 1e3 for e in every]
+    elapsed = max(float(e[0]) for e in every)
     # data-parallel invariant: every rank applied the same averaged gradient to the same weights, so the
     # replicas must still be bit-identical (checked outside the timed region: two small all-reduces)
     p64 = eng.params.double()
@@ -233,6 +340,28 @@ def main():
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     replicas_identical = bool(torch.equal(lo, hi))
+    del p64
+    # also outside the timed region (and after the digest: un-reduced steps let the replicas drift): the same
+    # steps without the exchange, and the exchange alone, to see how much of it the back-prop kernels hide
+    reps = max(3, min(10, args.steps))
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+      train_step(eng, feed, None, lr, global_batch)
+    sync()
+    compute_ms = (time.perf_counter() - t1) / reps * 1e3
+    t1 = time.perf_counter()
+    for _ in range(reps):
+      for i in reversed(range(len(eng.layers))):
+        reducer.on_layer_done(i)
+      reducer.finish()
+    sync()
+    allreduce_ms = (time.perf_counter() - t1) / reps * 1e3
+    c = torch.tensor([compute_ms, allreduce_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX)
+    comm = dict(compute_only_ms_per_step=round(float(c[0]), 3), allreduce_alone_ms=round(float(c[1]), 3),
+                exposed_comm_ms=round(max(0.0, elapsed / args.steps * 1e3 - float(c[0])), 3),
+                gradient_mb=round(eng.n_flat * 4 / 1e6, 1), buckets=len(reducer.buckets))
 
   if rank == 0:
     ms = elapsed / args.steps * 1e3
@@ -242,6 +371,9 @@ def main():
         'metric': 'utterances/sec (training step, 10 s@16 kHz, batch 32)',
         'value': round(global_batch / (elapsed / args.steps), 2), 'unit': 'utterances/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+        'ms_per_step_median': round(median_ms, 3),
+        'step_includes': 'pinned H2D of the feature batch (copy stream, double-buffered) + label upload + forward + '
+                         'CTC loss/grad + back-prop' + (' + gradient all-reduce' if reducer else '') + ' + clip + Adam',
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x6': 'f32 (bf16x6 split)', 'bf16': 'bf16 activations, f32 accumulate/CTC/Adam'}[eng.conv_mode],
         'data': 'synthetic',
         'config': {'workload': ('configs[3] arithmetic: data-parallel training step, batch {} per GPU of {:g} s synthetic clips, '
@@ -252,13 +384,17 @@ def main():
                    'global_batch': global_batch, 'frames': frames, 'parallelism': 'dp%d' % world,
                    'allreduce': reducer.transport if reducer else None},
         'final_avg_loss': round(loss, 4),
+        'ctc_loss_delta': parity['ctc_loss_delta'], 'max_logit_err': parity['max_logit_err'], 'parity': parity,
         'replicas_identical': replicas_identical,
+        'per_rank_ms_per_step': [round(v, 3) for v in rank_ms], 'comm': comm,
         'step_tflops_algorithmic': round(step_gflop / ms, 2),
     }
     out['roofline'] = measure_dominant_kernel(eng, args.batch)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
     if out['roofline'] and os.path.exists(traffic_file):
       out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
+      out['roofline']['traffic_source'] = ('profiles/traffic.json: TCC_EA0_RDREQ/WRREQ PMC passes of rocprofv3 over this '
+                                           'command (scripts/gpu_traffic.sh); counters cannot be read from inside the run')
     util_file = os.path.join(ROOT, 'profiles', 'mfma_util.json')
     if out['roofline'] and os.path.exists(util_file):      # PMC pass (scripts/gpu_mfma_util.sh), padded work included
       out['roofline']['mfma_busy_pmc'] = json.load(open(util_file)).get('gemm_nn_kernel<128, 128, 2, 2, 0, true>', {}).get('mfma_busy_frac_at_2p4ghz')
@@ -278,14 +414,13 @@ def main():
         alt = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
         alt.params.copy_(eng.params)
         alt.mark_weights_changed()
-        alt.load_batch(x, seq_lens)
-        alt.set_labels(labels)
+        alt_feed = HostFeed(alt, x, seq_lens, labels)
         for _ in range(args.warmup):
-          train_step(alt, x_dev, None, lr, global_batch)
+          train_step(alt, alt_feed, None, lr, global_batch)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-          train_step(alt, x_dev, None, lr, global_batch)
+          train_step(alt, alt_feed, None, lr, global_batch)
         torch.cuda.synchronize()
         alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
         out[key] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),
@@ -294,7 +429,9 @@ def main():
         del alt
         torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline(args.mels, frames)
+      # two CPU restatements of the reference path on this box's host cores; the faster one is `cpu_baseline`
+      out['cpu_baseline'] = cpu_baseline_torch(args.mels, frames, args.batch)
+      out['cpu_baseline_numpy_oracle'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))
   if dist.is_initialized():
     dist.destroy_process_group()

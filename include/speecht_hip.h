@@ -49,6 +49,19 @@ typedef struct st_tensor3 {
 int st_version(void);
 const char* st_last_error(void);
 
+/* ---- diagnostics (no reference counterpart) ----------------------------------------------
+ * Launch trace: between st_trace_begin() and st_trace_end() every entry point appends one text line per
+ * kernel launch naming the variant and split policy it chose (e.g. "gemm_nn<128,128,2,2,fast> epi=1
+ * splits=2 M=16032 Np=256 Kp=64512").  st_trace_end copies the text to a HOST buffer (truncating) and
+ * returns the bytes needed including the terminator.  Used by the parity tests to assert which kernels a
+ * full-size step really ran.
+ * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "mel_variant"); value 0 restores the library's own policy.
+ * The launch path never reads the environment. */
+int st_trace_begin(void);
+size_t st_trace_end(char* host_buf, size_t capacity);
+int st_set_tuning(const char* name, int value);
+
 /* ---- filter packing -------------------------------------------------------------------
  * Reference filters are [W, Cin, Cout] (speech_model.py:148-151; the `export --weights`
  * layout, exporting.py:30-40).  The kernels use the row-major GEMM operand

@@ -23,6 +23,9 @@ _T3P = POINTER(Tensor3)
 _SIGNATURES = {
     'st_version': (c_int, []),
     'st_last_error': (c_char_p, []),
+    'st_trace_begin': (c_int, []),
+    'st_trace_end': (c_size_t, [c_char_p, c_size_t]),
+    'st_set_tuning': (c_int, [c_char_p, c_int]),
     'st_packed_dims': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'st_pack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_unpack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -127,3 +130,26 @@ def check(code, what):
 def call(name, *args):
   """Invoke an int-returning entry point and raise on a non-zero status."""
   check(getattr(load(), name)(*args), name)
+
+
+class launch_trace:
+  """``with launch_trace() as tr: ...`` -> ``tr.lines``: one line per kernel launch the library made inside
+  the block, naming the variant and split policy (st_trace_begin / st_trace_end)."""
+
+  def __enter__(self):
+    load().st_trace_begin()
+    self.lines = []
+    return self
+
+  def __exit__(self, *exc):
+    lib = load()
+    need = lib.st_trace_end(None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    lib.st_trace_end(buf, need)
+    self.lines = [l for l in buf.value.decode().split('\n') if l]
+    return False
+
+
+def set_tuning(name, value):
+  """Performance-experiment override (0 = library policy); see include/speecht_hip.h."""
+  call('st_set_tuning', name.encode(), int(value))

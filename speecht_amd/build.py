@@ -16,13 +16,29 @@ def sources():
   return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+HASH_PATH = os.path.join(LIB_DIR, 'libspeecht_hip.sha256')
+
+
+def source_digest():
+  """sha256 over the flags and the bytes of every source/header the library is built from.  The shipped .so is
+  reused only when the digest recorded next to it at link time matches -- file times say nothing after a copy."""
+  import hashlib
+  h = hashlib.sha256(' '.join(FLAGS).replace(ROOT, '').encode())
+  deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+  inc = os.path.join(ROOT, 'include')
+  deps += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h'))
+  for d in deps:
+    h.update(os.path.basename(d).encode())
+    with open(d, 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()
+
+
 def _stale():
-  if not os.path.exists(LIB_PATH):
+  if not (os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH)):
     return True
-  t = os.path.getmtime(LIB_PATH)
-  deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-  deps.append(os.path.join(ROOT, 'include', 'speecht_hip.h'))
-  return any(os.path.getmtime(d) > t for d in deps)
+  with open(HASH_PATH) as f:
+    return f.read().strip() != source_digest()
 
 
 def build_library(force=False, verbose=True):
@@ -48,6 +64,8 @@ def build_library(force=False, verbose=True):
   if verbose:
     print(' '.join(cmd), file=sys.stderr)
   subprocess.check_call(cmd)
+  with open(HASH_PATH, 'w') as f:
+    f.write(source_digest() + '\n')
   return LIB_PATH
 
 

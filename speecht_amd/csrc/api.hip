@@ -1,4 +1,9 @@
-// libspeecht_hip.so: version + thread-local error text.
+// libspeecht_hip.so: version, thread-local error text, launch trace and tuning overrides (diagnostics).
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <string.h>
+
 #include "st_common.h"
 
 namespace st {
@@ -9,9 +14,62 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- launch trace: which kernel variant / split policy a call took (tests assert on it) ----
+static std::atomic<int> g_trace_on{0};
+static std::mutex g_trace_mu;
+static std::string g_trace;
+bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
+void trace(const char* fmt, ...) {
+  if (!trace_on()) return;
+  char line[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(line, sizeof(line), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lock(g_trace_mu);
+  if (g_trace.size() < (1u << 20)) { g_trace += line; g_trace += '\n'; }
+}
+
+// ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
+// the launch path reads plain ints (no environment look-ups).
+static const char* const kTuneNames[TUNE_COUNT] = {"gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm", "no_fast",
+                                                   "bf16_tile", "bf16_wgrad_splits", "mel_variant"};
+static std::atomic<int> g_tune[TUNE_COUNT];
+int tuning(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 }  // namespace st
 
 extern "C" {
-int st_version(void) { return 100; }
+int st_version(void) { return 200; }
 const char* st_last_error(void) { return st::g_err; }
+
+int st_trace_begin(void) {
+  std::lock_guard<std::mutex> lock(st::g_trace_mu);
+  st::g_trace.clear();
+  st::g_trace_on.store(1);
+  return ST_OK;
+}
+
+size_t st_trace_end(char* host_buf, size_t capacity) {
+  st::g_trace_on.store(0);
+  std::lock_guard<std::mutex> lock(st::g_trace_mu);
+  const size_t need = st::g_trace.size() + 1;
+  if (host_buf && capacity > 0) {
+    const size_t n = need <= capacity ? need - 1 : capacity - 1;
+    memcpy(host_buf, st::g_trace.data(), n);
+    host_buf[n] = 0;
+  }
+  return need;
+}
+
+int st_set_tuning(const char* name, int value) {
+  ST_REQUIRE(name, "st_set_tuning: null name");
+  for (int i = 0; i < st::TUNE_COUNT; ++i)
+    if (!strcmp(name, st::kTuneNames[i])) {
+      st::g_tune[i].store(value);
+      return ST_OK;
+    }
+  st::set_error("st_set_tuning: unknown knob '%s'", name);
+  return ST_EINVAL;
+}
 }

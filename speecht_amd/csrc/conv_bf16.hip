@@ -621,10 +621,10 @@ __global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restr
 //   wide problems  -> 256 x 256 tile, 8 waves, LDS ring + ping-pong wave groups
 //                     (NP = 3: 16-deep stages, ring of 3; NP = 1: 32-deep stages, ring of 4)
 //   everything else -> 128 x 128 tile, 4 waves (NP = 3: 32-deep stages, 2 slots; NP = 1: 64-deep, ring of 4)
-// ST_BF16_TILE=128 forces the small tile (perf experiments).
+// st_set_tuning("bf16_tile", 128) forces the small tile (perf experiments).
 template <int NP>
 int launch_gemm(X6Params& p, hipStream_t s) {
-  static const int forced_tile = getenv("ST_BF16_TILE") ? atoi(getenv("ST_BF16_TILE")) : 0;
+  const int forced_tile = st::tuning(st::TUNE_BF16_TILE);
   if (p.splits < 1) p.splits = 1;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
   const bool wide = (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192;
@@ -633,6 +633,7 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   p.tiles_n = st::ceil_div(p.Np, BT);
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
+  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps);
   const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
 #define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
   do {                                                                                                         \
@@ -832,7 +833,7 @@ WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int s
   const long M = (long)width * x.c_pitch;
   const long tiles = st::ceil_div((int)M, 128) * (long)st::ceil_div(w.n_pad, 128);
   const int stages = (int)((w.red + 63) / 64);
-  static const int forced = getenv("ST_BF16_WGRAD_SPLITS") ? atoi(getenv("ST_BF16_WGRAD_SPLITS")) : 0;
+  const int forced = st::tuning(st::TUNE_BF16_WGRAD_SPLITS);
   w.splits = forced ? forced : tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(st::ceil_div(512, (int)tiles), stages / 8));
   w.slab_bytes = w.splits > 1 ? (size_t)w.splits * M * w.n_pad * 4 : 0;
   return w;

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(NNParams p, int ep
 // of today, 3.99 -> 3.75 ms (128.7 -> 136.8 TFLOP/s) including the slab epilogue; 3 splits leave a ragged round
 // (4.74 ms), 4 splits 3.87 ms.  (The first version of this kernel measured no gain: 4.31 vs 4.32 ms.)
 int nn_splits(int M, int Np, int Kp) {
-  static const int forced = getenv("ST_GEMM_SPLITS") ? atoi(getenv("ST_GEMM_SPLITS")) : 0;
+  const int forced = st::tuning(st::TUNE_GEMM_SPLITS);
   if (Np % 128) return 1;
   const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
   const int nk = Kp / BK;
@@ -751,7 +751,7 @@ int nn_splits(int M, int Np, int Kp) {
 // 2 s utterance: 1.18 ms unsplit, 0.355 ms with this policy (>= 8 tiles per slice 0.396, >= 2: 0.398, twice
 // the workgroups 0.363).
 int fwd_splits(int M, int Np, int nk) {
-  static const int forced = getenv("ST_FWD_SPLITS") ? atoi(getenv("ST_FWD_SPLITS")) : 0;
+  const int forced = st::tuning(st::TUNE_FWD_SPLITS);
   if (Np % 128) return 1;
   const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
   if (forced) return std::max(1, std::min(forced, nk));
@@ -767,7 +767,7 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     // operand bytes an XCD's L2 has to pull in: the activation rows of its M range (once per N column group)
     // and the filter panel of its N range (once per M row group)
     const double a_bytes = (double)p.M * p.cp * 4.0, b_bytes = (double)p.Kp * p.Np * 4.0;
-    static const int forced_gm = getenv("ST_XCD_GM") ? atoi(getenv("ST_XCD_GM")) : 0;
+    const int forced_gm = st::tuning(st::TUNE_XCD_GM);
     double best = 0.0;
     p.gm = 1;
     for (int gm = 1; gm <= 8; gm *= 2) {
@@ -784,6 +784,8 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.chunk = p.tm_per * p.tn_per;
   }
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
+  st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
+            FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
   if (p.splits > 1) {
@@ -794,13 +796,13 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
 }
 
 int run_nn(NNParams& p, int epi, hipStream_t s) {
-  static const int force = getenv("ST_GEMM_TILE") ? atoi(getenv("ST_GEMM_TILE")) : 0;   // perf experiments
+  const int force = st::tuning(st::TUNE_GEMM_TILE);   // perf experiments (st_set_tuning)
   if (p.Np % 128 == 0) {
     long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128);
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
-    else if ((tiles128 >= 192 || p.splits > 1) && p.cp % 32 == 0 && p.Kvalid % 32 == 0 && !getenv("ST_NO_FAST"))
+    else if ((tiles128 >= 192 || p.splits > 1) && p.cp % 32 == 0 && p.Kvalid % 32 == 0 && !st::tuning(st::TUNE_NO_FAST))
       launch_nn<128, 128, 2, 2, true>(p, epi, s);                                      // whole k-tiles only: unclamped DMA addresses
     else if (tiles128 >= 192 || p.splits > 1) launch_nn<128, 128, 2, 2>(p, epi, s);   // >= 3/4 of the CUs busy
     else launch_nn<64, 128, 2, 2>(p, epi, s);
@@ -1063,6 +1065,8 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   p.amap_batches = dz->batch;
   p.adv_b = 32 / dz->frames;
   p.adv_t = 32 % dz->frames;
+  st::trace("gemm_tn<%d> slabs=%d rows_per_slab=%d M=%d Kp=%d Np=%d", p.Np % 128 == 0 ? 128 : p.Np, used,
+            p.rows_per_split, p.M, p.Kp, p.Np);
   if (p.Np % 128 == 0) {
     p.tiles_n = p.Np / 128;
     hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);

@@ -114,6 +114,17 @@ class _PendingDecode:
     return [ids[b, :lens[b]].tolist() for b in range(self._batch)]
 
 
+class _StagedHostBatch:
+  """One of the engine's two H2D staging buffers: ``event`` = copy finished, ``consumed`` = the compute stream has
+  read it (``Wav2LetterEngine.stage_host_batch`` / ``load_batch``)."""
+
+  def __init__(self, tensor):
+    self.tensor = tensor
+    self.event = torch.cuda.Event()
+    self.consumed = torch.cuda.Event()
+    self.consumed.record()
+
+
 class Wav2LetterEngine:
   """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
 
@@ -398,15 +409,43 @@ class Wav2LetterEngine:
       stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
       stream.wait_event(inputs.event)              # H2D ran on the pipeline's copy stream
       inputs.tensor.record_stream(stream)          # keep the allocator from recycling it under the copy below
-      inputs = inputs.tensor
+      staged, inputs = inputs, inputs.tensor
+    else:
+      staged = None
     x = torch.as_tensor(inputs)
     B, T, C = x.shape
     assert C == self.layers[0].cin, 'input_size mismatch'
     self._ensure_shape(B, T)
     self.X[0].interior().copy_(x.to(torch.float32), non_blocking=True)
+    if staged is not None and hasattr(staged, 'consumed'):
+      staged.consumed.record(self._stream if self._stream is not None else torch.cuda.current_stream(self.device))
     self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
     # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
     self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32))
+
+  def stage_host_batch(self, x_host):
+    """Asynchronous H2D copy of a padded feature batch [B, T, C] (float32; a pinned torch tensor copies without
+    an intermediate host copy) on the engine's copy stream into one of two staging buffers in HBM.  Returns a
+    handle for ``load_batch``; the copy of batch k+1 overlaps the kernels of batch k.  A staging buffer is
+    re-used only after the compute stream has consumed it (event recorded by ``load_batch``)."""
+    if not hasattr(self, '_h2d'):
+      self._h2d = dict(stream=torch.cuda.Stream(self.device), slots=[None, None], turn=0)
+    h = self._h2d
+    h['turn'] ^= 1
+    x = torch.as_tensor(x_host)
+    if x.dtype != torch.float32:
+      x = x.to(torch.float32)
+    slot = h['slots'][h['turn']]
+    if slot is None or slot.tensor.shape != x.shape:
+      if slot is not None:
+        slot.consumed.synchronize()
+      slot = _StagedHostBatch(torch.empty(x.shape, dtype=torch.float32, device=self.device))
+      h['slots'][h['turn']] = slot
+    with torch.cuda.stream(h['stream']):
+      h['stream'].wait_event(slot.consumed)            # the compute stream is done reading this buffer
+      slot.tensor.copy_(x, non_blocking=True)
+      slot.event.record(h['stream'])
+    return slot
 
   def _upload_i32(self, values):
     """Small int32 host array -> device through a ring of pinned slots.  A hipMemcpyAsync from pageable memory

@@ -1,0 +1,131 @@
+"""Per-GPU shards of BASELINE configs[3] and configs[4] at their real sizes (what one of the 8 ranks runs).
+
+configs[3]: 8 x MI355X data-parallel training, global batch 256 -> one rank: B = 32 x 10 s, bf16 activations /
+            fp32 CTC.  Checked against the oracle run with the same storage model (oracle.bf16_round where the
+            device writes bf16) on the WHOLE shard: logits, per-utterance losses, all 22 gradient tensors.
+configs[4]: 8 x MI355X, 30 s utterances, batch 128 -> one rank: B = 16, T = 3001 (T' = 1501), forward + greedy +
+            prefix beam search (beam 16).  Logits against the float64 oracle on two rows; decoders against the
+            oracle decoders fed the device's own logits (so that ties cannot flip), all 16 rows greedy, 2 rows beam.
+The 8-rank exchange itself (RCCL) cannot run on a 1-GPU box; its control flow is covered by
+test_gpu_api.py::test_data_parallel_two_ranks_on_one_gpu_match_single_process and bench.py --gpus 2 (ST_SHARE_GPU).
+"""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as O
+from tests import workloads as WL
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+ULP = 2.0 ** -8
+
+
+def scaled_err(a, b):
+  s = float(np.max(np.abs(b))) + 1e-30
+  d = np.abs(np.asarray(a, np.float64) - b) / s
+  return float(d.max()), float(d.mean())
+
+
+def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from speecht_amd._lib import launch_trace
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)
+  B = 32
+  x, seq, labels = WL.make_batch([1001] * B, 80, seed=103)            # rank 3's shard of bench.py's global batch
+  x = x.astype(np.float32)
+  eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode='bf16')
+  eng.set_weights(params)
+  eng.load_batch(x, seq)
+  eng.set_labels(labels)
+  with launch_trace() as tr:
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / (8 * B))                                  # d avg_loss over the GLOBAL batch of 256
+    eng.backward()
+  torch.cuda.synchronize()
+  eng.check_ctc_status()
+  assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 6, '\n'.join(tr.lines)
+  t0 = time.time()
+  p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round)
+  loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)
+  ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round)
+  print('bf16-storage oracle on the whole shard: %.1f s' % (time.time() - t0))
+  got = eng.logits_time_major().cpu().numpy()
+  mx, mean = scaled_err(got, logits)
+  print('logits: max %.2f ulp, mean %.3f ulp (bf16 ulp of the tensor scale)' % (mx / ULP, mean / ULP))
+  assert mx < 16 * ULP and mean < 0.5 * ULP, (mx, mean)
+  np.testing.assert_allclose(eng.loss.cpu().numpy(), loss, rtol=2e-2)
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref_grads)):
+    mxF, meanF = scaled_err(gF, rF)
+    mxb, _ = scaled_err(gb, rb)
+    print('L%d: filters max %.2f ulp mean %.3f ulp, bias max %.2f ulp' % (i, mxF / ULP, meanF / ULP, mxb / ULP))
+    assert mxF < 16 * ULP and meanF < 0.5 * ULP and mxb < 16 * ULP, (i, mxF, meanF, mxb)
+
+
+def test_config4_rank_shard_long_form_forward_and_decoders():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)
+  B, T = 16, 3001
+  frames = [T] * 14 + [2500, 1777]
+  x, seq, _ = WL.make_batch(frames, 80, seed=11)
+  x = x.astype(np.float32)
+  eng = Wav2LetterEngine(layers, device='cuda:0')
+  eng.set_weights(params)
+  eng.load_batch(x, seq)
+  eng.forward()
+  torch.cuda.synchronize()
+  got = eng.logits_time_major().cpu().numpy()
+  assert got.shape == (1501, B, 29)
+  rows = [0, 15]
+  p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  ref = O.wav2letter_forward(x[rows].astype(np.float64), p64, layers)
+  err = float(np.max(np.abs(got[:, rows] - ref)))
+  print('config 4 shard: max|logit err| on rows %s = %.2e' % (rows, err))
+  assert err < 1e-4
+  ids, score = eng.greedy_decode()
+  ref_ids, ref_score = O.ctc_greedy_decode(got, seq // 2)
+  assert ids == ref_ids
+  np.testing.assert_allclose(score, ref_score, rtol=1e-5)
+  b_ids, b_score = eng.beam_search_decode(beam_width=16)
+  r_ids, r_score = O.ctc_beam_search_decode(got[:, rows], (seq // 2)[rows], beam_width=16)
+  assert [b_ids[r] for r in rows] == r_ids
+  np.testing.assert_allclose(b_score[rows], r_score, rtol=1e-4, atol=1e-3)
+  # the beam's best labelling is at least as probable as the greedy path's labelling
+  assert all(len(i) <= 1501 for i in b_ids)
+
+
+def test_bench_self_launch_two_ranks_share_one_gpu():
+  """`python bench.py --gpus 2` exactly as the driver invokes it (no torch.distributed environment): bench.py
+  re-launches itself under torch.distributed.run.  On a 1-GPU box the two ranks share cuda:0 and use gloo
+  (test knobs ST_SHARE_GPU / ST_DIST_BACKEND); the control flow, the bucketed exchange hooks, the max-over-ranks
+  timing and the one JSON line are the production ones."""
+  import json
+  import os
+  import subprocess
+  import sys
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, ST_SHARE_GPU='1', ST_DIST_BACKEND='gloo')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                      '--batch', '4', '--seconds', '2', '--no-alt', '--no-cpu-baseline'],
+                     env=env, cwd=root, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  out = json.loads(lines[0])
+  assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and out['scaling'] == 'weak'
+  assert out['replicas_identical'] is True
+  assert len(out['per_rank_ms_per_step']) == 2 and out['comm']['allreduce_alone_ms'] > 0
+  assert out['max_logit_err'] < 1e-4 and out['parity']['ctc_loss_delta_rel'] < 1e-4

@@ -1,0 +1,113 @@
+"""Gradient parity AT BASELINE's headline size (configs[1]: B=32 x 10 s x 80-mel, 250/2000 channels).
+
+The kernels the benchmark runs -- gemm_nn<128,128,2,2,fast> forward and back-prop (incl. the 2-way split-K of
+L8's back-prop), gemm_tn<128> with row slabs at M = 16 032 -- are only selected at near-full batch, so this module
+runs one full-size step and compares EVERY gradient tensor, the per-utterance losses and the logits with an
+independent CPU evaluation of the same step in float64 (tests/torch_ref.py: F.conv1d + F.ctc_loss + autograd,
+which agrees with the numpy oracle to 1e-13, tests/test_oracle_conv_ctc.py::test_torch_ref_equals_oracle).
+The launch trace of the library is asserted so that the test cannot silently take the small-problem kernels.
+
+Tolerances: logits <= 1e-4 absolute, loss <= 1e-4 relative, every gradient tensor
+<= 2e-4 of its own max."""
+import time
+
+import numpy as np
+import pytest
+
+from tests import torch_ref as TR
+from tests import workloads as WL
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+FRAMES = [1001] * 30 + [777, 500]                          # ragged tail like a real batch
+
+
+@pytest.fixture(scope='module')
+def case():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)      # non-zero biases
+  x, seq, labels = WL.make_batch(FRAMES, 80, seed=3)
+  x32 = x.astype(np.float32)
+  t0 = time.time()
+  ref = TR.loss_and_grads(x32, seq, labels, params, layers, dtype=torch.float64)
+  print('float64 CPU reference of the full-size step: %.1f s' % (time.time() - t0))
+  return dict(layers=layers, params=params, x=x32, seq=seq, labels=labels, ref=ref)
+
+
+def run_step(case, mode):
+  from speecht_amd._lib import launch_trace
+  from speecht_amd.engine import Wav2LetterEngine
+  eng = Wav2LetterEngine(case['layers'], device='cuda:0', conv_mode=mode)
+  eng.set_weights(case['params'])
+  eng.load_batch(case['x'], case['seq'])
+  eng.set_labels(case['labels'])
+  with launch_trace() as tr:
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / len(FRAMES))
+    eng.backward()
+  torch.cuda.synchronize()
+  eng.check_ctc_status()
+  return eng, tr.lines
+
+
+def compare(eng, ref, grad_tol=2e-4):
+  logits = eng.logits_time_major().cpu().numpy()
+  assert logits.shape == ref['logits'].shape == (501, 32, 29)
+  # frames beyond an utterance's own length are computed too (nothing is masked): compare all
+  err = float(np.max(np.abs(logits - ref['logits'])))
+  assert err < 1e-4, err
+  np.testing.assert_allclose(eng.loss.cpu().numpy(), ref['loss'], rtol=1e-4)
+  worst = 0.0
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref['grads'])):
+    for name, g, r in (('filters', gF, rF), ('bias', gb, rb)):
+      assert g.shape == r.shape
+      rel = float(np.max(np.abs(g - r)) / np.max(np.abs(r)))
+      worst = max(worst, rel)
+      assert rel < grad_tol, ('layer %d %s' % (i, name), rel)
+  return err, worst
+
+
+def test_fullsize_fp32_gradients_match_float64_reference(case):
+  eng, trace = run_step(case, 'fp32')
+  text = '\n'.join(trace)
+  # the benchmark's kernels, not the small-problem ones
+  fwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=0')]
+  bwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=1')]
+  assert len(fwd_fast) == 9, text                                  # L1..L9 forward
+  assert len(bwd_fast) == 9, text                                  # L2..L10 back-prop to the input (L1 from 250 ch)
+  assert any('splits=2' in l and 'Kp=64512' in l for l in bwd_fast), text        # L8 back-prop: 2 K-halves
+  slabbed = [l for l in trace if l.startswith('gemm_tn<') and 'slabs=1 ' not in l]
+  assert len(slabbed) >= 9 and all('M=16032' in l for l in trace if l.startswith('gemm_tn<')), text
+  err, worst = compare(eng, case['ref'])
+  print('fp32 full-size: max|logit err| %.2e, worst gradient error %.2e of max' % (err, worst))
+
+
+def test_fullsize_bf16x6_gradients_match_float64_reference(case):
+  eng, trace = run_step(case, 'bf16x6')
+  assert sum(1 for l in trace if l.startswith('gemm_nn_bf16<256,NP=3>')) >= 4, '\n'.join(trace)
+  err, worst = compare(eng, case['ref'])
+  print('bf16x6 full-size: max|logit err| %.2e, worst gradient error %.2e of max' % (err, worst))
+
+
+def test_fullsize_update_matches_reference_adam(case):
+  """clip_by_global_norm(5) + TF-Adam on the full-size gradients: the global norm and the first update of every
+  tensor against the float64 reference gradients pushed through the oracle's optimizer (speech_model.py:77-82)."""
+  from oracle import w2l_oracle as O
+  eng, _ = run_step(case, 'fp32')
+  flat = [g for pair in case['ref']['grads'] for g in pair]
+  clipped, gn = O.clip_by_global_norm(flat, 5.0)
+  eng.apply_update(lr=1e-4)
+  torch.cuda.synchronize()
+  assert float(eng.stats[0]) == pytest.approx(gn, rel=1e-5)
+  new = eng.get_weights()
+  for i, (F, b) in enumerate(case['params']):
+    for j, (p0, got) in enumerate(((F, new[i][0]), (b, new[i][1]))):
+      g = clipped[2 * i + j]
+      want, _, _ = O.adam_tf_step(p0.astype(np.float64), g, np.zeros_like(g), np.zeros_like(g), 1, 1e-4)
+      # the first Adam step moves every weight by lr * g/(|g| + eps*sqrt(1-b2)/(1-b1))-ish: compare the DELTA
+      d_got, d_want = got.astype(np.float64) - p0, want - p0
+      # + one fp32 rounding of the stored weight (the delta can be smaller than an ulp of the weight)
+      assert np.max(np.abs(d_got - d_want)) < 2e-3 * np.max(np.abs(d_want)) + 1.2e-7 * np.max(np.abs(p0)) + 1e-12, (i, j)

@@ -252,3 +252,22 @@ def test_beam_search_oracle_beam1_and_empty():
   ids, score = O.ctc_beam_search_decode(x, [30, 0], beam_width=1)
   assert ids[1] == [] and score[1, 0] == 0.0
   assert len(ids[0]) > 0 and score[0, 0] < 0.0
+
+
+def test_torch_ref_equals_oracle():
+  """tests/torch_ref.py (F.conv1d + F.ctc_loss + autograd, float64) and the numpy oracle are two independent
+  formulations of the step; the full-size GPU gradient tests lean on the former, so pin them against each other
+  on a full-depth network with ragged lengths, repeats and non-zero biases."""
+  from tests import torch_ref as TR
+  from tests import workloads as WL
+  layers = WL.w2l_layers(16, width=24, fc=40)
+  params = WL.xavier_params(layers, seed=5)
+  x, seq, labels = WL.make_batch([75, 61, 40], 16, seed=4)
+  labels[1] = [1, 1, 1, 2]
+  ref = O.train_step(x, seq, labels, params, layers, O.zero_opt_state(params), update=False)
+  got = TR.loss_and_grads(x, seq, labels, params, layers, dtype=torch.float64)
+  np.testing.assert_allclose(got['logits'], ref['logits'], rtol=0, atol=1e-12)
+  np.testing.assert_allclose(got['loss'], ref['loss'], rtol=1e-11)
+  for (gF, gb), (rF, rb) in zip(got['grads'], ref['grads']):
+    np.testing.assert_allclose(gF, rF, rtol=0, atol=1e-11 * np.max(np.abs(rF)) + 1e-300)
+    np.testing.assert_allclose(gb, rb, rtol=0, atol=1e-11 * np.max(np.abs(rb)) + 1e-300)

@@ -1,0 +1,96 @@
+"""Independent CPU formulation of the training step with torch CPU ops (checker only, like oracle/).
+
+``F.conv1d`` (oneDNN / native im2col GEMM) + ``F.ctc_loss`` + autograd share no code with
+``oracle/w2l_oracle.py`` (numpy im2col + hand-written alpha/beta) nor with the HIP kernels, so agreement of
+all three at BASELINE's full sizes is the strongest pin available while TF1 cannot be installed.
+Used by the full-size GPU parity tests and by ``bench.py``'s second ``cpu_baseline`` leg.
+Reference lines restated: speech_model.py:74-75 (ctc_loss + reduce_mean), :155,173,177 (conv1d SAME + bias
++ relu), :275-295 (layer table), :78 (compute_gradients).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def same_padding(t_in, width, stride):
+  t_out = -(-t_in // stride)
+  total = max((t_out - 1) * stride + width - t_in, 0)
+  return t_out, total // 2, total - total // 2
+
+
+def make_params(params, dtype, requires_grad=True):
+  """[(filters [W,Cin,Cout], bias [Cout])] numpy -> torch leaf tensors in conv1d's [Cout,Cin,W] layout."""
+  out = []
+  for Fw, b in params:
+    w = torch.tensor(np.ascontiguousarray(np.transpose(Fw, (2, 1, 0))), dtype=dtype, requires_grad=requires_grad)
+    bb = torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad)
+    out.append((w, bb))
+  return out
+
+
+def forward(x, tparams, layers):
+  """x [B,T,Cin] torch -> logits [B,T',C] (channels-last like the reference)."""
+  h = x.permute(0, 2, 1)
+  for (w, b), (W, s, cin, cout, relu) in zip(tparams, layers):
+    _, pl, pr = same_padding(h.shape[2], W, s)
+    h = F.conv1d(F.pad(h, (pl, pr)), w, b, stride=s)
+    if relu:
+      h = torch.relu(h)
+  return h.permute(0, 2, 1)
+
+
+def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, threads=None):
+  """One forward + CTC + backward.  Returns dict(logits [T',B,C], loss [B], avg_loss,
+  grads [(dF [W,Cin,Cout], db [Cout])]) as numpy float64 -- gradients of avg_loss = mean_b loss_b."""
+  if threads:
+    torch.set_num_threads(threads)
+  tparams = make_params(params, dtype)
+  xt = torch.tensor(np.asarray(x), dtype=dtype)
+  logits = forward(xt, tparams, layers)                       # [B, T', C]
+  tm = logits.permute(1, 0, 2)
+  lens = torch.as_tensor(np.asarray(seq_lens) // 2, dtype=torch.long)
+  flat = torch.tensor([v for l in labels for v in l], dtype=torch.long)
+  llen = torch.tensor([len(l) for l in labels], dtype=torch.long)
+  per_utt = F.ctc_loss(torch.log_softmax(tm, dim=-1), flat, lens, llen, blank=tm.shape[2] - 1, reduction='none',
+                       zero_infinity=False)
+  avg = per_utt.mean()
+  avg.backward()
+  grads = [(np.transpose(w.grad.numpy(), (2, 1, 0)).astype(np.float64), b.grad.numpy().astype(np.float64))
+           for w, b in tparams]
+  return dict(logits=tm.detach().numpy().astype(np.float64), loss=per_utt.detach().numpy().astype(np.float64),
+              avg_loss=float(avg.detach()), grads=grads)
+
+
+class TorchCpuTrainer:
+  """The same step with clip_by_global_norm(5) + TF-Adam (eps outside the bias correction,
+  speech_model.py:77-82) for the CPU baseline timing in bench.py: fp32, oneDNN convolutions, all host cores."""
+
+  def __init__(self, params, layers, lr=1e-4, dtype=torch.float32):
+    self.layers, self.lr, self.dtype = layers, lr, dtype
+    self.p = [t for pair in make_params(params, dtype) for t in pair]
+    self.m = [torch.zeros_like(t) for t in self.p]
+    self.v = [torch.zeros_like(t) for t in self.p]
+    self.t = 0
+
+  def step(self, x, seq_lens, labels):
+    for t in self.p:
+      t.grad = None
+    pairs = list(zip(self.p[0::2], self.p[1::2]))
+    logits = forward(torch.as_tensor(np.asarray(x), dtype=self.dtype), pairs, self.layers).permute(1, 0, 2)
+    lens = torch.as_tensor(np.asarray(seq_lens) // 2, dtype=torch.long)
+    flat = torch.tensor([v for l in labels for v in l], dtype=torch.long)
+    llen = torch.tensor([len(l) for l in labels], dtype=torch.long)
+    loss = F.ctc_loss(torch.log_softmax(logits, dim=-1), flat, lens, llen, blank=logits.shape[2] - 1,
+                      reduction='none').mean()
+    loss.backward()
+    with torch.no_grad():
+      gn = torch.sqrt(sum((t.grad.double() ** 2).sum() for t in self.p)).item()
+      scale = 5.0 / max(gn, 5.0)
+      self.t += 1
+      lr_t = self.lr * (1.0 - 0.999 ** self.t) ** 0.5 / (1.0 - 0.9 ** self.t)
+      for p, m, v in zip(self.p, self.m, self.v):
+        g = p.grad * scale
+        m.mul_(0.9).add_(g, alpha=0.1)
+        v.mul_(0.999).addcmul_(g, g, value=0.001)
+        p.sub_(lr_t * m / (v.sqrt() + 1e-3))
+    return float(loss)

@@ -175,9 +175,11 @@ def cpu_baseline(n_mels, frames, utts=2, steps=2):
 
 
 def cpu_baseline_torch(n_mels, frames, batch, budget_s=25.0):
-  """The same training step with torch CPU ops (oneDNN convolutions + native CTC, fp32, all host cores), the
+  """The same training step with torch CPU ops (F.conv1d + native CTC + autograd, fp32, all host cores), the
   fastest CPU formulation available here (TF1 cannot be installed): median of 3 steps after one warm-up step.
-  The batch is the full 32 utterances unless a probe step says three of them would not fit the time budget."""
+  The batch is the full 32 utterances unless a probe step says three of them would not fit the time budget.
+  oneDNN is switched off for the convolutions: on the 256-thread hosts of the GPU boxes its fp32 conv1d primitives
+  ran this network 100x slower (47 s for 4 utterances) than torch's native im2col + sgemm path."""
   from tests import torch_ref as TR
   layers = WL.w2l_layers(n_mels)
   params = WL.xavier_params(layers, seed=42, bias_range=0.0, dtype=np.float32)
@@ -185,25 +187,26 @@ def cpu_baseline_torch(n_mels, frames, batch, budget_s=25.0):
   x, sl, labels = WL.make_batch([frames] * batch, n_mels, seed=0)
   x = x.astype(np.float32)
   trainer = TR.TorchCpuTrainer(params, layers, lr=1e-4)
-  probe = min(4, batch)
-  trainer.step(x[:probe], sl[:probe], labels[:probe])               # warm-up (thread pool, primitive caches)
-  t0 = time.time()
-  trainer.step(x[:probe], sl[:probe], labels[:probe])
-  per_utt = (time.time() - t0) / probe
-  utts = batch
-  while utts > probe and 4 * utts * per_utt > budget_s:
-    utts //= 2
-  if utts != probe:
-    trainer.step(x[:utts], sl[:utts], labels[:utts])                # warm-up at the timed shape
-  times = []
-  for _ in range(3):
+  probe = min(2, batch)
+  with torch.backends.mkldnn.flags(enabled=False):
+    trainer.step(x[:1, :201], [201], [labels[0][:20]])                # warm-up (thread pool)
     t0 = time.time()
-    trainer.step(x[:utts], sl[:utts], labels[:utts])
-    times.append(time.time() - t0)
+    trainer.step(x[:probe], sl[:probe], labels[:probe])
+    per_utt = (time.time() - t0) / probe
+    utts = batch
+    while utts > probe and 4 * utts * per_utt > budget_s:
+      utts //= 2
+    if utts != probe:
+      trainer.step(x[:utts], sl[:utts], labels[:utts])                # warm-up at the timed shape
+    times = []
+    for _ in range(3):
+      t0 = time.time()
+      trainer.step(x[:utts], sl[:utts], labels[:utts])
+      times.append(time.time() - t0)
   med = sorted(times)[1]
   return dict(value=round(utts / med, 3), unit='utterances/s', cores=os.cpu_count(), kind='port',
               sample='batch of {} x 10 s utterances, median of 3 full training steps (forward + CTC + backward + '
-                     'clip + TF-Adam) of tests/torch_ref.py: torch {} CPU ops (oneDNN conv1d, native ctc_loss), fp32, '
+                     'clip + TF-Adam) of tests/torch_ref.py: torch {} CPU ops (native conv1d = im2col + sgemm, native ctc_loss), fp32, '
                      '{} threads; CPU restatement of the reference path (TF1 not installable)'.format(
                          utts, torch.__version__, torch.get_num_threads()),
               step_seconds=[round(t, 3) for t in times])
@@ -300,7 +303,7 @@ def main():
   x, seq_lens, labels = WL.make_batch([frames] * args.batch, args.mels, seed=100 + rank)
   parity = parity_on_bench_inputs(eng, x, seq_lens, labels) if rank == 0 else None
   feed = HostFeed(eng, x, seq_lens, labels)
-  reducer = GradientAllReducer(eng.grads, eng.layer_ranges, force=args.force_allreduce, transport=args.allreduce) if (world > 1 or args.force_allreduce) else None
+  reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, force=args.force_allreduce, transport=args.allreduce) if (world > 1 or args.force_allreduce) else None
   global_batch = args.batch * world
   lr = 1e-4
 

@@ -146,6 +146,16 @@ int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, fl
                                  float clip_norm, float lr_t, float beta1, float beta2, float eps,
                                  float* stats, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* Gated form.  tf.nn.ctc_loss rejects a batch with an utterance that cannot be aligned (InvalidArgument,
+ * speech_model.py:74) and the failing sess.run then touches no variable (speech_model.py:82).  Here the CTC
+ * kernel reports such utterances in `status`; st_ctc_status_gate_f32 folds the status words into one device float
+ * (the number of bad utterances; data-parallel training all-reduces it with the gradients), and the update
+ * becomes a no-op -- params, m and v untouched, stats still written -- when *gate != 0.  gate == NULL: ungated. */
+int st_ctc_status_gate_f32(const int32_t* status, int batch, float* gate, void* stream);
+int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float* m, float* v, size_t n,
+                                       float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                                       float* stats, const float* gate, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 /* norm only (stats[0] = ||g||, stats[1] = clip/max(norm,clip)); used for reporting */
 int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* stats,
                        void* workspace, size_t workspace_bytes, void* stream);

@@ -51,6 +51,10 @@ _SIGNATURES = {
     'st_global_norm_ws': (c_size_t, [c_size_t]),
     'st_global_norm_clip_adam_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                              c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_ctc_status_gate_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'st_global_norm_clip_adam_gated_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
+                                                   c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                   c_void_p]),
     'st_global_norm_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_melspec_ws': (c_size_t, [c_int, c_int64, c_int]),
     'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,

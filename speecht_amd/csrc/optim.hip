@@ -60,11 +60,15 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         const float* __restrict__ partial, float clip, float lr_t,
-                                                        float b1, float b2, float eps, float* __restrict__ stats) {
+                                                        float b1, float b2, float eps, float* __restrict__ stats,
+                                                        const float* __restrict__ gate) {
   __shared__ float red[4];
   const float gn = sqrtf(total_sumsq(partial, red));
   const float scale = clip / fmaxf(gn, clip);
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats) { stats[0] = gn; stats[1] = scale; }
+  // a batch that tf.nn.ctc_loss would have rejected (InvalidArgument fails the whole sess.run before any variable
+  // is touched, speech_model.py:74,82) must leave weights and Adam state alone: uniform early exit
+  if (gate && gate[0] != 0.f) return;
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * scale;
@@ -91,9 +95,22 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   }
 }
 
+__global__ void status_gate_kernel(const int* __restrict__ status, int n, float* __restrict__ gate) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < n; i += 64) bad += status[i] != 0;
+  bad = (int)st::wave_sum((float)bad);
+  if (threadIdx.x == 0) gate[0] = (float)bad;
+}
+
 }  // namespace
 
 extern "C" {
+
+int st_ctc_status_gate_f32(const int32_t* status, int batch, float* gate, void* stream) {
+  ST_REQUIRE(status && gate && batch > 0, "status_gate: bad args");
+  hipLaunchKernelGGL(status_gate_kernel, dim3(1), dim3(64), 0, st::as_stream(stream), status, batch, gate);
+  return st::check_launch("status_gate");
+}
 
 size_t st_global_norm_ws(size_t n) { (void)n; return NORM_BLOCKS * sizeof(float); }
 
@@ -111,6 +128,13 @@ int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* sta
 int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
                                  float lr_t, float beta1, float beta2, float eps, float* stats, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  return st_global_norm_clip_adam_gated_f32(params, grads, m, v, n, clip_norm, lr_t, beta1, beta2, eps, stats, nullptr,
+                                            workspace, workspace_bytes, stream);
+}
+
+int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
+                                       float lr_t, float beta1, float beta2, float eps, float* stats, const float* gate,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(params && grads && m && v && workspace && workspace_bytes >= st_global_norm_ws(n), "clip_adam: bad args");
   ST_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "clip_adam: buffers must be 16-byte aligned");
@@ -119,7 +143,7 @@ int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, fl
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, partial);
   const int blocks = (int)std::max<size_t>(1, std::min<size_t>((n / 4 + 255) / 256, 2048));
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, partial, clip_norm,
-                     lr_t, beta1, beta2, eps, stats);
+                     lr_t, beta1, beta2, eps, stats, gate);
   return st::check_launch("clip_adam");
 }
 

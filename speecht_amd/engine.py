@@ -155,7 +155,13 @@ class Wav2LetterEngine:
       off += l.k_pad * l.n_pad + l.n_pad
     self.n_flat = off
     z = lambda: torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
-    self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()
+    self.params, self.adam_m, self.adam_v = z(), z(), z()
+    # the gradient buffer carries one extra slot behind the last layer: the update gate (number of utterances of
+    # this step that CTC could not align).  It sits inside the last all-reduce bucket so that in data-parallel
+    # training every rank sees the global count and skips the update together (apply_update / fetch_losses).
+    self.reduce_buffer = torch.zeros(self.n_flat + 16, dtype=torch.float32, device=self.device)
+    self.grads = self.reduce_buffer[:self.n_flat]
+    self.gate = self.reduce_buffer[self.n_flat:self.n_flat + 1]
     self.packed_t = [None] + [torch.zeros(l.kt_pad * l.nt_pad, dtype=torch.float32, device=self.device)
                               for l in self.layers[1:]]
     self._packed_t_fresh = False
@@ -184,6 +190,13 @@ class Wav2LetterEngine:
   def layer_ranges(self):
     """(start, end) of each layer's filters+bias inside the flat buffers."""
     return [(fo, bo + l.n_pad) for (fo, bo), l in zip(self.offsets, self.layers)]
+
+  @property
+  def reduce_ranges(self):
+    """``layer_ranges`` over ``reduce_buffer``: the last layer's slice also carries the update gate."""
+    r = self.layer_ranges
+    r[-1] = (r[-1][0], self.n_flat + 16)
+    return r
 
   def _ptr(self, t):
     return ctypes.c_void_p(t.data_ptr())
@@ -535,6 +548,12 @@ class Wav2LetterEngine:
     self.max_label_len = int(max(lens + [0]))
     # CSR ids (+1 pad entry so that the buffer is never empty); array-per-utterance inputs stay in numpy
     ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
+    # tf.nn.ctc_loss raises InvalidArgument for a label outside [0, num_classes - 1); the kernels index LDS with
+    # the id, so it must never reach them (vocabulary.letter_to_id maps e.g. a digit to a negative id)
+    if ids.size > 1 and (int(ids.min()) < 0 or int(ids.max()) >= self.num_classes - 1):
+      bad = [b for b, l in enumerate(label_list) if len(l) and (min(l) < 0 or max(l) >= self.num_classes - 1)]
+      raise ValueError('label ids must lie in [0, {}) (blank = {}); offending utterances: {}'.format(
+          self.num_classes - 1, self.num_classes - 1, bad))
     self.label_ids = self._upload_i32(ids)
     self.label_offs = self._upload_i32(offs)
 
@@ -549,6 +568,7 @@ class Wav2LetterEngine:
     call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
          self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
+    call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
 
   def refresh_packed_t(self):
     s = self.stream_ptr
@@ -606,9 +626,12 @@ class Wav2LetterEngine:
     self.step_count += 1
     t = self.step_count
     lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-    call('st_global_norm_clip_adam_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
+    # gated on the device: a step whose batch CTC rejected (on any rank) leaves params / m / v untouched
+    call('st_global_norm_clip_adam_gated_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
          self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), float(lr_t), beta1, beta2, eps,
-         self._ptr(self.stats), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
+         self._ptr(self.stats), self._ptr(self.gate), self._ptr(self.norm_ws), self.norm_ws.numel() * 4,
+         self.stream_ptr)
+    self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
     self._packed_t_fresh = False
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
@@ -666,17 +689,26 @@ class Wav2LetterEngine:
     B = self.loss.numel()
     if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < B:
       self._loss_host = (torch.empty(max(B, 64), dtype=torch.float32, pin_memory=True),
-                         torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-    loss_h, status_h, event = self._loss_host
+                         torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True), torch.cuda.Event(),
+                         torch.empty(16, dtype=torch.float32, pin_memory=True))
+    loss_h, status_h, event, gate_h = self._loss_host
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     with torch.cuda.stream(stream):
       loss_h[:B].copy_(self.loss, non_blocking=True)
       status_h[:B].copy_(self.ctc_status, non_blocking=True)
+      gate_h[:1].copy_(self.gate, non_blocking=True)
       event.record(stream)
     event.synchronize()
     st = status_h[:B].numpy()
-    if st.any():
-      raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))
+    skipped = getattr(self, '_updates_in_flight', 0)
+    self._updates_in_flight = 0
+    if st.any() or float(gate_h[0]) != 0.0:
+      # the gated Adam kernel enqueued behind this CTC evaluation was a no-op: take its step count back so that
+      # the bias correction stays in step with the updates that really happened
+      self.step_count -= min(skipped, 1)
+      if st.any():
+        raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))
+      raise ValueError('Not enough time for target transition sequence ({:g} utterance(s) on other ranks)'.format(float(gate_h[0])))
     return loss_h[:B].numpy().copy()
 
   def check_ctc_status(self):

@@ -94,17 +94,23 @@ class Evaluation(execution.DatasetExecutor):
     if verbose:
       perplexity = math.exp(float(avg_loss)) if avg_loss < 300 else float('inf')
       print('validation average loss {:.2f} perplexity {:.2f}'.format(avg_loss, perplexity))
-    # Deliberate fix of a reference defect: evaluation.py:144-151 pairs labels with decodings through
-    # extract_decoded_ids, which drops utterances that decode to the empty string (shifting every later
-    # pairing and raising StopIteration when the last ones are empty).  Here rows are paired by batch
-    # index; extract_decoded_ids itself stays faithful for other callers.
-    paths = [self.rows_by_batch(path) for path in decoded]
-    for row, label_ids in enumerate(self.rows_by_batch(label)):
+    # Pairing of labels with decodings.  Default: the reference's own walk (evaluation.py:144-151) -- both sparse
+    # tensors go through extract_decoded_ids and are consumed in lock-step, with its quirk that an utterance
+    # decoding to the empty string yields nothing (every later pairing shifts, and ``next`` raises StopIteration
+    # when the decodings run out first).  ``--pair-by-row`` (flags.pair_by_row; not a reference flag) pairs by batch
+    # row instead, which is what the statistics mean to measure.
+    if getattr(self.flags, 'pair_by_row', False):
+      label_rows = self.rows_by_batch(label)
+      path_iters = [iter(self.rows_by_batch(path)) for path in decoded]
+    else:
+      label_rows = self.extract_decoded_ids(label)
+      path_iters = [self.extract_decoded_ids(path) for path in decoded]
+    for label_ids in label_rows:
       expected = vocabulary.ids_to_sentence(label_ids)
       if verbose:
         print('expected: {}'.format(expected))
-      for rows in paths:
-        hypothesis = vocabulary.ids_to_sentence(rows[row])
+      for path in path_iters:
+        hypothesis = vocabulary.ids_to_sentence(next(path))
         stats.track_decoding(hypothesis, expected)
         if verbose:
           print('decoded: {}'.format(hypothesis))

@@ -195,7 +195,10 @@ class InputBatchLoader(BaseInputLoader):
       coord.register_thread(t)
       threads.append(t)
     device = getattr(sess, 'device', None)
-    if device is not None and getattr(device, 'type', None) == 'cuda':
+    if device is not None:
+      import torch
+      device = torch.device(device)          # Session.device is a plain string such as 'cuda:0'
+    if device is not None and device.type == 'cuda':
       # the H2D copy of batch k+1.. overlaps the kernels of batch k (separate HIP stream, own thread)
       self._staged = queue.Queue(maxsize=self.DEVICE_PREFETCH)
       t = threading.Thread(target=self._stage, args=(device, coord), daemon=True)

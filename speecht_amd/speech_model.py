@@ -75,19 +75,47 @@ class _Saver:
   holding what tf.train.Saver(tf.global_variables()) holds (speech_model.py:122): weights, Adam
   m/v, global_step, learning_rate."""
 
+  MAX_TO_KEEP = 5        # tf.train.Saver's default
+
   def __init__(self, model):
     self.model = model
 
   def save(self, sess, save_path, global_step=None):
+    """Like tf.train.Saver.save: ``<save_path>-<step>`` + the ``checkpoint`` index, which names files RELATIVE to
+    the checkpoint directory (so a moved train dir or another cwd still restores) and lists the last
+    MAX_TO_KEEP checkpoints; older ones are deleted.  Files are written to a temporary name and renamed, so a
+    crash never leaves a truncated checkpoint behind the index.  In data-parallel training only rank 0 writes
+    (the replicas are identical)."""
     step = global_step.eval() if hasattr(global_step, 'eval') else global_step
     path = '{}-{}'.format(save_path, step) if step is not None else save_path
+    if getattr(self.model, '_rank', 0) != 0:
+      return path
     eng = self.model.engine
-    np.savez(path + '.npz', params=eng.params.cpu().numpy(), adam_m=eng.adam_m.cpu().numpy(),
+    directory = os.path.dirname(path) or '.'
+    tmp = path + '.tmp.npz'
+    np.savez(tmp, params=eng.params.cpu().numpy(), adam_m=eng.adam_m.cpu().numpy(),
              adam_v=eng.adam_v.cpu().numpy(), global_step=self.model.global_step.eval(),
              learning_rate=self.model.learning_rate.eval() if hasattr(self.model, 'learning_rate') else 0.0,
              layers=np.array([(l.width, l.stride, l.cin, l.cout, int(l.relu)) for l in eng.layers]))
-    with open(os.path.join(os.path.dirname(path) or '.', 'checkpoint'), 'w') as f:
-      json.dump({'model_checkpoint_path': path + '.npz'}, f)
+    os.replace(tmp, path + '.npz')
+    index_path = os.path.join(directory, 'checkpoint')
+    name = os.path.basename(path) + '.npz'
+    kept = []
+    if os.path.exists(index_path):
+      try:
+        kept = [n for n in json.load(open(index_path)).get('all_model_checkpoint_paths', []) if n != name]
+      except ValueError:
+        kept = []
+    kept.append(name)
+    for old in kept[:-self.MAX_TO_KEEP]:
+      try:
+        os.remove(os.path.join(directory, os.path.basename(old)))
+      except OSError:
+        pass
+    kept = kept[-self.MAX_TO_KEEP:]
+    with open(index_path + '.tmp', 'w') as f:
+      json.dump({'model_checkpoint_path': name, 'all_model_checkpoint_paths': kept}, f)
+    os.replace(index_path + '.tmp', index_path)
     return path
 
   def restore(self, sess, path):
@@ -112,7 +140,14 @@ def latest_checkpoint(checkpoint_directory):
   if not os.path.exists(index):
     return None
   path = json.load(open(index)).get('model_checkpoint_path')
-  return path if path and os.path.exists(path) else None
+  if not path:
+    return None
+  # names in the index are relative to the checkpoint directory (indices written before that hold a path
+  # relative to the cwd of the run that wrote them: its basename still resolves here)
+  local = os.path.join(checkpoint_directory, os.path.basename(path))
+  if os.path.exists(local):
+    return local
+  return path if os.path.exists(path) else None
 
 
 class SpeechModel:
@@ -133,6 +168,7 @@ class SpeechModel:
     self._decoding = False
     self._reducer = None
     self._world = 1
+    self._rank = 0
 
   # ---- graph-building protocol ---------------------------------------------------------------
   def _convolution(self, value, filter_width, stride, input_channels, out_channels, apply_non_linearity=True):
@@ -192,7 +228,22 @@ class SpeechModel:
     import torch.distributed as dist
     from .data_parallel import GradientAllReducer
     self._world = dist.get_world_size(group) if dist.is_initialized() else 1
-    self._reducer = GradientAllReducer(self.engine.grads, self.engine.layer_ranges, group) if self._world > 1 else None
+    eng = self.engine
+    self._rank = dist.get_rank(group) if dist.is_initialized() else 0
+    self._reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, group) if self._world > 1 else None
+    if self._world > 1:
+      # Only gradients are exchanged afterwards, so the replicas must START identical: rank 0's weights, Adam
+      # moments, step counters and learning rate go to everyone (init_session draws an unseeded Xavier sample
+      # per process, and a restore may have read different files).
+      src = dist.get_global_rank(group, 0) if group is not None else 0
+      for t in (eng.params, eng.adam_m, eng.adam_v):
+        dist.broadcast(t, src=src, group=group)
+      box = [(eng.step_count, self.global_step.value, self.learning_rate.value if hasattr(self, 'learning_rate') else None)]
+      dist.broadcast_object_list(box, src=src, group=group)
+      eng.step_count, self.global_step.value = int(box[0][0]), int(box[0][1])
+      if box[0][2] is not None and hasattr(self, 'learning_rate'):
+        self.learning_rate.value = float(box[0][2])
+      eng.mark_weights_changed()
 
   def step(self, sess, loss=True, update=True, decode=False, return_label=False, summary=False, feed_dict=None):
     """One evaluation of the path.  Returns, in this order and only when requested:
@@ -219,9 +270,12 @@ class SpeechModel:
         eng.backward(self._reducer.on_layer_done if self._reducer else None)
         if self._reducer:
           self._reducer.finish()
-        eng.apply_update(self.learning_rate.value, self.max_gradient_norm)
+        eng.apply_update(self.learning_rate.value, self.max_gradient_norm)   # no-op on the device if CTC rejected the batch
+      # raises on a CTC status word (of any rank) -- before global_step moves: like TF's failed sess.run, a rejected
+      # batch leaves weights, Adam state and counters as they were
+      avg_loss = np.float32(eng.fetch_losses().mean(dtype=np.float32))
+      if update:
         self.global_step.value += 1
-      avg_loss = np.float32(eng.fetch_losses().mean(dtype=np.float32))     # raises on a CTC status word
       if self._world > 1:
         from .data_parallel import all_reduce_mean_scalar
         avg_loss = np.float32(all_reduce_mean_scalar(float(avg_loss), eng.device))

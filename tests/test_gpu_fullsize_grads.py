@@ -60,13 +60,20 @@ def compare(eng, ref, grad_tol=2e-4):
   err = float(np.max(np.abs(logits - ref['logits'])))
   assert err < 1e-4, err
   np.testing.assert_allclose(eng.loss.cpu().numpy(), ref['loss'], rtol=1e-4)
-  worst = 0.0
+  worst, report, failed = 0.0, [], []
   for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref['grads'])):
     for name, g, r in (('filters', gF, rF), ('bias', gb, rb)):
       assert g.shape == r.shape
       rel = float(np.max(np.abs(g - r)) / np.max(np.abs(r)))
       worst = max(worst, rel)
-      assert rel < grad_tol, ('layer %d %s' % (i, name), rel)
+      report.append('L%d %s %.2e' % (i, name, rel))
+      if not rel < grad_tol:
+        failed.append('L%d %s' % (i, name))
+        if name == 'filters':                 # where: per filter tap (max over channels), relative to the tensor max
+          per_tap = np.max(np.abs(g - r), axis=(1, 2)) / np.max(np.abs(r))
+          report.append('   per tap: ' + ' '.join('%.1e' % v for v in per_tap))
+  print('gradient errors (max |g - ref| / max |ref|): ' + '; '.join(report))
+  assert not failed, (failed, report)
   return err, worst
 
 
@@ -77,7 +84,7 @@ def test_fullsize_fp32_gradients_match_float64_reference(case):
   fwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=0')]
   bwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=1')]
   assert len(fwd_fast) == 9, text                                  # L1..L9 forward
-  assert len(bwd_fast) == 9, text                                  # L2..L10 back-prop to the input (L1 from 250 ch)
+  assert len(bwd_fast) == 10, text                                 # back-prop to the input of L10..L1
   assert any('splits=2' in l and 'Kp=64512' in l for l in bwd_fast), text        # L8 back-prop: 2 K-halves
   slabbed = [l for l in trace if l.startswith('gemm_tn<') and 'slabs=1 ' not in l]
   assert len(slabbed) >= 9 and all('M=16032' in l for l in trace if l.startswith('gemm_tn<')), text

@@ -1,5 +1,6 @@
 """CPU tests of the host-side mirror of the reference API: batch/label layout, input pipeline,
 evaluation statistics, CLI flags, corpus cache format, and the data-parallel all-reduce (gloo)."""
+import json
 import os
 import subprocess
 import sys
@@ -90,6 +91,35 @@ def test_editdistance_and_eval_statistics():
   # extract_decoded_ids: faithful to the reference, including the empty-row quirk
   sp = SparseTensorValue(np.array([[0, 0], [0, 1], [2, 0]]), np.array([5, 6, 7]), np.array([3, 2]))
   assert [list(x) for x in Evaluation.extract_decoded_ids(sp)] == [[5, 6], [7]]   # row 1 (empty) vanishes
+
+
+def test_run_step_pairs_like_the_reference_by_default():
+  """evaluation.py:144-151: labels and decodings are walked with extract_decoded_ids in lock-step, so an utterance
+  that decodes to the empty string shifts the later pairings and the walk ends in StopIteration when the decodings
+  run out first; flags.pair_by_row (extension, --pair-by-row) pairs by batch row."""
+  import types
+  from speecht_amd.evaluation import Evaluation, EvalStatistics
+  from speecht_amd.speech_input import SparseTensorValue
+  from speecht_amd import vocabulary as V
+  ids = V.sentence_to_ids
+  labels = [ids('ab'), ids('cd'), ids('ef')]
+  decoded = [ids('ab'), [], ids('ef')]                 # row 1 decodes to nothing
+
+  def sparse(rows):
+    idx = [[b, p] for b, r in enumerate(rows) for p in range(len(r))]
+    return SparseTensorValue(np.array(idx).reshape(-1, 2), np.array([v for r in rows for v in r]), np.array([len(rows), 2]))
+  model = types.SimpleNamespace(global_step=types.SimpleNamespace(eval=lambda: 0),
+                                step=lambda sess, **kw: [np.float32(1.0), [sparse(decoded)], sparse(labels)])
+  ev = Evaluation.__new__(Evaluation)
+  ev.flags = types.SimpleNamespace(pair_by_row=False)
+  stats = EvalStatistics()
+  with pytest.raises(StopIteration):                   # label 'ef' finds no third decoding
+    ev.run_step(model, None, stats, save=False, verbose=False)
+  assert stats.decodings_counter == 2 and stats.sum_letter_edit_distance == 0 + 2     # 'ab'~'ab', 'cd'~'ef'
+  ev.flags.pair_by_row = True
+  stats = EvalStatistics()
+  ev.run_step(model, None, stats, save=False, verbose=False)
+  assert stats.decodings_counter == 3 and stats.sum_letter_edit_distance == 0 + 2 + 0  # 'cd'~'' costs 2
 
 
 def test_cli_flags_and_derived_values():
@@ -222,3 +252,41 @@ def test_flac_ingest_matches_the_references_fixture_expectations(golden_dir):
   assert np.max(np.abs(z - np.sin(2 * np.pi * 1000.0 * np.arange(22050) / 22050.0))[200:-200]) < 1e-6
   with pytest.raises(audio_io.FlacError):
     audio_io.decode_flac(b'fLaC' + bytes(60))
+
+
+def test_saver_index_is_relative_atomic_and_pruned(tmp_path, monkeypatch):
+  """tf.train.Saver semantics kept by the .npz saver: the index names files relative to the checkpoint directory
+  (restore works from another cwd / after moving the directory), keeps the last 5, never leaves temp files."""
+  import shutil
+  import types
+  import torch
+  from speecht_amd import speech_model as SM
+  eng = types.SimpleNamespace(params=torch.arange(8.0), adam_m=torch.zeros(8), adam_v=torch.ones(8), n_flat=8,
+                              layers=[types.SimpleNamespace(width=1, stride=1, cin=2, cout=2, relu=True)],
+                              device='cpu', step_count=0, mark_weights_changed=lambda: None)
+  model = types.SimpleNamespace(engine=eng, global_step=SM._Scalar(0, int), learning_rate=SM._Scalar(1e-3, float), _rank=0)
+  saver = SM._Saver(model)
+  run = tmp_path / 'train' / 'noname'
+  run.mkdir(parents=True)
+  monkeypatch.chdir(tmp_path)
+  for step in range(1, 8):
+    model.global_step.value = step
+    saver.save(None, os.path.join('train', 'noname', 'speechT.ckpt'), global_step=model.global_step)
+  files = sorted(os.listdir(run))
+  assert files == ['checkpoint'] + ['speechT.ckpt-%d.npz' % s for s in range(3, 8)]
+  index = json.load(open(run / 'checkpoint'))
+  assert index['model_checkpoint_path'] == 'speechT.ckpt-7.npz'
+  # another cwd and a moved directory still resolve
+  monkeypatch.chdir('/')
+  moved = tmp_path / 'elsewhere'
+  shutil.move(str(run), str(moved))
+  path = SM.latest_checkpoint(str(moved))
+  assert path == os.path.join(str(moved), 'speechT.ckpt-7.npz')
+  eng.params = torch.zeros(8)
+  saver.restore(None, path)
+  assert torch.equal(eng.params, torch.arange(8.0)) and model.global_step.eval() == 7 and eng.step_count == 7
+  # a non-zero rank of a data-parallel job writes nothing
+  model._rank = 1
+  model.global_step.value = 9
+  saver.save(None, os.path.join(str(moved), 'speechT.ckpt'), global_step=model.global_step)
+  assert not os.path.exists(moved / 'speechT.ckpt-9.npz')

@@ -93,4 +93,4 @@ class TorchCpuTrainer:
         m.mul_(0.9).add_(g, alpha=0.1)
         v.mul_(0.999).addcmul_(g, g, value=0.001)
         p.sub_(lr_t * m / (v.sqrt() + 1e-3))
-    return float(loss)
+    return float(loss.detach())

@@ -29,14 +29,30 @@ def scaled_err(a, b):
   return float(d.max()), float(d.mean())
 
 
+def plane(t3, buf):
+  """[B,T,C] float64 copy of the valid region of a bf16 (or fp32) buffer laid out like the padded NWC tensor t3."""
+  v = buf.view(t3.batch, t3.t_pitch, t3.c_pitch)[:, t3.halo:t3.halo + t3.frames, :t3.channels]
+  return v.float().cpu().numpy().astype(np.float64)
+
+
 def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
+  """One rank's shard of configs[3] (B = 32 x 10 s, bf16 activations / fp32 CTC) at full size, two ways:
+
+  * end to end from the inputs against the oracle with the bf16 storage model: logits and losses (tight), the 22
+    gradient tensors (loose: in bf16 storage a 1e-5 difference upstream -- fp32 vs float64 accumulation, the CTC
+    kernel's 1.5e-5 -- turns into 1-ulp flips of stored values, i.e. noise of ~2e-4 of a tensor's scale, which the
+    ill-conditioned lower layers amplify ~75x on the way to L0; DESIGN 5);
+  * kernel by kernel on the device's OWN stored operands, where nothing is amplified: every layer's stored output
+    against round_bf16(conv(stored input)), every stored activation gradient against round_bf16(mask * back-prop of
+    the stored gradient above), every filter / bias gradient against the float64 product of the stored operands.
+    Here a mismatch can only be a value on a rounding boundary: max <= 1 bf16 ulp of the tensor scale, mean <= 0.01."""
   if not torch.cuda.is_available():
     pytest.skip('no GPU')
   from speecht_amd._lib import launch_trace
   from speecht_amd.engine import Wav2LetterEngine
   layers = WL.w2l_layers(80)
   params = WL.xavier_params(layers, seed=42, dtype=np.float32)
-  B = 32
+  B, L = 32, len(layers)
   x, seq, labels = WL.make_batch([1001] * B, 80, seed=103)            # rank 3's shard of bench.py's global batch
   x = x.astype(np.float32)
   eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode='bf16')
@@ -50,8 +66,11 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
   torch.cuda.synchronize()
   eng.check_ctc_status()
   assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 6, '\n'.join(tr.lines)
-  t0 = time.time()
   p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  grads = eng.get_grads()
+
+  # ---- end to end from the inputs ----
+  t0 = time.time()
   logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round)
   loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)
   ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round)
@@ -61,11 +80,44 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
   print('logits: max %.2f ulp, mean %.3f ulp (bf16 ulp of the tensor scale)' % (mx / ULP, mean / ULP))
   assert mx < 16 * ULP and mean < 0.5 * ULP, (mx, mean)
   np.testing.assert_allclose(eng.loss.cpu().numpy(), loss, rtol=2e-2)
-  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref_grads)):
+  for i, ((gF, gb), (rF, rb)) in enumerate(zip(grads, ref_grads)):
     mxF, meanF = scaled_err(gF, rF)
     mxb, _ = scaled_err(gb, rb)
-    print('L%d: filters max %.2f ulp mean %.3f ulp, bias max %.2f ulp' % (i, mxF / ULP, meanF / ULP, mxb / ULP))
-    assert mxF < 16 * ULP and meanF < 0.5 * ULP and mxb < 16 * ULP, (i, mxF, meanF, mxb)
+    print('end to end L%d: filters max %.2f ulp mean %.3f ulp, bias max %.2f ulp' % (i, mxF / ULP, meanF / ULP, mxb / ULP))
+    assert mxF < 64 * ULP and meanF < 8 * ULP and mxb < 64 * ULP, (i, mxF, meanF, mxb)
+  del acts, ref_grads
+
+  # ---- kernel by kernel on the device's stored operands ----
+  t0 = time.time()
+  Xs = [plane(eng.X[i], eng.Xb[i]) for i in range(L)]                 # stored bf16 inputs of every layer
+  dZs = [plane(eng.dZ[i], eng.dZb[i]) for i in range(L)]              # stored bf16 gradients wrt every layer's output
+  for i, ((F, b), (W, s, cin, cout, relu)) in enumerate(zip(p64, layers)):
+    y = O.conv1d_same_fwd(Xs[i], O.bf16_round(F), b, s, relu)
+    if i + 1 < L:
+      mx, mean = scaled_err(Xs[i + 1], O.bf16_round(y))
+      assert mx <= 1.01 * ULP and mean < 0.01 * ULP, ('forward', i, mx / ULP, mean / ULP)
+    else:
+      mx, _ = scaled_err(plane(eng.X[L], eng.X[L].buf), y)            # logits stay fp32
+      assert mx < 1e-5, ('logits from stored X10', mx)
+    # filter / bias gradient of layer i from its stored operands
+    dx, dF, db = O.conv1d_same_bwd(Xs[i], O.bf16_round(F), None, dZs[i], s, relu=False, need_dx=(i > 0))
+    mxF, _ = scaled_err(grads[i][0], dF)
+    mxb, _ = scaled_err(grads[i][1], db)
+    assert mxF < 2e-4 and mxb < 2e-4, ('filter/bias gradient', i, mxF, mxb)
+    # gradient handed to the layer below: mask of the stored activation, rounded to bf16 when written
+    if i > 0:
+      if layers[i - 1][4]:
+        dx = dx * (Xs[i] > 0)
+      mx, mean = scaled_err(dZs[i - 1], O.bf16_round(dx))
+      assert mx <= 1.01 * ULP and mean < 0.01 * ULP, ('back-prop to the input', i, mx / ULP, mean / ULP)
+    print('kernel-level L%d ok (filters %.1e, bias %.1e of max)' % (i, mxF, mxb))
+  # the bf16 copy of d loss / d logits and the fp32 CTC gradient it was rounded from
+  mx, _ = scaled_err(dZs[L - 1], O.bf16_round(plane(eng.dZ[L - 1], eng.dZ[L - 1].buf)))
+  assert mx == 0.0
+  dl_ref = np.transpose(O.ctc_loss_and_grad(got.astype(np.float64), labels, seq // 2)[1], (1, 0, 2)) / (8 * B)
+  mx, _ = scaled_err(plane(eng.dZ[L - 1], eng.dZ[L - 1].buf), dl_ref)
+  assert mx < 2e-4, mx
+  print('kernel-by-kernel checks on the stored operands: %.1f s' % (time.time() - t0))
 
 
 def test_config4_rank_shard_long_form_forward_and_decoders():

@@ -7,8 +7,8 @@ independent CPU evaluation of the same step in float64 (tests/torch_ref.py: F.co
 which agrees with the numpy oracle to 1e-13, tests/test_oracle_conv_ctc.py::test_torch_ref_equals_oracle).
 The launch trace of the library is asserted so that the test cannot silently take the small-problem kernels.
 
-Tolerances: logits <= 1e-4 absolute, loss <= 1e-4 relative, every gradient tensor
-<= 2e-4 of its own max."""
+Tolerances: logits <= 1e-4 absolute, loss <= 1e-4 relative, d loss / d logits and every
+gradient tensor <= 2e-4 of its own max (see ``compare`` for how the ReLU discontinuity is handled)."""
 import time
 
 import numpy as np
@@ -53,28 +53,53 @@ def run_step(case, mode):
   return eng, tr.lines
 
 
-def compare(eng, ref, grad_tol=2e-4):
+def rel_err(g, r):
+  return float(np.max(np.abs(g - r)) / np.max(np.abs(r)))
+
+
+def compare(eng, ref, case, grad_tol=2e-4):
+  """Three comparisons, from the most independent to the most exact:
+
+  1. logits, per-utterance losses and d avg_loss / d logits against the float64 autograd reference;
+  2. the BACKWARD KERNELS at full size: all 22 gradient tensors against float64 back-prop evaluated on the
+     device's own stored activations and its own dlogits (tests/torch_ref.backward_from_acts) -- the exact linear
+     map the kernels must reproduce, tolerance 2e-4 of each tensor's max;
+  3. end to end against the fully independent reference gradients.  The step has one discontinuity: a ReLU input
+     within rounding of zero lands on different sides in fp32 and float64 (about one element in 10^7-10^8; the
+     flipped unit's whole gradient appears or vanishes).  Such a flip at the output of layer k perturbs the filter
+     gradients of layers <= k far above rounding level (L0 is the worst conditioned: its gradient is a sum over
+     16 032 frames that cancels to ~1/100 of its terms), so layers above the highest flip keep the 2e-4 bound and
+     layers at or below it get a loose sanity bound; with no flip every layer keeps 2e-4."""
   logits = eng.logits_time_major().cpu().numpy()
   assert logits.shape == ref['logits'].shape == (501, 32, 29)
   # frames beyond an utterance's own length are computed too (nothing is masked, SURVEY F7): compare all
   err = float(np.max(np.abs(logits - ref['logits'])))
   assert err < 1e-4, err
   np.testing.assert_allclose(eng.loss.cpu().numpy(), ref['loss'], rtol=1e-4)
-  worst, report, failed = 0.0, [], []
-  for i, ((gF, gb), (rF, rb)) in enumerate(zip(eng.get_grads(), ref['grads'])):
-    for name, g, r in (('filters', gF, rF), ('bias', gb, rb)):
-      assert g.shape == r.shape
-      rel = float(np.max(np.abs(g - r)) / np.max(np.abs(r)))
-      worst = max(worst, rel)
-      report.append('L%d %s %.2e' % (i, name, rel))
-      if not rel < grad_tol:
-        failed.append('L%d %s' % (i, name))
-        if name == 'filters':                 # where: per filter tap (max over channels), relative to the tensor max
-          per_tap = np.max(np.abs(g - r), axis=(1, 2)) / np.max(np.abs(r))
-          report.append('   per tap: ' + ' '.join('%.1e' % v for v in per_tap))
-  print('gradient errors (max |g - ref| / max |ref|): ' + '; '.join(report))
-  assert not failed, (failed, report)
-  return err, worst
+  dl = eng.dZ[-1].interior().cpu().numpy().astype(np.float64)
+  dl_err = rel_err(dl, ref['dlogits'])
+  assert dl_err < 2e-4, dl_err
+  acts = [eng.X[i].interior().cpu().numpy() for i in range(len(eng.layers) + 1)]
+  flips = [int(np.sum((acts[i] > 0) != (ref['acts'][i] > 0))) for i in range(1, len(eng.layers))]   # ReLU outputs
+  top_flip = max([i for i, n in enumerate(flips) if n] + [-1])       # index of the highest layer whose output flipped
+  got = eng.get_grads()
+  exact, _ = TR.backward_from_acts(acts, case['params'], case['layers'], dl)
+  kernel_report, e2e_report, failed = [], [], []
+  for i, ((gF, gb), (xF, xb), (rF, rb)) in enumerate(zip(got, exact, ref['grads'])):
+    for name, g, x, r in (('filters', gF, xF, rF), ('bias', gb, xb, rb)):
+      assert g.shape == x.shape == r.shape
+      k, e = rel_err(g, x), rel_err(g, r)
+      kernel_report.append('L%d %s %.1e' % (i, name, k))
+      e2e_report.append('L%d %s %.1e' % (i, name, e))
+      if not k < grad_tol:
+        failed.append('kernel L%d %s %.2e' % (i, name, k))
+      if not e < (grad_tol if i > top_flip else 5e-2):
+        failed.append('end-to-end L%d %s %.2e' % (i, name, e))
+  print('dlogits error %.2e of max; ReLU sign flips vs float64 per layer output: %s' % (dl_err, flips))
+  print('backward kernels vs float64 back-prop on the device activations: ' + '; '.join(kernel_report))
+  print('end to end vs float64 autograd: ' + '; '.join(e2e_report))
+  assert not failed, failed
+  return err, dl_err
 
 
 def test_fullsize_fp32_gradients_match_float64_reference(case):
@@ -88,23 +113,21 @@ def test_fullsize_fp32_gradients_match_float64_reference(case):
   assert any('splits=2' in l and 'Kp=64512' in l for l in bwd_fast), text        # L8 back-prop: 2 K-halves
   slabbed = [l for l in trace if l.startswith('gemm_tn<') and 'slabs=1 ' not in l]
   assert len(slabbed) >= 9 and all('M=16032' in l for l in trace if l.startswith('gemm_tn<')), text
-  err, worst = compare(eng, case['ref'])
-  print('fp32 full-size: max|logit err| %.2e, worst gradient error %.2e of max' % (err, worst))
+  compare(eng, case['ref'], case)
 
 
 def test_fullsize_bf16x6_gradients_match_float64_reference(case):
   eng, trace = run_step(case, 'bf16x6')
   assert sum(1 for l in trace if l.startswith('gemm_nn_bf16<256,NP=3>')) >= 4, '\n'.join(trace)
-  err, worst = compare(eng, case['ref'])
-  print('bf16x6 full-size: max|logit err| %.2e, worst gradient error %.2e of max' % (err, worst))
+  compare(eng, case['ref'], case)
 
 
 def test_fullsize_update_matches_reference_adam(case):
-  """clip_by_global_norm(5) + TF-Adam on the full-size gradients: the global norm and the first update of every
-  tensor against the float64 reference gradients pushed through the oracle's optimizer (speech_model.py:77-82)."""
+  """clip_by_global_norm(5) + TF-Adam at full size: the global norm and the first update of every tensor against
+  the oracle's optimizer (speech_model.py:77-82) fed the device's own gradients (whose parity is the tests above)."""
   from oracle import w2l_oracle as O
   eng, _ = run_step(case, 'fp32')
-  flat = [g for pair in case['ref']['grads'] for g in pair]
+  flat = [g.astype(np.float64) for pair in eng.get_grads() for g in pair]
   clipped, gn = O.clip_by_global_norm(flat, 5.0)
   eng.apply_update(lr=1e-4)
   torch.cuda.synchronize()
@@ -117,4 +140,4 @@ def test_fullsize_update_matches_reference_adam(case):
       # the first Adam step moves every weight by lr * g/(|g| + eps*sqrt(1-b2)/(1-b1))-ish: compare the DELTA
       d_got, d_want = got.astype(np.float64) - p0, want - p0
       # + one fp32 rounding of the stored weight (the delta can be smaller than an ulp of the weight)
-      assert np.max(np.abs(d_got - d_want)) < 2e-3 * np.max(np.abs(d_want)) + 1.2e-7 * np.max(np.abs(p0)) + 1e-12, (i, j)
+      assert np.max(np.abs(d_got - d_want)) < 1e-4 * np.max(np.abs(d_want)) + 1.2e-7 * np.max(np.abs(p0)) + 1e-12, (i, j)

@@ -28,25 +28,59 @@ def make_params(params, dtype, requires_grad=True):
   return out
 
 
-def forward(x, tparams, layers):
-  """x [B,T,Cin] torch -> logits [B,T',C] (channels-last like the reference)."""
+def forward(x, tparams, layers, keep=None):
+  """x [B,T,Cin] torch -> logits [B,T',C] (channels-last like the reference).  ``keep``: a list that receives
+  every layer's output [B,T_i,C_i] (detached numpy)."""
   h = x.permute(0, 2, 1)
   for (w, b), (W, s, cin, cout, relu) in zip(tparams, layers):
     _, pl, pr = same_padding(h.shape[2], W, s)
     h = F.conv1d(F.pad(h, (pl, pr)), w, b, stride=s)
     if relu:
       h = torch.relu(h)
+    if keep is not None:
+      keep.append(h.detach().permute(0, 2, 1).numpy())
   return h.permute(0, 2, 1)
+
+
+def backward_from_acts(acts, params, layers, dlogits, dtype=torch.float64):
+  """Back-prop evaluated on GIVEN activations: acts[0] = the input batch, acts[i+1] = output of layer i (all
+  [B,T_i,C_i]), dlogits [B,T',C] = d avg_loss / d logits.  ReLU masks are (acts[i+1] > 0), the filter gradients
+  use acts[i] -- so feeding the device's own stored activations makes this the exact linear map the device's
+  backward kernels have to reproduce, free of the one discontinuity of the step (a pre-activation within rounding
+  of zero takes different sides in fp32 and float64 and changes every gradient below it by far more than any
+  rounding error).  torch.nn.grad.conv1d_input / conv1d_weight in float64.
+  Returns [(dF [W,Cin,Cout], db [Cout])] and the list of dz_i [B,T_i+1,C_i+1] (gradient wrt layer i's output)."""
+  from torch.nn import grad as G
+  tparams = make_params(params, dtype, requires_grad=False)
+  dy = torch.as_tensor(np.asarray(dlogits), dtype=dtype).permute(0, 2, 1)          # [B, C, T']
+  grads, dzs = [None] * len(layers), [None] * len(layers)
+  for i in reversed(range(len(layers))):
+    (w, b), (W, s, cin, cout, relu) = tparams[i], layers[i]
+    out = torch.as_tensor(np.asarray(acts[i + 1]), dtype=dtype).permute(0, 2, 1)
+    dz = dy * (out > 0).to(dtype) if relu else dy
+    x = torch.as_tensor(np.asarray(acts[i]), dtype=dtype).permute(0, 2, 1)
+    _, pl, pr = same_padding(x.shape[2], W, s)
+    xp = F.pad(x, (pl, pr))
+    dw = G.conv1d_weight(xp, w.shape, dz.contiguous(), stride=s)
+    grads[i] = (np.transpose(dw.numpy(), (2, 1, 0)).astype(np.float64), dz.sum(dim=(0, 2)).numpy().astype(np.float64))
+    dzs[i] = dz.permute(0, 2, 1).numpy()
+    if i > 0:
+      dxp = G.conv1d_input(xp.shape, w, dz.contiguous(), stride=s)
+      dy = dxp[:, :, pl:pl + x.shape[2]]
+  return grads, dzs
 
 
 def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, threads=None):
   """One forward + CTC + backward.  Returns dict(logits [T',B,C], loss [B], avg_loss,
-  grads [(dF [W,Cin,Cout], db [Cout])]) as numpy float64 -- gradients of avg_loss = mean_b loss_b."""
+  grads [(dF [W,Cin,Cout], db [Cout])], acts (input + every layer output, [B,T_i,C_i]), dlogits [B,T',C]) as
+  numpy -- gradients of avg_loss = mean_b loss_b."""
   if threads:
     torch.set_num_threads(threads)
   tparams = make_params(params, dtype)
   xt = torch.tensor(np.asarray(x), dtype=dtype)
-  logits = forward(xt, tparams, layers)                       # [B, T', C]
+  acts = []
+  logits = forward(xt, tparams, layers, keep=acts)            # [B, T', C]
+  logits.retain_grad()
   tm = logits.permute(1, 0, 2)
   lens = torch.as_tensor(np.asarray(seq_lens) // 2, dtype=torch.long)
   flat = torch.tensor([v for l in labels for v in l], dtype=torch.long)
@@ -58,7 +92,8 @@ def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, thr
   grads = [(np.transpose(w.grad.numpy(), (2, 1, 0)).astype(np.float64), b.grad.numpy().astype(np.float64))
            for w, b in tparams]
   return dict(logits=tm.detach().numpy().astype(np.float64), loss=per_utt.detach().numpy().astype(np.float64),
-              avg_loss=float(avg.detach()), grads=grads)
+              avg_loss=float(avg.detach()), grads=grads, acts=[np.asarray(x)] + acts,
+              dlogits=logits.grad.numpy().astype(np.float64))
 
 
 class TorchCpuTrainer:

@@ -166,6 +166,14 @@ int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* sta
  * ref = max, top_db 80, then (x-mean)/std over the whole matrix, written transposed as
  * out[frame_offsets[u] + t][n_mels] (frames = 1 + len/hop).  max_samples = longest utterance
  * (each must exceed n_fft/2 samples, numpy reflect padding); total_frames = frame_offsets[n_utts]. */
+/* Planned form: the sparse mel filterbank is compiled once per (sample rate, n_mels) into a device-side plan
+ * (st_melspec_plan_bytes() bytes, 16-byte aligned) and st_melspec_planned_f32 runs without touching mel_basis;
+ * st_melspec_f32 is the one-call form that rebuilds the plan inside its workspace on every call. */
+size_t st_melspec_plan_bytes(void);
+int st_melspec_plan_f32(const float* mel_basis, int n_mels, int n_fft, void* plan, size_t plan_bytes, void* stream);
+int st_melspec_planned_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
+                           const void* plan, int n_mels, int n_fft, int hop, const int64_t* frame_offsets,
+                           int64_t total_frames, float* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t st_melspec_ws(int n_utts, int64_t total_frames, int n_mels);
 int st_melspec_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
                    const float* mel_basis, int n_mels, int n_fft, int hop,

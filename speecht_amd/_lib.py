@@ -56,6 +56,10 @@ _SIGNATURES = {
                                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                                    c_void_p]),
     'st_global_norm_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_melspec_plan_bytes': (c_size_t, []),
+    'st_melspec_plan_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'st_melspec_planned_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_melspec_ws': (c_size_t, [c_int, c_int64, c_int]),
     'st_melspec_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -399,6 +399,42 @@ def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
     assert np.max(np.abs(feats[0] - gold)) < 1e-3
 
 
+@pytest.mark.parametrize('n_mels', [13, 40, 256])
+def test_melspec_filterbank_extremes_and_planned_form(dev, n_mels):
+  """Few wide filters (13 mels: up to 60 bins = 4 plan pieces each, summed in plan order), many narrow ones
+  (256 mels: 9+ projection rounds), an odd frame count (the last frame pair is half empty), and the planned entry
+  points (st_melspec_plan_f32 once + st_melspec_planned_f32) bit-identical to the one-call form, run to run."""
+  import ctypes
+  from speecht_amd import _lib
+  from speecht_amd.preprocessing import calc_power_spectrogram_batch, mel_filterbank
+  sr = 16000
+  audio = [O.synthetic_audio(21, 16000), O.synthetic_audio(22, 8000 + 159), O.synthetic_audio(23, 4000)]   # 101, 51, 26 frames
+  feats = calc_power_spectrogram_batch(audio, sr, n_mels=n_mels)
+  for a, f in zip(audio, feats):
+    ref = O.calc_power_spectrogram(a, sr, n_mels=n_mels)
+    assert f.shape == ref.shape and np.max(np.abs(f - ref)) < 1e-3
+  lens = np.array([len(a) for a in audio], dtype=np.int64)
+  s_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+  f_off = np.concatenate([[0], np.cumsum(1 + lens // 160)]).astype(np.int64)
+  total = int(f_off[-1])
+  d = lambda a: torch.as_tensor(a).to(dev)
+  x, so, fo = d(np.concatenate(audio)), d(s_off), d(f_off)
+  basis = d(mel_filterbank(float(sr), 512, n_mels).astype(np.float32)).contiguous()
+  lib = _lib.load()
+  plan = torch.empty(lib.st_melspec_plan_bytes() // 4, dtype=torch.float32, device=dev)
+  ws = torch.empty(lib.st_melspec_ws(len(audio), total, n_mels) // 4 + 64, dtype=torch.float32, device=dev)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  _lib.call('st_melspec_plan_f32', P(basis), n_mels, 512, P(plan), plan.numel() * 4, None)
+  outs = []
+  for _ in range(2):
+    out = torch.empty(total * n_mels, dtype=torch.float32, device=dev)
+    _lib.call('st_melspec_planned_f32', P(x), P(so), len(audio), int(lens.max()), P(plan), n_mels, 512, 160, P(fo),
+              total, P(out), P(ws), ws.numel() * 4, None)
+    outs.append(out.view(total, n_mels).cpu().numpy())
+  np.testing.assert_array_equal(outs[0], outs[1])
+  np.testing.assert_array_equal(outs[0], np.concatenate(feats))
+
+
 def test_mfcc_vs_oracle(dev):
   """calc_mfccs (preprocessing.py:61-84): 13 MFCC + delta + delta-delta, each block z-normalised; ragged
   batch.  Tolerance 2e-3 absolute on unit-variance features (fp32 FFT/log10/DCT vs float64; the delta-delta

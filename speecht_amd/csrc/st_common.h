@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...);
 bool trace_on();
 void trace(const char* fmt, ...);
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_MEL_VARIANT, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_COUNT };
 int tuning(int key);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

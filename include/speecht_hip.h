@@ -100,6 +100,13 @@ size_t st_conv1d_bwd_data_ws(const st_tensor3* dz, const st_tensor3* dx, int wid
 int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int width,
                                int pad_left, const st_tensor3* act, const st_tensor3* dx,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* Same, and additionally dbias_dx[n_pad of dx->channels] = column sums of the dx just written: the bias gradient
+ * of the layer BELOW (its pre-activation gradient is dx), collected in the epilogue of the kernel that writes dx
+ * instead of by a second pass over up to 129 MB.  Workspace: st_conv1d_bwd_data_bias_ws bytes. */
+size_t st_conv1d_bwd_data_bias_ws(const st_tensor3* dz, const st_tensor3* dx, int width);
+int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
+                                    const st_tensor3* act, const st_tensor3* dx, float* dbias_dx,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width);
 /* bias gradient alone: dbias[o] = sum_{b,t} dz[b,t,o]  (n_pad floats) */
 size_t st_bias_grad_ws(const st_tensor3* dz);

@@ -36,6 +36,9 @@ _SIGNATURES = {
                                           c_void_p]),
     'st_conv1d_bwd_data_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_data_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_size_t, c_void_p]),
+    'st_conv1d_bwd_data_bias_ws': (c_size_t, [_T3P, _T3P, c_int]),
+    'st_conv1d_nwc_bwd_data_bias_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p, c_size_t,
+                                                c_void_p]),
     'st_conv1d_bwd_filter_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_filter_f32': (c_int, [_T3P, _T3P, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                              c_size_t, c_void_p]),

@@ -53,6 +53,8 @@ struct NNParams {
   int gm, tm_per, tn_per;            // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per)
   int splits, steps_per_split;       // split-K over blockIdx.y: raw partial tiles go to `slab`
   float* slab;                       // [splits][M][Np]
+  float* colsum;                     // EPI 1, optional: column sums of the stored tile rows, one row of Np floats per
+  int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
 };
 
 // ------------------------------------------------------------------------------------
@@ -331,6 +333,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     return;
   }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
+  float csum[NT];                                // EPI 1 + p.colsum: this lane's share of the column sums
+#pragma unroll
+  for (int n = 0; n < NT; ++n) csum[n] = 0.f;
   bvec bv;
 #pragma unroll
   for (int n = 0; n < NT; ++n) vset<NT>(bv, n, (EPI == 0 && p.bias && col_ok) ? p.bias[col0 + n] : 0.f);
@@ -363,11 +368,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
           } else if (p.mask) {
             v = vget<NT>(mk[r], n) > 0.f ? v : 0.f;
           }
+          if (EPI == 1) csum[n] += v;
           vset<NT>(out, n, v);
         }
         *reinterpret_cast<bvec*>(p.C + co + col0) = out;
       }
     }
+  }
+  if (EPI == 1 && p.colsum) {
+    // the gradient tile just stored is also the operand of the bias gradient of the layer below: its column sums
+    // over this wave's rows (lanes l and l + 32 hold the same columns, other rows), fixed order, no atomics
+    bvec out;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) vset<NT>(out, n, csum[n] + __shfl_xor(csum[n], 32, 64));
+    if (h == 0) *reinterpret_cast<bvec*>(p.colsum + (long)(tile_m * WMW + wm) * p.Np + col0) = out;
   }
 }
 
@@ -752,6 +766,10 @@ int nn_splits(int M, int Np, int Kp) {
 // the workgroups 0.363).
 int fwd_splits(int M, int Np, int nk) {
   const int forced = st::tuning(st::TUNE_FWD_SPLITS);
+  // The 29-class output layer at full batch (L10: 16032 x 2016 x 32) is an HBM stream of the activations with
+  // one 128-row tile per workgroup: 126 workgroups leave half the CUs without any and every workgroup walks 1 MB
+  // alone (72 us for 130 MB).  Four slices of the reduction put ~2 workgroups on every CU.
+  if (Np == 32 && !forced) return (M >= 4096 && nk >= 32) ? 4 : 1;
   if (Np % 128) return 1;
   const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
   if (forced) return std::max(1, std::min(forced, nk));
@@ -783,6 +801,7 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.tn_per = st::ceil_div(p.tiles_n, 8 / p.gm);
     p.chunk = p.tm_per * p.tn_per;
   }
+  p.colsum_rows = p.tiles_m * WMW;
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
             FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
@@ -952,6 +971,19 @@ size_t st_conv1d_bwd_data_ws(const st_tensor3* dz, const st_tensor3* dx, int wid
 int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
                                const st_tensor3* act, const st_tensor3* dx, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  return st_conv1d_nwc_bwd_data_bias_f32(dz, packed_t, width, pad_left, act, dx, nullptr, workspace, workspace_bytes, stream);
+}
+
+size_t st_conv1d_bwd_data_bias_ws(const st_tensor3* dz, const st_tensor3* dx, int width) {
+  if (!dz || !dx) return 0;
+  const int np = npad_of(dx->channels);
+  const size_t rows = (size_t)std::max(st::ceil_div(dx->batch * dx->frames, 64) * 4, dx->batch * st::ceil_div(dx->frames, COLSUM_ROWS));
+  return st::round_up(st_conv1d_bwd_data_ws(dz, dx, width), 256) + rows * np * sizeof(float) + 256;
+}
+
+int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
+                                    const st_tensor3* act, const st_tensor3* dx, float* dbias_dx, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && packed_t, "conv bwd_data: bad tensor descriptor");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames, "conv bwd_data: stride-1 layers only");
   const int lead = width - 1 - pad_left;   // zero rows needed in front of dz frame 0
@@ -986,7 +1018,26 @@ int st_conv1d_nwc_bwd_data_f32(const st_tensor3* dz, const float* packed_t, int 
     p.splits = st::ceil_div(nk, p.steps_per_split);
     p.slab = reinterpret_cast<float*>(workspace);
   }
-  return run_nn(p, 1, st::as_stream(stream));
+  if (!dbias_dx) return run_nn(p, 1, st::as_stream(stream));
+  // bias gradient of the layer below = column sums of dx.  One-pass launches collect them in the epilogue of the
+  // kernel that writes dx (no second read of up to 129 MB); split-K launches finish in splitk_epilogue_kernel, so
+  // there the two-level column sum reads dx back.
+  ST_REQUIRE(workspace && workspace_bytes >= st_conv1d_bwd_data_bias_ws(dz, dx, width), "conv bwd_data: workspace too small for the bias gradient");
+  hipStream_t s = st::as_stream(stream);
+  float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + st::round_up(st_conv1d_bwd_data_ws(dz, dx, width), 256));
+  if (p.splits <= 1) p.colsum = partial;
+  if (int e = run_nn(p, 1, s)) return e;
+  if (p.splits <= 1) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(st::ceil_div(p.Np, 32)), dim3(256), 0, s, partial, p.colsum_rows, p.Np, dbias_dx);
+  } else {
+    const int chunks = st::ceil_div(dx->frames, COLSUM_ROWS);
+    const RowMap xmap = make_map(*dx, dx->halo, 1, dx->frames);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(st::ceil_div(p.Np, 128), chunks, dx->batch), dim3(256), 0, s, dx->base,
+                       xmap.batch_stride, xmap.row0, xmap.row_stride, dx->frames, dx->channels, dx->c_pitch, partial, p.Np);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(st::ceil_div(p.Np, 32)), dim3(256), 0, s, partial, chunks * dx->batch, p.Np,
+                       dbias_dx);
+  }
+  return st::check_launch("bwd_data bias gradient");
 }
 
 static int bwd_filter_splits(int M, int kp, int np) {

@@ -282,7 +282,7 @@ class Wav2LetterEngine:
     self.t_out = geo[-1][1]
     lib = _lib.load()
     ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
-    ws = max([ws] + [lib.st_conv1d_bwd_data_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
+    ws = max([ws] + [lib.st_conv1d_bwd_data_bias_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
     ws = max([ws] + [lib.st_conv1d_fwd_ws(self.X[i].ref, self.X[i + 1].ref, l.width) for i, l in enumerate(self.layers)])
     if self.conv_mode == 'bf16x6':
@@ -557,6 +557,31 @@ class Wav2LetterEngine:
     self.label_ids = self._upload_i32(ids)
     self.label_offs = self._upload_i32(offs)
 
+  def _on_side_stream(self, fn):
+    """Run ``fn`` (which enqueues kernels through ``self.stream_ptr``) on the engine's side stream, ordered after
+    everything enqueued so far on the compute stream; ``_join_side_stream`` makes the compute stream wait for it.
+    Used to put small HBM-bound operand preparation next to the CTC recursion, which is a latency chain of 500
+    dependent steps on 64 wavefronts and leaves the rest of the chip idle."""
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    if getattr(self, '_side', None) is None:
+      self._side = torch.cuda.Stream(self.device)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    self._side.wait_event(fork)
+    saved, self._stream = self._stream, self._side
+    try:
+      fn()
+    finally:
+      self._stream = saved
+    self._side_done = torch.cuda.Event()
+    self._side_done.record(self._side)
+
+  def _join_side_stream(self):
+    done = getattr(self, '_side_done', None)
+    if done is not None:
+      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(done)
+      self._side_done = None
+
   def ctc_loss_grad(self, grad_scale):
     B, T = self.X[-1].batch, self.X[-1].frames
     lib = _lib.load()
@@ -565,6 +590,13 @@ class Wav2LetterEngine:
       raise ValueError('label of length {} is too long for the CTC kernel (max 511)'.format(self.max_label_len))
     if self.ctc_ws is None or self.ctc_ws.numel() * 4 < need:
       self.ctc_ws = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
+    # the filter operands of back-prop (flipped / transposed copies of the weights Adam just updated) are rebuilt
+    # on the side stream while the CTC recursion runs
+    if self.conv_mode == 'bf16':
+      if not self._wtplanes_fresh and hasattr(self, 'WTb'):
+        self._on_side_stream(lambda: self._refresh_bf16_filters(True))
+    elif not self._packed_t_fresh:
+      self._on_side_stream(self.refresh_packed_t)
     call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
          self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
@@ -585,13 +617,16 @@ class Wav2LetterEngine:
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
     called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce)."""
     s = self.stream_ptr
+    self._join_side_stream()
     if self.conv_mode == 'bf16':
       return self._backward_bf16(on_layer_done)
     if not self._packed_t_fresh:
       self.refresh_packed_t()
+    bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
+      need_bias, bias_from_above = not bias_from_above, False
       if self.conv_mode == 'bf16x6' and self._x6_wgrad(i):
         tq, red = self.tq[i], self.X[i].batch * self.tq[i]
         call('st_exp_transpose_split3_bf16', self.X[i].ref, 0, self.X[i].t_pitch, tq, l.cin_pitch * red + 4096,
@@ -600,10 +635,11 @@ class Wav2LetterEngine:
              self._ptr(self.dZTp[i]), s)
         call('st_exp_conv1d_bwd_filter_bf16x6', self._ptr(self.XTp[i]), self._ptr(self.dZTp[i]), self.X[i].batch, tq,
              l.width, l.cin_pitch, self.X[i].halo - self.geo[i][2], l.cout, self._ptr(gf), s)
-        call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+        if need_bias:
+          call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
-             self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+             self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       if on_layer_done is not None:
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):
@@ -617,9 +653,12 @@ class Wav2LetterEngine:
              self.geo[i][2], act, self.dZ[i - 1].ref, dxp, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
+        # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1
         act = self.X[i].ref if self.layers[i - 1].relu else None
-        call('st_conv1d_nwc_bwd_data_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
-             act, self.dZ[i - 1].ref, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+        call('st_conv1d_nwc_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
+             act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
+             self.wgrad_ws.numel() * 4, s)
+        bias_from_above = True
 
   def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
     """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""

@@ -50,7 +50,11 @@ def test_fullsize_batch_independence_bit_exact(full):
   split_small_batches=False keeps the one-pass kernels and with them bit-exact batch invariance."""
   from speecht_amd.engine import Wav2LetterEngine
   eng = full['eng']
-  b = eng.X[-1].interior()[5]
+  # the one-pass kernels for the full batch too (by default its 29-class output layer splits its reduction)
+  eng.split_small_batches = False
+  eng.forward()
+  eng.split_small_batches = True
+  b = eng.X[-1].interior()[5].clone()
   for split in (False, True):
     solo = Wav2LetterEngine(full['layers'], device='cuda:0', split_small_batches=split)
     solo.params.copy_(eng.params)

@@ -61,6 +61,9 @@ const char* st_last_error(void);
 int st_trace_begin(void);
 size_t st_trace_end(char* host_buf, size_t capacity);
 int st_set_tuning(const char* name, int value);
+/* CRC-32C of a HOST buffer, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint bundles carry
+ * (speech_model.py:122 tf.train.Saver; read and written by speecht_amd/tf_checkpoint.py). */
+uint32_t st_host_crc32c(const void* host_data, size_t n, uint32_t crc);
 
 /* ---- filter packing -------------------------------------------------------------------
  * Reference filters are [W, Cin, Cout] (speech_model.py:148-151; the `export --weights`

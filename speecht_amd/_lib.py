@@ -26,6 +26,7 @@ _SIGNATURES = {
     'st_trace_begin': (c_int, []),
     'st_trace_end': (c_size_t, [c_char_p, c_size_t]),
     'st_set_tuning': (c_int, [c_char_p, c_int]),
+    'st_host_crc32c': (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     'st_packed_dims': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'st_pack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'st_unpack_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

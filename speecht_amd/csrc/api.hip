@@ -62,6 +62,36 @@ size_t st_trace_end(char* host_buf, size_t capacity) {
   return need;
 }
 
+// CRC-32C (Castagnoli) on the HOST, slicing-by-8: the checksum of TensorFlow's checkpoint bundles
+// (speecht_amd/tf_checkpoint.py reads / writes the reference's speechT.ckpt-N files, speech_model.py:122,251-260).
+uint32_t st_host_crc32c(const void* host_data, size_t n, uint32_t crc) {
+  static uint32_t table[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+  });
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(host_data);
+  crc = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+          table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) crc = (crc >> 8) ^ table[0][(crc ^ *p++) & 0xFF];
+  return ~crc;
+}
+
 int st_set_tuning(const char* name, int value) {
   ST_REQUIRE(name, "st_set_tuning: null name");
   for (int i = 0; i < st::TUNE_COUNT; ++i)

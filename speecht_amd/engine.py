@@ -202,19 +202,32 @@ class Wav2LetterEngine:
     return ctypes.c_void_p(t.data_ptr())
 
   # ---- weights in the reference's layout (exporting.py:30-40: [W, Cin, Cout] + [Cout]) ----------
-  def set_weights(self, params):
-    """params: list of (filters [W,Cin,Cout], bias [Cout]) numpy arrays."""
-    self.params.zero_()
+  def _pack(self, flat, params):
+    """Fill one of the flat buffers (weights, Adam m or v) from per-layer arrays in the reference's layout."""
+    flat.zero_()
     for i, ((F, b), l) in enumerate(zip(params, self.layers)):
       assert F.shape == (l.width, l.cin, l.cout) and b.shape == (l.cout,), (i, F.shape, b.shape)
       Fd = torch.as_tensor(np.ascontiguousarray(F), dtype=torch.float32).to(self.device).contiguous()
-      pf, pb = self._slice(self.params, i)
+      pf, pb = self._slice(flat, i)
       call('st_pack_filters_f32', self._ptr(Fd), l.width, l.cin, l.cout, l.cin_pitch, self._ptr(pf), self.stream_ptr)
       pb[:l.cout] = torch.as_tensor(np.asarray(b), dtype=torch.float32).to(self.device)
     torch.cuda.synchronize(self.device)
+
+  def set_weights(self, params):
+    """params: list of (filters [W,Cin,Cout], bias [Cout]) numpy arrays."""
+    self._pack(self.params, params)
     self._packed_t_fresh = False
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
+
+  def set_adam_state(self, m, v, step):
+    """Adam moments in the reference's layout (lists like ``set_weights``) and the number of updates applied."""
+    self._pack(self.adam_m, m)
+    self._pack(self.adam_v, v)
+    self.step_count = int(step)
+
+  def get_adam_state(self):
+    return self._unpack(self.adam_m), self._unpack(self.adam_v)
 
   def mark_weights_changed(self):
     """Call after writing ``self.params`` directly: derived operand copies are rebuilt on next use."""

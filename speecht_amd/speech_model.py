@@ -85,7 +85,10 @@ class _Saver:
     the checkpoint directory (so a moved train dir or another cwd still restores) and lists the last
     MAX_TO_KEEP checkpoints; older ones are deleted.  Files are written to a temporary name and renamed, so a
     crash never leaves a truncated checkpoint behind the index.  In data-parallel training only rank 0 writes
-    (the replicas are identical)."""
+    (the replicas are identical).  ``model.checkpoint_format = 'tf'`` (CLI ``--tf-checkpoints``) writes TensorFlow
+    bundles instead (``save_tf``)."""
+    if getattr(self.model, 'checkpoint_format', 'npz') == 'tf':
+      return self.save_tf(sess, save_path, global_step)
     step = global_step.eval() if hasattr(global_step, 'eval') else global_step
     path = '{}-{}'.format(save_path, step) if step is not None else save_path
     if getattr(self.model, '_rank', 0) != 0:
@@ -118,8 +121,77 @@ class _Saver:
     os.replace(index_path + '.tmp', index_path)
     return path
 
+  # ---- the reference's own format: TensorFlow V2 bundles (tf.train.Saver, speech_model.py:122) --------------------
+  def save_tf(self, sess, save_path, global_step=None):
+    """``<save_path>-<step>.index`` / ``.data-00000-of-00001`` + TF's text ``checkpoint`` file, with the reference's
+    variable names, so that the reference (or anything that reads TF checkpoints) can restore this model."""
+    from . import tf_checkpoint as tfc
+    step = global_step.eval() if hasattr(global_step, 'eval') else global_step
+    path = '{}-{}'.format(save_path, step) if step is not None else save_path
+    if getattr(self.model, '_rank', 0) != 0:
+      return path
+    eng = self.model.engine
+    weights = eng.get_weights()
+    m, v = eng.get_adam_state()
+    t = eng.step_count
+    tensors = {'Variable': np.array(self.model.global_step.eval(), dtype=np.int32),
+               'learning_rate': np.array(self.model.learning_rate.eval() if hasattr(self.model, 'learning_rate') else 0.0,
+                                         dtype=np.float32),
+               'beta1_power': np.array(0.9 ** (t + 1), dtype=np.float32), 'beta2_power': np.array(0.999 ** (t + 1), dtype=np.float32)}
+    for i, ((F, b), (mF, mb), (vF, vb)) in enumerate(zip(weights, m, v)):
+      scope = 'convolution_layer_{}'.format(i)
+      tensors.update({scope + '/filters': F, scope + '/bias': b, scope + '/filters/Adam': mF, scope + '/bias/Adam': mb,
+                      scope + '/filters/Adam_1': vF, scope + '/bias/Adam_1': vb})
+    tfc.write_bundle(path, tensors)
+    directory = os.path.dirname(path) or '.'
+    state = tfc.read_checkpoint_state(directory)
+    kept = [os.path.basename(p) for p in (state[1] if state else []) if os.path.basename(p) != os.path.basename(path)]
+    kept.append(os.path.basename(path))
+    for old in kept[:-self.MAX_TO_KEEP]:
+      for suffix in ('.index', '.data-00000-of-00001'):
+        try:
+          os.remove(os.path.join(directory, old + suffix))
+        except OSError:
+          pass
+    tfc.write_checkpoint_state(directory, os.path.basename(path), kept[-self.MAX_TO_KEEP:])
+    return path
+
+  def restore_tf(self, sess, prefix):
+    """Restore a checkpoint written by the reference (or by ``save_tf``): filters / biases are required, Adam
+    slots, global_step and learning_rate are taken when present (``export --weights``-style files have none)."""
+    from . import tf_checkpoint as tfc
+    eng = self.model.engine
+    layers, scalars = tfc.split_variables(tfc.read_bundle(prefix))
+    def per_layer(slot):
+      out = []
+      for i, l in enumerate(eng.layers):
+        vs = layers.get(i, {})
+        if ('filters', slot) not in vs or ('bias', slot) not in vs:
+          return None
+        out.append((vs[('filters', slot)], vs[('bias', slot)]))
+      return out
+    weights = per_layer(None)
+    if weights is None:
+      raise ValueError('checkpoint {} does not hold convolution_layer_0..{} filters and biases'.format(prefix, len(eng.layers) - 1))
+    for (F, b), l in zip(weights, eng.layers):
+      if F.shape != (l.width, l.cin, l.cout) or b.shape != (l.cout,):
+        raise ValueError('checkpoint {} does not match the model layout'.format(prefix))
+    eng.set_weights(weights)
+    step = int(scalars['Variable']) if 'Variable' in scalars else int(scalars.get('global_step', 0))
+    m, v = per_layer('Adam'), per_layer('Adam_1')
+    if m is not None and v is not None:
+      eng.set_adam_state(m, v, step)
+    else:
+      eng.adam_m.zero_(); eng.adam_v.zero_()
+      eng.step_count = 0
+    self.model.global_step.value = step
+    if hasattr(self.model, 'learning_rate') and 'learning_rate' in scalars:
+      self.model.learning_rate.value = float(scalars['learning_rate'])
+
   def restore(self, sess, path):
     import torch
+    if not path.endswith('.npz'):
+      return self.restore_tf(sess, path)
     eng = self.model.engine
     with np.load(path) as ck:
       if ck['params'].shape[0] != eng.n_flat:
@@ -139,7 +211,19 @@ def latest_checkpoint(checkpoint_directory):
   index = os.path.join(checkpoint_directory, 'checkpoint')
   if not os.path.exists(index):
     return None
-  path = json.load(open(index)).get('model_checkpoint_path')
+  try:
+    path = json.load(open(index)).get('model_checkpoint_path')
+  except ValueError:
+    # not this package's JSON index: TensorFlow's text CheckpointState (the reference's own train directories and
+    # its published weights, README.md:72-79) names a bundle prefix
+    from . import tf_checkpoint as tfc
+    state = tfc.read_checkpoint_state(checkpoint_directory)
+    if not state:
+      return None
+    for prefix in (state[0], os.path.join(checkpoint_directory, os.path.basename(state[0]))):
+      if os.path.exists(prefix + '.index'):
+        return prefix
+    return None
   if not path:
     return None
   # names in the index are relative to the checkpoint directory (indices written before that hold a path
@@ -374,4 +458,5 @@ def create_default_model(flags, input_size: int, speech_input: BaseInputLoader) 
                            valid_word_count_weight=getattr(flags, 'valid_word_count_weight', 2.3),
                            beam_width=getattr(flags, 'beam_width', 0))
   model.finalize(log_dir=flags.log_dir, run_name=flags.run_name, run_type=flags.run_type)
+  model.checkpoint_format = 'tf' if getattr(flags, 'tf_checkpoints', False) else 'npz'
   return model

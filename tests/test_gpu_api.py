@@ -406,3 +406,40 @@ def test_input_pipeline_stages_batches_on_the_device(dev, tmp_path):
     with pytest.raises(OutOfRangeError):
       model.step(sess)
   coord.request_stop()
+
+
+def test_tensorflow_checkpoint_bundle_round_trip(dev, tmp_path):
+  """The reference's own checkpoint format (tf.train.Saver V2 bundles, speech_model.py:122,251-260): train a few
+  steps, save as `speechT.ckpt-N.{index,data-00000-of-00001}` + TF's text `checkpoint` file with the reference's
+  variable names, restore through `restore()` (auto-detected) into a fresh model: weights, Adam moments, global
+  step and learning rate come back bit-exact and the next training step is bit-identical to the original's."""
+  from speecht_amd import tf_checkpoint as tfc
+  from speecht_amd.speech_model import Session, create_default_model
+  flags = Flags()
+  flags.log_dir = str(tmp_path / 'log')
+  flags.tf_checkpoints = True
+  models = []
+  for _ in range(2):
+    loader, coord, _data = make_loader(16, 4, [121, 100, 90, 121], seed=2)
+    models.append((create_default_model(flags, 16, loader), coord))
+  (a, ca), (b, cb) = models
+  ck = str(tmp_path / 'run')
+  os.makedirs(ck)
+  with Session(dev) as sess:
+    a.init_session(sess)
+    for _ in range(3):
+      a.step(sess)
+    a.learning_rate.value = 2.5e-4
+    a.saver.save(sess, os.path.join(ck, 'speechT.ckpt'), global_step=a.global_step)
+    assert sorted(os.listdir(ck)) == ['checkpoint', 'speechT.ckpt-3.data-00000-of-00001', 'speechT.ckpt-3.index']
+    names = set(tfc.read_bundle(os.path.join(ck, 'speechT.ckpt-3'), names=lambda n: 'layer_10' in n or '/' not in n))
+    assert {'Variable', 'learning_rate', 'beta1_power', 'beta2_power', 'convolution_layer_10/filters',
+            'convolution_layer_10/bias/Adam_1'} <= names
+    b.init_session(sess)                                          # different random weights
+    b.restore(sess, ck)
+    ea, eb = a.engine, b.engine
+    assert torch.equal(ea.params, eb.params) and torch.equal(ea.adam_m, eb.adam_m) and torch.equal(ea.adam_v, eb.adam_v)
+    assert b.global_step.eval() == 3 and eb.step_count == 3 and b.learning_rate.eval() == pytest.approx(2.5e-4)
+    la, lb = a.step(sess)[0], b.step(sess)[0]
+    assert la == lb and torch.equal(ea.params, eb.params)
+  ca.request_stop(); cb.request_stop()

@@ -429,7 +429,7 @@ def test_tensorflow_checkpoint_bundle_round_trip(dev, tmp_path):
     a.init_session(sess)
     for _ in range(3):
       a.step(sess)
-    a.learning_rate.value = 2.5e-4
+    a.learning_rate.value = float(np.float32(2.5e-4))             # the reference's learning_rate is a float32 variable
     a.saver.save(sess, os.path.join(ck, 'speechT.ckpt'), global_step=a.global_step)
     assert sorted(os.listdir(ck)) == ['checkpoint', 'speechT.ckpt-3.data-00000-of-00001', 'speechT.ckpt-3.index']
     names = set(tfc.read_bundle(os.path.join(ck, 'speechT.ckpt-3'), names=lambda n: 'layer_10' in n or '/' not in n))

@@ -56,7 +56,7 @@ const char* st_last_error(void);
  * returns the bytes needed including the terminator.  Used by the parity tests to assert which kernels a
  * full-size step really ran.
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_prio"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 size_t st_trace_end(char* host_buf, size_t capacity);
@@ -91,6 +91,38 @@ size_t st_conv1d_fwd_ws(const st_tensor3* x, const st_tensor3* y, int width);
 int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const float* bias, int width,
                              int stride, int pad_left, int relu, const st_tensor3* y, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* ---- frequency-domain form of the same three operations for long, wide filters (csrc/conv_fft.hip) ----------
+ * For the model's 32-tap 250 -> 2000 layer (speech_model.py:285; 66 % of the step's MACs) time is cut into blocks,
+ * every block is taken to the frequency domain by a length-N DFT (N <= 128 chosen by st_conv1d_fft_plan), the W taps
+ * become one complex channel-contraction per frequency bin -- run as real GEMMs on the exact-fp32 MFMA kernel --
+ * and the result comes back by an inverse DFT fused with the bias / ReLU / mask epilogue: ~10x fewer
+ * multiplications than the W-tap form, same fp32 arithmetic class (tests/test_gpu_fft_conv.py).  stride 1 only;
+ * both channel counts must pack to multiples of 128.
+ *   twiddles  2 * N floats, filled once per (width, frames, batch) by st_conv1d_fft_twiddles_f32
+ *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats each), rebuilt by
+ *             st_conv1d_fft_filters_f32 whenever the weights change (gbwd from the flipped / transposed copy)
+ *   sf/sft    spectra of the layer input, written by the forward call and read by the filter-gradient call
+ *             (st_conv1d_fft_sf_floats floats each)
+ *   workspace st_conv1d_fft_ws bytes, scratch of one call */
+int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
+int st_conv1d_fft_twiddles_f32(int width, int frames, int batch, float* twiddles, size_t twiddle_floats, void* stream);
+size_t st_conv1d_fft_filter_floats(int width, int frames, int batch, int cin_pitch, int cout_pitch, int cin, int cout,
+                                   int backward);
+int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int frames, int batch, int cin,
+                              int cout, int cin_pitch, int cout_pitch, const float* twiddles, float* gfwd, float* gbwd,
+                              void* stream);
+size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width);
+size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width);
+int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
+                              const st_tensor3* y, const float* twiddles, float* sf, float* sft, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* gbwd, int width, int pad_left, const st_tensor3* act,
+                                   const st_tensor3* dx, const float* twiddles, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, int width,
+                                     const float* twiddles, float* dpacked, void* workspace, size_t workspace_bytes,
+                                     void* stream);
 
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),

@@ -20,7 +20,12 @@ def main():
   ap.add_argument('--frames', type=int, default=1001)
   ap.add_argument('--reps', type=int, default=10)
   ap.add_argument('--layers', type=str, default='0,1,8,9,10')
+  ap.add_argument('--tune', action='append', default=[], help='name=value tuning override (st_set_tuning)')
   args = ap.parse_args()
+  from speecht_amd._lib import set_tuning
+  for kv in args.tune:
+    k, v = kv.split('=')
+    set_tuning(k, int(v))
   layers = WL.w2l_layers(80)
   eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode='bf16')
   eng.set_weights(WL.xavier_params(layers, seed=42, dtype=np.float32))

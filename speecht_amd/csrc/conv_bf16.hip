@@ -220,6 +220,7 @@ struct X6Params {
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
   int tiles_m, tiles_n, chunk;
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+  int prio_mode;                         // experiment (st_set_tuning "bf16_prio"): see the ping-pong loop
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -392,6 +393,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       if (full_ring) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * N_DMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    // wave priorities (MI355X_MICROARCH.md "Two waves per SIMD"): VALU issue between the two waves of a SIMD goes
+    // by priority, then age.  mode 0: the MFMA phase runs at priority 1 (round 1); 1: no priorities; 2: the READ
+    // phase at priority 1; 3: static priority 1 for the younger group, no per-phase flips
+    const int prio_mode = p.prio_mode;
+    if (prio_mode == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
     if (grp == 1) phase_barrier();                   // group 1 runs one phase behind
     for (int kt = 0; kt < nk; ++kt) {
       const int nks = FAST ? KS : tile_ks(tap, chunk);
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       const unsigned short* bs = Bs + cur * NP * PL;
       bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
       // ---- read phase (the other group is in its MFMA phase)
+      if (prio_mode == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -419,13 +426,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       }
       if (grp == 1) wait_stage(more);                // this barrier is group 0's end-of-stage barrier
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (prio_mode == 2) __builtin_amdgcn_s_setprio(0);
       phase_barrier();
       // ---- MFMA phase: nothing but the matrix instructions (the other group reads / issues DMA)
-      __builtin_amdgcn_s_setprio(1);
+      if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         if (ks < nks) mfma_terms(af, bf, ks);
-      __builtin_amdgcn_s_setprio(0);
+      if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
       if (grp == 0) wait_stage(more);
       phase_barrier();
       cur = cur + 1 == ST ? 0 : cur + 1;
@@ -625,6 +633,7 @@ __global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restr
 template <int NP>
 int launch_gemm(X6Params& p, hipStream_t s) {
   const int forced_tile = st::tuning(st::TUNE_BF16_TILE);
+  p.prio_mode = st::tuning(st::TUNE_BF16_PRIO);
   if (p.splits < 1) p.splits = 1;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
   const bool wide = (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192;

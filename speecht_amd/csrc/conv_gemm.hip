@@ -55,6 +55,8 @@ struct NNParams {
   float* slab;                       // [splits][M][Np]
   float* colsum;                     // EPI 1, optional: column sums of the stored tile rows, one row of Np floats per
   int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
+  int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
+  long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
 };
 
 // ------------------------------------------------------------------------------------
@@ -123,10 +125,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // the CUs sharing the L2 stream the same filter panel together.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
-  const int xm = xcd % p.gm, xn = xcd / p.gm;
-  const int ln = local / p.tm_per, lm = local - ln * p.tm_per;
-  const int tile_m = xm * p.tm_per + lm, tile_n = xn * p.tn_per + ln;
-  if (local >= p.chunk || tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+  int tile_m, tile_n;
+  const float* __restrict__ Abase = p.A;
+  const float* __restrict__ Bbase = p.Bm;
+  float* __restrict__ Cbase = p.C;
+  if (p.batches > 0) {
+    // Batched mode: bin = 8 * set + xcd -- all tiles of one bin run on ONE XCD, whose L2 then holds that bin's
+    // operands (a bin's filter matrix is 8 MB: spread over the XCDs every L2 would stream all of them).
+    // Row tiles fastest, so the workgroups sharing a filter panel sit next to each other.
+    const int per_bin = p.tiles_m * p.tiles_n;
+    const int set = local / per_bin, t = local - set * per_bin;
+    const int bin = set * 8 + xcd;
+    if (bin >= p.batches) return;
+    tile_n = t / p.tiles_m;
+    tile_m = t - tile_n * p.tiles_m;
+    Abase += (long)bin * p.a_batch;
+    Bbase += (long)bin * p.b_batch;
+    Cbase += (long)bin * p.c_batch;
+  } else {
+    const int xm = xcd % p.gm, xn = xcd / p.gm;
+    const int ln = local / p.tm_per, lm = local - ln * p.tm_per;
+    tile_m = xm * p.tm_per + lm;
+    tile_n = xn * p.tn_per + ln;
+    if (local >= p.chunk || tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
@@ -152,13 +174,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
     const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
-    asrc[i] = p.A + a_off[row];
+    asrc[i] = Abase + a_off[row];
     aslot4[i] = (((lane & 7) ^ ((row >> 1) & 7))) * 4;
   }
   const float* bsrc[B_DMA];
 #pragma unroll
   for (int i = 0; i < B_DMA; ++i) {
-    bsrc[i] = p.Bm + n0 + (lane % B_LPR) * 4;
+    bsrc[i] = Bbase + n0 + (lane % B_LPR) * 4;
   }
   const int ktail = p.Kvalid - 4;   // last float4 inside the valid reduction range
 
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
           if (EPI == 1) csum[n] += v;
           vset<NT>(out, n, v);
         }
-        *reinterpret_cast<bvec*>(p.C + co + col0) = out;
+        *reinterpret_cast<bvec*>(Cbase + co + col0) = out;
       }
     }
   }
@@ -802,6 +824,7 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.chunk = p.tm_per * p.tn_per;
   }
   p.colsum_rows = p.tiles_m * WMW;
+  if (p.batches > 0) p.chunk = st::ceil_div(p.batches, 8) * p.tiles_m * p.tiles_n;
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
             FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
@@ -817,7 +840,7 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
 int run_nn(NNParams& p, int epi, hipStream_t s) {
   const int force = st::tuning(st::TUNE_GEMM_TILE);   // perf experiments (st_set_tuning)
   if (p.Np % 128 == 0) {
-    long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128);
+    long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128) * std::max(1, p.batches);
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
@@ -835,6 +858,36 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
   }
   return st::check_launch("gemm_nn");
 }
+
+}  // namespace
+
+// Plain batched C[b] = A[b] * B[b] (row-major fp32, no epilogue) on the convolution GEMM kernel: A [M][lda] with
+// K <= lda readable floats per row, B [K][N] with N a multiple of 128, C [M][ldc]; K a multiple of 32.
+int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc,
+                        long c_batch, int M, int K, int N, int batches, hipStream_t s) {
+  if (!(A && B && C && M > 0 && K > 0 && K % 32 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldc % 4 == 0)) {
+    st::set_error("gemm_nn_batched: bad shape M=%d K=%d N=%d", M, K, N);
+    return ST_EINVAL;
+  }
+  NNParams p{};
+  p.A = A;
+  p.amap.frames = M; p.amap.row_stride = (int)lda; p.amap.batch_stride = 0; p.amap.row0 = 0;
+  p.Bm = B;
+  p.Np = N;
+  p.C = C;
+  p.cmap.frames = M; p.cmap.row_stride = (int)ldc; p.cmap.batch_stride = 0; p.cmap.row0 = 0;
+  p.M = M;
+  p.Kvalid = K;
+  p.Kp = K;
+  p.n_store = N;
+  p.taps = 1;
+  p.cp = K;
+  p.batches = batches;
+  p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
+  return run_nn(p, 0, s);
+}
+
+namespace {
 
 bool tensor_ok(const st_tensor3* t) {
   return t && t->base && t->batch > 0 && t->frames > 0 && t->channels > 0 && t->halo >= 0 &&

@@ -39,7 +39,7 @@ def main():
     k, v = kv.split('=')
     set_tuning(k, int(v))
   layers = WL.w2l_layers(80)
-  eng = Wav2LetterEngine(layers, device='cuda:0')
+  eng = Wav2LetterEngine(layers, device='cuda:0', fft_conv=False)
   eng.set_weights(WL.xavier_params(layers, seed=42, dtype=np.float32))
   x, sl, labels = WL.make_batch([args.frames] * args.batch, 80, seed=0)
   eng.load_batch(x, sl)

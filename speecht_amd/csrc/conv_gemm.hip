@@ -826,8 +826,12 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.colsum_rows = p.tiles_m * WMW;
   if (p.batches > 0) p.chunk = st::ceil_div(p.batches, 8) * p.tiles_m * p.tiles_n;
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
-  st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
-            FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
+  if (p.batches > 0)
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
+              p.batches, p.M, p.Np, p.Kp);
+  else
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
+              FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
   if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
   if (p.splits > 1) {

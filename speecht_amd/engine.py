@@ -128,7 +128,7 @@ class _StagedHostBatch:
 class Wav2LetterEngine:
   """Owns weights/optimizer state and runs forward / loss / backward / update on one GPU."""
 
-  def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None, split_small_batches=True):
+  def __init__(self, layers, device='cuda:0', stream=None, conv_mode=None, split_small_batches=True, fft_conv=None):
     _lib.load()
     # With few output rows (single-utterance / live inference) the forward GEMMs split their reduction over
     # the otherwise idle CUs (3x lower latency for one 2 s utterance).  The summation order then depends on the
@@ -141,6 +141,10 @@ class Wav2LetterEngine:
     # logits / CTC / Adam (csrc/conv_bf16.hip, NP = 1).
     self.conv_mode = conv_mode or os.environ.get('ST_CONV_MODE', 'fp32')
     assert self.conv_mode in ('fp32', 'bf16x6', 'bf16'), self.conv_mode
+    # fp32 mode: long, wide filters (the 32-tap 250 -> 2000 layer) run in the frequency domain (csrc/conv_fft.hip:
+    # ~10x fewer multiplications, same fp32 arithmetic class; results differ from the W-tap kernels by rounding,
+    # ~1e-6 of the tensor scale).  fft_conv=False / ST_FFT_CONV=0 keeps the W-tap kernels everywhere.
+    self.fft_conv = (os.environ.get('ST_FFT_CONV', '1') != '0') if fft_conv is None else bool(fft_conv)
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -174,6 +178,9 @@ class Wav2LetterEngine:
     self.ctc_ws = None
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
+    self._gfwd_fresh = False
+    self._gbwd_fresh = False
+    self.fft = {}
 
   # ---- plumbing --------------------------------------------------------------------------
   @property
@@ -216,9 +223,7 @@ class Wav2LetterEngine:
   def set_weights(self, params):
     """params: list of (filters [W,Cin,Cout], bias [Cout]) numpy arrays."""
     self._pack(self.params, params)
-    self._packed_t_fresh = False
-    self._wplanes_fresh = False
-    self._wtplanes_fresh = False
+    self.mark_weights_changed()
 
   def set_adam_state(self, m, v, step):
     """Adam moments in the reference's layout (lists like ``set_weights``) and the number of updates applied."""
@@ -234,6 +239,8 @@ class Wav2LetterEngine:
     self._packed_t_fresh = False
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
+    self._gfwd_fresh = False
+    self._gbwd_fresh = False
 
   def _unpack(self, flat):
     out = []
@@ -311,7 +318,54 @@ class Wav2LetterEngine:
       self._alloc_planes()
     if self.conv_mode == 'bf16':
       self._alloc_bf16()
+    self._alloc_fft(batch)
     self._shape = (batch, frames)
+
+  # ---- frequency-domain layers (csrc/conv_fft.hip) ---------------------------------------------------
+  def _use_fft(self, i, batch, t_out):
+    l = self.layers[i]
+    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and 16 <= l.width <= 64 and
+            l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
+
+  def _alloc_fft(self, batch):
+    """Per frequency-domain layer: twiddles, the filter spectra in both operand layouts, the input spectra the
+    forward pass leaves for the filter gradient, and one scratch area.  The plan (DFT length, block count) depends
+    on (batch, frames), so the filter spectra are rebuilt after a shape change."""
+    lib = _lib.load()
+    self.fft = {}
+    for i, l in enumerate(self.layers):
+      t_in, t_out, pl, pr = self.geo[i]
+      if not self._use_fft(i, batch, t_out):
+        continue
+      n = ctypes.c_int()
+      call('st_conv1d_fft_plan', l.width, t_out, batch, ctypes.byref(n), None, None, None, None)
+      view = lambda name, numel: self._storage.view('fft%d_%s' % (i, name), numel)[0]
+      f = dict(n=n.value,
+               tw=view('tw', 2 * n.value),
+               gfwd=view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, t_out, batch, l.cin_pitch, l.cout_pitch, l.cin, l.cout, 0)),
+               gbwd=view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, t_out, batch, l.cin_pitch, l.cout_pitch, l.cin, l.cout, 1)),
+               sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
+               sft=view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
+               ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64))
+      call('st_conv1d_fft_twiddles_f32', l.width, t_out, batch, self._ptr(f['tw']), f['tw'].numel(), self.stream_ptr)
+      self.fft[i] = f
+    self._gfwd_fresh = False
+    self._gbwd_fresh = False
+
+  def _refresh_fft_filters(self, forward):
+    for i, f in self.fft.items():
+      l = self.layers[i]
+      call('st_conv1d_fft_filters_f32', self._ptr(self._slice(self.params, i)[0]), self._ptr(self.packed_t[i]), l.width,
+           self.geo[i][1], self.X[i].batch, l.cin, l.cout, l.cin_pitch, l.cout_pitch, self._ptr(f['tw']),
+           self._ptr(f['gfwd']) if forward else None, None if forward else self._ptr(f['gbwd']), self.stream_ptr)
+    if forward:
+      self._gfwd_fresh = True
+    else:
+      self._gbwd_fresh = True
+
+  def _refresh_gfwd(self):
+    if self.fft and self._shape is not None:
+      self._refresh_fft_filters(True)
 
   # ---- bf16 activations (config 4) ------------------------------------------------------------------
   def _alloc_bf16(self):
@@ -513,6 +567,14 @@ class Wav2LetterEngine:
         yp = self._ptr(self.Xp[i + 1]) if (i + 1 < len(self.layers) and self._x6_fwd(i + 1)) else None
         call('st_exp_conv1d_fwd_bf16x6', self.X[i].ref, self._ptr(self.Xp[i]), self._ptr(self.Wp[i]), self._ptr(pb),
              l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref, yp, s)
+      elif i in self.fft and self.fft_conv:
+        f = self.fft[i]
+        self._join_side_stream()                         # the filter spectra may still be on their way
+        if not self._gfwd_fresh:
+          self._refresh_fft_filters(True)
+        call('st_conv1d_nwc_fwd_fft_f32', self.X[i].ref, self._ptr(f['gfwd']), self._ptr(pb), l.width, self.geo[i][2],
+             int(l.relu), self.X[i + 1].ref, self._ptr(f['tw']), self._ptr(f['sf']), self._ptr(f['sft']), self._ptr(f['ws']),
+             f['ws'].numel() * 4, s)
       else:
         call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
@@ -530,6 +592,9 @@ class Wav2LetterEngine:
       self._refresh_bf16_filters(False)            # derived operands are rebuilt outside the graph
     if self.conv_mode == 'bf16x6' and not self._wplanes_fresh:
       self._refresh_wplanes()
+    self._join_side_stream()
+    if self.fft and self.fft_conv and not self._gfwd_fresh:
+      self._refresh_fft_filters(True)
     key = (self._shape, self._storage.generation)
     graph = self._graphs.get(key)
     if graph is None:
@@ -608,12 +673,18 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16':
       if not self._wtplanes_fresh and hasattr(self, 'WTb'):
         self._on_side_stream(lambda: self._refresh_bf16_filters(True))
-    elif not self._packed_t_fresh:
-      self._on_side_stream(self.refresh_packed_t)
+    elif not self._packed_t_fresh or (self.fft and not self._gbwd_fresh):
+      self._on_side_stream(self._refresh_backward_operands)
     call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
          self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
     call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
+
+  def _refresh_backward_operands(self):
+    if not self._packed_t_fresh:
+      self.refresh_packed_t()
+    if self.fft and self.fft_conv and not self._gbwd_fresh:
+      self._refresh_fft_filters(False)
 
   def refresh_packed_t(self):
     s = self.stream_ptr
@@ -650,6 +721,12 @@ class Wav2LetterEngine:
              l.width, l.cin_pitch, self.X[i].halo - self.geo[i][2], l.cout, self._ptr(gf), s)
         if need_bias:
           call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+      elif i in self.fft and self.fft_conv:
+        f = self.fft[i]
+        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sft']), l.width,
+             self._ptr(f['tw']), self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        if need_bias:
+          call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
@@ -684,9 +761,11 @@ class Wav2LetterEngine:
          self._ptr(self.stats), self._ptr(self.gate), self._ptr(self.norm_ws), self.norm_ws.numel() * 4,
          self.stream_ptr)
     self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
-    self._packed_t_fresh = False
-    self._wplanes_fresh = False
-    self._wtplanes_fresh = False
+    self.mark_weights_changed()
+    if self.fft:
+      # the forward filter spectra of the frequency-domain layers, on the side stream: they are first needed eight
+      # layers into the next forward pass
+      self._on_side_stream(self._refresh_gfwd)
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

@@ -51,9 +51,9 @@ def test_fullsize_batch_independence_bit_exact(full):
   from speecht_amd.engine import Wav2LetterEngine
   eng = full['eng']
   # the one-pass kernels for the full batch too (by default its 29-class output layer splits its reduction)
-  eng.split_small_batches = False
+  eng.split_small_batches, eng.fft_conv = False, False      # (the frequency-domain layer's block plan depends on the batch)
   eng.forward()
-  eng.split_small_batches = True
+  eng.split_small_batches, eng.fft_conv = True, True
   b = eng.X[-1].interior()[5].clone()
   for split in (False, True):
     solo = Wav2LetterEngine(full['layers'], device='cuda:0', split_small_batches=split)

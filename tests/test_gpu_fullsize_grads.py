@@ -37,10 +37,10 @@ def case():
   return dict(layers=layers, params=params, x=x32, seq=seq, labels=labels, ref=ref)
 
 
-def run_step(case, mode):
+def run_step(case, mode, fft_conv=False):
   from speecht_amd._lib import launch_trace
   from speecht_amd.engine import Wav2LetterEngine
-  eng = Wav2LetterEngine(case['layers'], device='cuda:0', conv_mode=mode)
+  eng = Wav2LetterEngine(case['layers'], device='cuda:0', conv_mode=mode, fft_conv=fft_conv)
   eng.set_weights(case['params'])
   eng.load_batch(case['x'], case['seq'])
   eng.set_labels(case['labels'])
@@ -116,6 +116,18 @@ def test_fullsize_fp32_gradients_match_float64_reference(case):
   compare(eng, case['ref'], case)
 
 
+def test_fullsize_fp32_frequency_domain_l8_gradients_match_float64_reference(case):
+  """The default fp32 step: the 32-tap 250 -> 2000 layer runs in the frequency domain (csrc/conv_fft.hip) -- block DFTs,
+  48 per-bin GEMMs per pass on the fp32 MFMA kernel (batched launches in the trace), fused inverse + epilogue.  Same
+  three comparisons and the same tolerances as the W-tap kernels."""
+  eng, trace = run_step(case, 'fp32', fft_conv=True)
+  text = '\n'.join(trace)
+  batched = [l for l in trace if ' batched bins=48 ' in l]
+  assert len(batched) == 3, text                                     # forward, back-prop to the input, filter gradient
+  assert not any('Kp=8192' in l or 'Kp=64512' in l for l in trace if l.startswith('gemm_nn<')), text   # no W-tap L8 launch
+  compare(eng, case['ref'], case)
+
+
 def test_fullsize_bf16x6_gradients_match_float64_reference(case):
   eng, trace = run_step(case, 'bf16x6')
   assert sum(1 for l in trace if l.startswith('gemm_nn_bf16<256,NP=3>')) >= 4, '\n'.join(trace)
@@ -126,7 +138,7 @@ def test_fullsize_update_matches_reference_adam(case):
   """clip_by_global_norm(5) + TF-Adam at full size: the global norm and the first update of every tensor against
   the oracle's optimizer (speech_model.py:77-82) fed the device's own gradients (whose parity is the tests above)."""
   from oracle import w2l_oracle as O
-  eng, _ = run_step(case, 'fp32')
+  eng, _ = run_step(case, 'fp32', fft_conv=True)
   flat = [g.astype(np.float64) for pair in eng.get_grads() for g in pair]
   clipped, gn = O.clip_by_global_norm(flat, 5.0)
   eng.apply_update(lr=1e-4)

@@ -741,6 +741,13 @@ class Wav2LetterEngine:
         dxp = self._ptr(self.dZp[i - 1]) if self._x6_bwd(i - 1) else None
         call('st_exp_conv1d_bwd_data_bf16x6', self.dZ[i].ref, self._ptr(self.dZp[i]), self._ptr(self.WTp[i]), l.width,
              self.geo[i][2], act, self.dZ[i - 1].ref, dxp, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+      elif i > 0 and i in self.fft and self.fft_conv:
+        f = self.fft[i]
+        if not self._gbwd_fresh:
+          self._refresh_fft_filters(False)
+        act = self.X[i].ref if self.layers[i - 1].relu else None
+        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['gbwd']), l.width, self.geo[i][2], act,
+             self.dZ[i - 1].ref, self._ptr(f['tw']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1

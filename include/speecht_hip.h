@@ -93,35 +93,38 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
                              size_t workspace_bytes, void* stream);
 
 /* ---- frequency-domain form of the same three operations for long, wide filters (csrc/conv_fft.hip) ----------
- * For the model's 32-tap 250 -> 2000 layer (speech_model.py:285; 66 % of the step's MACs) time is cut into blocks,
- * every block is taken to the frequency domain by a length-N DFT (N <= 128 chosen by st_conv1d_fft_plan), the W taps
- * become one complex channel-contraction per frequency bin -- run as real GEMMs on the exact-fp32 MFMA kernel --
- * and the result comes back by an inverse DFT fused with the bias / ReLU / mask epilogue: ~10x fewer
- * multiplications than the W-tap form, same fp32 arithmetic class (tests/test_gpu_fft_conv.py).  stride 1 only;
- * both channel counts must pack to multiples of 128.
- *   twiddles  2 * N floats, filled once per (width, frames, batch) by st_conv1d_fft_twiddles_f32
- *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats each), rebuilt by
+ * For the model's 32-tap 250 -> 2000 layer (speech_model.py:285; 66 % of the step's MACs) time is cut into blocks of
+ * 64 frames, every block is taken to the frequency domain by a length-(63 + W) DFT, the W taps become one complex
+ * channel-contraction per frequency bin -- run as real GEMMs on the exact-fp32 MFMA kernel -- and the result comes
+ * back by an inverse DFT fused with the bias / ReLU / mask epilogue: ~10x fewer multiplications than the W-tap
+ * form, same fp32 arithmetic class (tests/test_gpu_fft_conv.py).  stride 1, W <= 33; both channel counts must pack
+ * to multiples of 128.
+ *   tables    st_conv1d_fft_table_floats() floats, filled once per (width, pad_left) by st_conv1d_fft_tables_f32
+ *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats), rebuilt by
  *             st_conv1d_fft_filters_f32 whenever the weights change (gbwd from the flipped / transposed copy)
- *   sf/sft    spectra of the layer input, written by the forward call and read by the filter-gradient call
- *             (st_conv1d_fft_sf_floats floats each)
+ *   sf/sft    spectra of the layer input (st_conv1d_fft_sf_floats floats each), written by the forward call, sft
+ *             read by the filter-gradient call
+ *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
+ *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
  *   workspace st_conv1d_fft_ws bytes, scratch of one call */
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
-int st_conv1d_fft_twiddles_f32(int width, int frames, int batch, float* twiddles, size_t twiddle_floats, void* stream);
-size_t st_conv1d_fft_filter_floats(int width, int frames, int batch, int cin_pitch, int cout_pitch, int cin, int cout,
-                                   int backward);
-int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int frames, int batch, int cin,
-                              int cout, int cin_pitch, int cout_pitch, const float* twiddles, float* gfwd, float* gbwd,
-                              void* stream);
+size_t st_conv1d_fft_table_floats(void);
+int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
+size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward);
+int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int cin, int cout, int cin_pitch,
+                              int cout_pitch, const float* tables, float* gfwd, float* gbwd, void* stream);
 size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width);
+size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width);
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width);
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
-                              const st_tensor3* y, const float* twiddles, float* sf, float* sft, void* workspace,
+                              const st_tensor3* y, const float* tables, float* sf, float* sft, void* workspace,
                               size_t workspace_bytes, void* stream);
-int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* gbwd, int width, int pad_left, const st_tensor3* act,
-                                   const st_tensor3* dx, const float* twiddles, void* workspace, size_t workspace_bytes,
-                                   void* stream);
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, int width,
-                                     const float* twiddles, float* dpacked, void* workspace, size_t workspace_bytes,
+int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream);
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
+                                   const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, const float* zf, int width,
+                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
                                      void* stream);
 
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------

@@ -1,19 +1,21 @@
 // Frequency-domain convolution for long, wide filters (the model's L8: 32 taps, 250 -> 2000 channels, 66 % of the
 // MACs of the step; speech_model.py:285, tf.nn.conv1d 'SAME' + bias + relu and its gradients).
 //
-// Time is cut into blocks of V output frames; a block's receptive window has N = V + W - 1 frames.  With the
-// length-N DFT along time (real input: bins k = 0 .. N/2), per bin and per (row = utterance x block):
-//     forward    Y[k] = S[k] . conj(G[k])            S = DFT of x[jV - pad_left + n],  n < N   (overlap-save)
-//     to input   X[k] = D[k] . G[k]                  D = DFT of dz[jV + pad_left - (W-1) + n], outputs m >= W-1
-//     filters    Q[k] = sum_rows conj-pairing S[k]^T Z[k]   Z = DFT of dz[jV + t'], t' < V, zero padded; lags w < W
-// (G = DFT of the zero-padded filter) -- one complex [rows x Cin] x [Cin x Cout] product per bin instead of W taps
-// per frame: 8 bins-flops per 63 frames against 64 flops per frame, a 10x cut of the multiplications (N = 94).
-// The complex products run as REAL GEMMs on the exact-fp32 MFMA convolution kernel (gemm_nn_batched, one bin per
-// XCD at a time) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]]; the transforms are direct DFTs
-// (N <= 128: a few hundred multiply-adds per value, no butterflies, fp32 twiddles from a float64 table) in
-// thread-per-channel kernels whose twiddles come through the scalar cache.
-// Accuracy: every step is fp32 with exact products; the direct DFT sums N terms -- errors of 1e-6 of the tensor
-// scale, the same class as the fp32 accumulation of the direct kernel (tests/test_gpu_fft_conv.py).
+// Time is cut into blocks of V = 64 output frames; a block's receptive window has N = V + W - 1 frames (95 for 32
+// taps).  With the length-N DFT along time (real input: bins k = 0 .. N/2), per bin and per (row = utterance x block):
+//     forward    Y[k] = S[k] . conj(G[k])       S = DFT of x[jV - pad_left + n], n < N          (overlap-save)
+//     to input   X[k] = Z[k] . G[k]             Z = DFT of dz[jV + t'], t' < V, zero padded      (overlap-add: frame
+//                                               jV + t' sums block j at m = t' + pad_left and its two neighbours)
+//     filters    Q[k] = sum_rows S[k]^T conj(Z[k]),  lags w < W
+// (G = DFT of the zero-padded filter): one complex [rows x Cin] x [Cin x Cout] product per bin instead of W taps per
+// frame -- 48 bins x 8 flops per 64 frames against 64 flops per frame, a 10x cut of the multiplications.
+// The complex products run as REAL GEMMs on the exact-fp32 MFMA convolution kernel (st::gemm_nn_batched, one bin per
+// XCD at a time) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]].  The transforms are dense DFTs on the
+// same matrix instruction (v_mfma_f32_32x32x2_f32): a wavefront owns 32 channels of one row, keeps the 96 x 96
+// (forward) or 64 x 96 (inverse) DFT matrix in registers as MFMA A fragments, loads the frames straight from the
+// NWC tensor as B fragments (128-byte runs per frame) and writes 128-byte runs -- no LDS, no barriers; the inverse
+// carries the bias / ReLU / mask epilogue.  They are bound by the 200 MB of spectra they move, not by arithmetic.
+// Accuracy: fp32 throughout, exact products, N-term sums: ~1e-6 of the tensor scale (tests/test_gpu_fft_conv.py).
 #include <algorithm>
 
 #include "st_common.h"
@@ -21,165 +23,203 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NMAX = 128;
-constexpr int CH = 64;                       // channels per workgroup (one per lane), 4 waves share them
+constexpr int V = 64;                        // output frames per block
+constexpr int KP = 96;                       // padded DFT length (N = V + W - 1 <= 96) and padded 2 * bins
+constexpr int HB = KP / 2;                   // rows [0, HB) of a spectrum matrix are real parts, [HB, KP) imaginary
+// device tables (st_conv1d_fft_tables_f32), floats:
+constexpr int T_FS = 0;                      // forward DFT of N-frame segments          [KP][KP]
+constexpr int T_FZ = T_FS + KP * KP;         // forward DFT of V-frame, zero-padded ones [KP][KP]
+constexpr int T_IY = T_FZ + KP * KP;         // inverse at m = t'                        [V][KP]
+constexpr int T_IX = T_IY + V * KP;          // inverse at m = t' + pl, t' + V + pl, t' - V + pl   [3][V][KP]
+constexpr int T_TW = T_IX + 3 * V * KP;      // (cos, sin)(2 pi j / N), j < N            [128][2]
+constexpr int T_END = T_TW + 256;
 
 int npad_of(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)st::round_up(c, 128)); }
 
 struct Plan {
-  int n, v, blocks, bins, rows, rows_pad;
+  int n, blocks, bins, rows, rows_pad;
 };
-
-// N even in [2W, 128]: fewest GEMM tile-steps  ceil(bins / 8) * 8 * round_up(rows, 128)  (8 bins run side by side,
-// one per XCD; row tiles are 128 deep)
 Plan make_plan(int width, int frames, int batch) {
-  Plan best{};
-  long best_cost = -1;
-  for (int n = std::max(2 * width, 16); n <= NMAX; n += 2) {
-    Plan p;
-    p.n = n;
-    p.v = n - width + 1;
-    p.blocks = st::ceil_div(frames, p.v);
-    p.bins = n / 2 + 1;
-    p.rows = batch * p.blocks;
-    p.rows_pad = (int)st::round_up(p.rows, 128);
-    const long cost = (long)st::round_up(p.bins, 8) * p.rows_pad;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = p; }
-  }
-  return best;
+  Plan p;
+  p.n = V + width - 1;
+  p.blocks = st::ceil_div(frames, V);
+  p.bins = p.n / 2 + 1;
+  p.rows = batch * p.blocks;
+  p.rows_pad = (int)st::round_up(p.rows, 128);
+  return p;
 }
 
-// twiddle table tw[j] = (cos, sin)(2 pi j / n), j < n, in a caller-provided device buffer (st_conv1d_fft_twiddles_f32)
-__global__ void twiddle_kernel(int n, f32x2* __restrict__ tw) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) {
-    float sn, cs;
-    sincospif(2.0f * (float)j / (float)n, &sn, &cs);
-    tw[j] = f32x2{cs, sn};
+__global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
+  const int bins = n / 2 + 1;
+  const float inv_n = 1.f / (float)n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T_END; i += gridDim.x * blockDim.x) {
+    float val = 0.f;
+    if (i < T_IY) {                                        // forward matrices: row m = (re | im, bin), column = frame
+      const int z = i >= T_FZ, r = (i - (z ? T_FZ : T_FS)) / KP, col = (i - (z ? T_FZ : T_FS)) % KP;
+      const int k = r < HB ? r : r - HB;
+      if (k < bins && col < (z ? V : n)) {
+        float sn, cs;
+        sincospif(2.0f * (float)((k * col) % n) * inv_n, &sn, &cs);
+        val = r < HB ? cs : -sn;
+      }
+    } else if (i < T_TW) {                                 // inverse matrices: row t', column = (re | im, bin)
+      const int which = i < T_IX ? 0 : 1 + (i - T_IX) / (V * KP);
+      const int rem = i < T_IX ? i - T_IY : (i - T_IX) % (V * KP);
+      const int tp = rem / KP, col = rem % KP;
+      const int k = col < HB ? col : col - HB;
+      int m = tp;
+      if (which == 1) m = tp + pad_left;
+      if (which == 2) m = tp + V + pad_left;
+      if (which == 3) m = tp - V + pad_left;
+      if (k < bins && m >= 0 && m < n) {
+        const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;
+        float sn, cs;
+        sincospif(2.0f * (float)((k * m) % n) * inv_n, &sn, &cs);
+        val = col < HB ? wk * cs : -wk * sn;
+      }
+    } else {
+      const int j = (i - T_TW) / 2;
+      if (j < n) {
+        float sn, cs;
+        sincospif(2.0f * (float)j * inv_n, &sn, &cs);
+        val = (i - T_TW) % 2 ? sn : cs;
+      }
+    }
+    t[i] = val;
   }
 }
 
 struct RowsIn {                  // a padded NWC tensor, read frame-wise
-  const float* base;
+  const float* base;             // frame 0 of utterance 0
   long batch_stride;             // floats between utterances
   int c_pitch, channels_read;    // floats per frame; channels to transform (<= c_pitch)
   int t_lo, t_hi;                // readable frames [t_lo, t_hi) relative to frame 0 (halos included: they hold zeros)
 };
 
-// ---- forward DFT of time segments ---------------------------------------------------------------------------
-// row = b * blocks + j  ->  out[k][row][c] = sum_{n < seg_len} x[b][j * v + start + n][c] * e^{-2 pi i k n / N}
-// stored [bins][rows_pad][2 * half]: re at column c, im at column half + c; zero for rows >= rows and for the
-// columns in [channels_read, half).  outT (optional): the same values as [bins][2 * half][rows_pad].
-// One lane per channel; the four waves of a workgroup take bins g, g+4, ... four at a time per pass over the
-// segment (8 multiply-adds per LDS read), twiddles through the scalar cache (their index is wave-uniform).
-__global__ __launch_bounds__(256) void dft_rows_kernel(RowsIn x, int blocks, int rows, int rows_pad, int n, int v, int start,
-                                                       int seg_len, int bins, int half, const f32x2* __restrict__ tw,
-                                                       float* __restrict__ out, float* __restrict__ outT) {
-  __shared__ float seg[NMAX][CH];
-  const int row = blockIdx.x, c0 = blockIdx.y * CH;
-  const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = c0 + lane;
-  const bool live = row < rows && c < x.channels_read;
-  const int b = row / blocks, j = row - b * blocks;
-  const int t0 = j * v + start;
-  for (int nn = g; nn < n; nn += 4) {
-    const int t = t0 + nn;
-    float val = 0.f;
-    if (live && nn < seg_len && t >= x.t_lo && t < x.t_hi) val = x.base[(long)b * x.batch_stride + (long)t * x.c_pitch + c];
-    seg[nn][lane] = val;
-  }
+// ---- forward DFT of time segments on the matrix pipe ----------------------------------------------------------
+// row = b * blocks + j:  out[k][row][c] = sum_n Wm[(re | im, k)][n] * x[b][j * V + start + n][c], stored
+// [bins][rows_pad][2 * half] with re at column c and im at column half + c; rows >= rows and channels >=
+// channels_read give zeros.  outT (optional): the same values as [bins][2 * half][rows_pad].
+// A wavefront takes (row, 32 channels) items: 48 frame pairs as B fragments straight from the tensor, the DFT matrix
+// as A fragments from LDS (one 32-row tile at a time), 3 x 48 MFMAs.
+__global__ __launch_bounds__(256, 2) void dft_mfma_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
+                                                          int rows_pad, int start, int bins, int half, int nchunks,
+                                                          float* __restrict__ out, float* __restrict__ outT) {
+  __shared__ float wl[KP][KP + 1];                         // the DFT matrix, row pitch 97: fragment reads hit 32 banks
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
+  for (int i = threadIdx.x; i < KP * KP; i += 256) wl[i / KP][i % KP] = wm[i];
   __syncthreads();
-  if (c >= half) return;
   const long plane = (long)rows_pad * 2 * half;
-  for (int k0 = g; k0 < bins; k0 += 16) {
-    float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
-    int idx[4] = {0, 0, 0, 0};
-    for (int nn = 0; nn < n; ++nn) {
-      const float xv = seg[nn][lane];
+  for (int item = gw; item < rows_pad * nchunks; item += total) {
+    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
+    f32x16 acc[3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2 w = tw[__builtin_amdgcn_readfirstlane(idx[q])];
-        re[q] = fmaf(xv, w[0], re[q]);
-        im[q] = fmaf(-xv, w[1], im[q]);
-        idx[q] += k0 + 4 * q;                              // (k n) mod N, k = k0 + 4 q < N
-        if (idx[q] >= n) idx[q] -= n;
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if (row < rows) {
+      const int b = row / blocks, j = row - b * blocks;
+      const int t0 = j * V + start + h;
+      const bool cok = c < x.channels_read;
+      const float* src = x.base + (long)b * x.batch_stride + c;
+      float bf[KP / 2];
+#pragma unroll
+      for (int s = 0; s < KP / 2; ++s) {
+        const int t = t0 + 2 * s;
+        bf[s] = (cok && t >= x.t_lo && t < x.t_hi) ? src[(long)t * x.c_pitch] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float a[KP / 2];
+#pragma unroll
+        for (int s = 0; s < KP / 2; ++s) a[s] = wl[i * 32 + l31][2 * s + h];
+#pragma unroll
+        for (int s = 0; s < KP / 2; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc[i], 0, 0, 0);
       }
     }
+    if (c < half) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = k0 + 4 * q;
-      if (k < bins) {
-        float* o = out + (long)k * plane + (long)row * 2 * half;
-        o[c] = re[q];
-        o[half + c] = im[q];
-        if (outT) {
-          float* ot = outT + (long)k * plane;
-          ot[(long)c * rows_pad + row] = re[q];
-          ot[(long)(half + c) * rows_pad + row] = im[q];
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
+          if (bin < bins) {
+            out[(long)bin * plane + (long)row * 2 * half + col] = acc[i][r];
+            if (outT) outT[(long)bin * plane + (long)col * rows_pad + row] = acc[i][r];
+          }
         }
-      }
     }
   }
 }
 
-// ---- inverse DFT of spectra back to frames, with the layer epilogue -----------------------------------------
-// in [bins][rows_pad][2 * half] (re | im).  For row = (b, j) and output offsets m in [m0, m0 + v):
-//   val[m][c] = (1 / N) * sum_k w_k (re[k][c] cos(2 pi k m / N) - im[k][c] sin(2 pi k m / N)),  w_k = 1 for k = 0 and
-//   k = N / 2, else 2;   frame t = j * v + (m - m0) < frames gets  act(val + bias[c])  or  mask * val.
+// ---- inverse DFT of spectra back to frames, with the layer epilogue ---------------------------------------------
+// in [bins][rows_pad][2 * half_in] (re | im).  Frame t = j * V + t' of utterance b gets
+//   val[c] = sum over TERMS of  Winv[term][t'][(re | im, k)] * in[k][row + off(term)][...]     off = 0, -1, +1 (same b)
+// then  act(val + bias[c])  (forward)  or  mask * val  (back-prop); pad channels and nothing beyond y.frames.
 struct RowsOut {
   float* base;
   long batch_stride;
   int c_pitch, channels, frames;
 };
-__global__ __launch_bounds__(256) void idft_rows_kernel(const float* __restrict__ in, int blocks, int rows, int rows_pad, int n,
-                                                        int v, int m0, int bins, int half, const f32x2* __restrict__ tw,
-                                                        RowsOut y, const float* __restrict__ bias, int relu,
-                                                        const float* __restrict__ mask, long mask_batch_stride,
-                                                        int mask_c_pitch) {
-  __shared__ float sre[NMAX / 2 + 1][CH], sim[NMAX / 2 + 1][CH];
-  const int row = blockIdx.x, c0 = blockIdx.y * CH;
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = c0 + lane;
-  const long plane = (long)rows_pad * 2 * half;
-  const float inv_n = 1.f / (float)n;
-  for (int k = g; k < bins; k += 4) {
-    const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;
-    const float* src = in + (long)k * plane + (long)row * 2 * half;
-    sre[k][lane] = c < half ? src[c] * wk : 0.f;
-    sim[k][lane] = c < half ? src[half + c] * wk : 0.f;
-  }
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void idft_mfma_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
+                                                           int rows, int rows_pad, int bins, int half_in, int nchunks,
+                                                           RowsOut y, const float* __restrict__ bias, int relu,
+                                                           const float* __restrict__ mask, long mask_batch_stride,
+                                                           int mask_c_pitch) {
+  __shared__ float wl[TERMS][V][KP + 1];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
+  for (int i = threadIdx.x; i < TERMS * V * KP; i += 256) wl[i / (V * KP)][(i / KP) % V][i % KP] = winv[i];
   __syncthreads();
-  if (c >= y.c_pitch) return;
-  const int b = row / blocks, j = row - b * blocks;
-  const float bv = (bias && c < y.channels) ? bias[c] : 0.f;
-  for (int t0 = g; t0 < v; t0 += 16) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int idx[4] = {0, 0, 0, 0}, step[4];
+  const long plane = (long)rows_pad * 2 * half_in;
+  for (int item = gw; item < rows * nchunks; item += total) {
+    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
+    const int b = row / blocks, j = row - b * blocks;
+    f32x16 acc[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) step[q] = (m0 + t0 + 4 * q) % n;
-    for (int k = 0; k < bins; ++k) {
-      const float r = sre[k][lane], i = sim[k][lane];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2 w = tw[__builtin_amdgcn_readfirstlane(idx[q])];
-        acc[q] = fmaf(r, w[0], acc[q]);
-        acc[q] = fmaf(-i, w[1], acc[q]);
-        idx[q] += step[q];                                 // (k m) mod N
-        if (idx[q] >= n) idx[q] -= n;
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int term = 0; term < TERMS; ++term) {
+      const int off = term == 0 ? 0 : (term == 1 ? -1 : 1);
+      if (j + off < 0 || j + off >= blocks) continue;                 // wave-uniform
+      const float* src = in + (long)(row + off) * 2 * half_in + c;
+      float bf[KP / 2];
+#pragma unroll
+      for (int s = 0; s < KP / 2; ++s) {
+        const int kk = 2 * s + h;
+        const int bin = kk < HB ? kk : kk - HB;
+        bf[s] = (c < half_in && bin < bins) ? src[(long)bin * plane + (kk < HB ? 0 : half_in)] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float a[KP / 2];
+#pragma unroll
+        for (int s = 0; s < KP / 2; ++s) a[s] = wl[term][i * 32 + l31][2 * s + h];
+#pragma unroll
+        for (int s = 0; s < KP / 2; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc[i], 0, 0, 0);
       }
     }
+    if (c < y.c_pitch) {
+      const float bv = (bias && c < y.channels) ? bias[c] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int tl = t0 + 4 * q, t = j * v + tl;
-      if (tl < v && t < y.frames) {
-        float val = c < y.channels ? acc[q] + bv : 0.f;    // pad channels stay zero
-        if (relu) val = fmaxf(val, 0.f);
-        if (mask) val = mask[(long)b * mask_batch_stride + (long)t * mask_c_pitch + c] > 0.f ? val : 0.f;
-        y.base[(long)b * y.batch_stride + (long)t * y.c_pitch + c] = val;
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (t < y.frames) {
+            float val = c < y.channels ? acc[i][r] + bv : 0.f;       // pad channels stay zero
+            if (relu) val = fmaxf(val, 0.f);
+            if (mask) val = mask[(long)b * mask_batch_stride + (long)t * mask_c_pitch + c] > 0.f ? val : 0.f;
+            y.base[(long)b * y.batch_stride + (long)t * y.c_pitch + c] = val;
+          }
+        }
     }
   }
 }
@@ -220,11 +260,12 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
   }
 }
 
-//  back-prop operand  gbwd [bins][2 cpo][2 npi]:  rows (re o | im o), columns (re c | im c):  [[Gr^T, Gi^T], [-Gi^T, Gr^T]]
+//  back-prop operand  gbwd [bins][2 npo][2 npi]:  rows (re o | im o), columns (re c | im c):  [[Gr^T, Gi^T], [-Gi^T, Gr^T]]
+//  (X = Z G; the rows match the columns of the dz spectra, npo per half, zero for o >= cout)
 //  from the flipped / transposed copy packed_t [w' * cpo + o][npi] with w' = W - 1 - w (c fastest there).
 template <int WT>
 __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __restrict__ packed_t, int width_rt, int cin, int cout,
-                                                              int cpo, int npi, int n, int bins,
+                                                              int cpo, int npo, int npi, int n, int bins,
                                                               const f32x2* __restrict__ tw, float* __restrict__ gbwd) {
   const int width = WT ? WT : width_rt;
   const int c = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
@@ -233,7 +274,7 @@ __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __res
   const bool live = c < cin && o < cout;
 #pragma unroll
   for (int w = 0; w < width; ++w) f[w] = live ? packed_t[((long)(width - 1 - w) * cpo + o) * npi + c] : 0.f;
-  const long plane = (long)2 * cpo * 2 * npi;
+  const long plane = (long)2 * npo * 2 * npi;
   for (int k = 0; k < bins; ++k) {
     float gr = 0.f, gi = 0.f;
     int idx = 0;
@@ -248,8 +289,8 @@ __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __res
     float* g = gbwd + (long)k * plane;
     g[(long)o * 2 * npi + c] = gr;
     g[(long)o * 2 * npi + npi + c] = gi;
-    g[(long)(cpo + o) * 2 * npi + c] = -gi;
-    g[(long)(cpo + o) * 2 * npi + npi + c] = gr;
+    g[(long)(npo + o) * 2 * npi + c] = -gi;
+    g[(long)(npo + o) * 2 * npi + npi + c] = gr;
   }
 }
 
@@ -272,7 +313,7 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
   if (live) {
     for (int k = 0; k < bins; ++k) {
       const float* p = q + (long)k * plane;
-      const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;
+      const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;      // DC (and the Nyquist bin of an even N) count once
       const float re = (p[(long)c * 2 * npo + o] + p[(long)(cpi + c) * 2 * npo + npo + o]) * wk;
       const float im = (p[(long)(cpi + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
       int idx = 0;
@@ -295,162 +336,169 @@ bool tensor_ok(const st_tensor3* t) {
          t->c_pitch >= t->channels && t->t_pitch >= t->halo + t->frames;
 }
 
-RowsIn rows_in(const st_tensor3& t, int channels_read) {
+RowsIn rows_in(const st_tensor3& t) {
   RowsIn r;
   r.base = t.base + (long)t.halo * t.c_pitch;        // frame 0 of utterance 0
   r.batch_stride = (long)t.t_pitch * t.c_pitch;
   r.c_pitch = t.c_pitch;
-  r.channels_read = channels_read;
+  r.channels_read = t.c_pitch;
   r.t_lo = -t.halo;
   r.t_hi = t.t_pitch - t.halo;
   return r;
 }
 
-void launch_dft(const st_tensor3& t, const Plan& pl, int start, int seg_len, int half, const f32x2* tw, float* out, float* outT,
+constexpr int TRANSFORM_WGS = 512;               // persistent: two workgroups per CU, every wave walks its share of the items
+
+void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int half, float* out, float* outT,
                 hipStream_t s) {
-  hipLaunchKernelGGL(dft_rows_kernel, dim3(pl.rows_pad, st::ceil_div(half, CH)), dim3(256), 0, s, rows_in(t, t.c_pitch), pl.blocks,
-                     pl.rows, pl.rows_pad, pl.n, pl.v, start, seg_len, pl.bins, half, tw, out, outT);
+  const int nchunks = st::ceil_div(half, 32);
+  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks, 4));
+  hipLaunchKernelGGL(dft_mfma_kernel, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start,
+                     pl.bins, half, nchunks, out, outT);
 }
+
+bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
 
 }  // namespace
 
 extern "C" {
 
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad) {
-  ST_REQUIRE(width >= 2 && 2 * width <= NMAX && width <= 64 && frames > 0 && batch > 0, "fft plan: filter width must be in [2, 64]");
+  ST_REQUIRE(width_ok(width) && frames > 0 && batch > 0, "fft plan: filter width must be in [2, 33]");
   const Plan p = make_plan(width, frames, batch);
   if (n) *n = p.n;
-  if (valid) *valid = p.v;
+  if (valid) *valid = V;
   if (blocks) *blocks = p.blocks;
   if (bins) *bins = p.bins;
   if (rows_pad) *rows_pad = p.rows_pad;
   return ST_OK;
 }
 
-size_t st_conv1d_fft_filter_floats(int width, int frames, int batch, int cin_pitch, int cout_pitch, int cin, int cout,
-                                   int backward) {
-  const Plan p = make_plan(width, frames, batch);
-  return backward ? (size_t)p.bins * 2 * cout_pitch * 2 * npad_of(cin) : (size_t)p.bins * 2 * cin_pitch * 2 * npad_of(cout);
+size_t st_conv1d_fft_table_floats(void) { return T_END; }
+
+int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream) {
+  ST_REQUIRE(width_ok(width) && pad_left >= 0 && pad_left < width && tables && table_floats >= (size_t)T_END,
+             "fft tables: bad argument");
+  hipLaunchKernelGGL(tables_kernel, dim3(64), dim3(256), 0, st::as_stream(stream), V + width - 1, pad_left, tables);
+  return st::check_launch("fft tables");
 }
 
-int st_conv1d_fft_twiddles_f32(int width, int frames, int batch, float* tw, size_t tw_floats, void* stream) {
-  ST_REQUIRE(width >= 2 && 2 * width <= NMAX && tw, "fft twiddles: bad argument");
-  const Plan p = make_plan(width, frames, batch);
-  ST_REQUIRE(tw_floats >= 2 * (size_t)p.n, "fft twiddles: table needs 2 * n floats");
-  hipLaunchKernelGGL(twiddle_kernel, dim3(1), dim3(NMAX), 0, st::as_stream(stream), p.n, reinterpret_cast<f32x2*>(tw));
-  return st::check_launch("fft twiddles");
+size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward) {
+  if (!width_ok(width)) return 0;
+  const size_t bins = (V + width - 1) / 2 + 1;
+  return backward ? bins * 2 * npad_of(cout) * 2 * npad_of(cin) : bins * 2 * cin_pitch * 2 * npad_of(cout);
 }
 
-int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int frames, int batch, int cin,
-                              int cout, int cin_pitch, int cout_pitch, const float* twiddles, float* gfwd, float* gbwd,
-                              void* stream) {
-  ST_REQUIRE(width >= 2 && width <= 64 && 2 * width <= NMAX && cin_pitch % 16 == 0 && cout_pitch % 16 == 0,
-             "fft filters: bad shape");
+int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int cin, int cout, int cin_pitch,
+                              int cout_pitch, const float* tables, float* gfwd, float* gbwd, void* stream) {
+  ST_REQUIRE(width_ok(width) && cin_pitch % 16 == 0 && cout_pitch % 16 == 0 && tables, "fft filters: bad shape");
   ST_REQUIRE(npad_of(cout) % 128 == 0 && npad_of(cin) % 128 == 0, "fft filters: both channel counts must pack to multiples of 128");
   hipStream_t s = st::as_stream(stream);
-  const Plan p = make_plan(width, frames, batch);
-  ST_REQUIRE(twiddles, "fft filters: twiddle table missing");
-  const f32x2* tw = reinterpret_cast<const f32x2*>(twiddles);
+  const int n = V + width - 1, bins = n / 2 + 1;
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_TW);
   const int npo = npad_of(cout), npi = npad_of(cin);
   if (gfwd) {
     ST_REQUIRE(packed, "fft filters: packed filters missing");
     // rows of pad channels (c in [cin, cin_pitch)) are written as zeros by the kernel's `live` test
     const dim3 grid(st::ceil_div(npo, 256), cin_pitch);
-    if (width == 32) hipLaunchKernelGGL(filters_dft_fwd_kernel<32>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, p.n, p.bins, tw, gfwd);
-    else hipLaunchKernelGGL(filters_dft_fwd_kernel<0>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, p.n, p.bins, tw, gfwd);
+    if (width == 32) hipLaunchKernelGGL(filters_dft_fwd_kernel<32>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
+    else hipLaunchKernelGGL(filters_dft_fwd_kernel<0>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
   }
   if (gbwd) {
     ST_REQUIRE(packed_t, "fft filters: flipped / transposed filters missing");
-    const dim3 grid(st::ceil_div(npi, 256), cout_pitch);
-    if (width == 32) hipLaunchKernelGGL(filters_dft_bwd_kernel<32>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npi, p.n, p.bins, tw, gbwd);
-    else hipLaunchKernelGGL(filters_dft_bwd_kernel<0>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npi, p.n, p.bins, tw, gbwd);
+    const dim3 grid(st::ceil_div(npi, 256), npo);
+    if (width == 32) hipLaunchKernelGGL(filters_dft_bwd_kernel<32>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
+    else hipLaunchKernelGGL(filters_dft_bwd_kernel<0>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
   }
   return st::check_launch("fft filters");
 }
 
-// floats: sf, sft (each), and the scratch spectra the three passes need
+// floats of the input spectra sf / sft (each) and of the dz spectra zf
 size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width) {
-  if (!x || !y) return 0;
+  if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
   return (size_t)p.bins * p.rows_pad * 2 * x->c_pitch;
 }
 
+size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
+  if (!dz || !width_ok(width)) return 0;
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  return (size_t)p.bins * p.rows_pad * 2 * npad_of(dz->channels);
+}
+
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
-  if (!x || !y) return 0;
+  if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
-  const size_t nf = 2 * (size_t)npad_of(y->channels), kb = 2 * (size_t)y->c_pitch, ka = 2 * (size_t)x->c_pitch,
-               nb = 2 * (size_t)npad_of(x->channels);
-  const size_t fwd = (size_t)p.bins * p.rows_pad * nf;                             // Yf
-  const size_t bwd = (size_t)p.bins * p.rows_pad * (kb + nb);                      // Df + Xf
-  const size_t wgr = (size_t)p.bins * p.rows_pad * nf + (size_t)p.bins * ka * nf;  // Zf + Qf
-  return (std::max(fwd, std::max(bwd, wgr)) + 64) * sizeof(float);
+  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)x->c_pitch, nb = 2 * (size_t)npad_of(x->channels);
+  const size_t yf = (size_t)p.bins * p.rows_pad * nf, xf = (size_t)p.bins * p.rows_pad * nb, qf = (size_t)p.bins * ka * nf;
+  return (std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
 }
 
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
-                              const st_tensor3* y, const float* twiddles, float* sf, float* sft, void* workspace,
+                              const st_tensor3* y, const float* tables, float* sf, float* sft, void* workspace,
                               size_t workspace_bytes, void* stream) {
-  ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && gfwd && sf && workspace, "conv fft fwd: bad argument");
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && gfwd && sf && workspace && tables && width_ok(width), "conv fft fwd: bad argument");
   ST_REQUIRE(x->batch == y->batch && x->frames == y->frames && pad_left >= 0 && pad_left < width, "conv fft fwd: stride-1 SAME layers only");
   ST_REQUIRE(npad_of(y->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, y, width), "conv fft fwd: workspace / shape");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, y->frames, y->batch);
-  ST_REQUIRE(twiddles, "conv fft: twiddle table missing");
-  const f32x2* tw = reinterpret_cast<const f32x2*>(twiddles);
   const int ka = 2 * x->c_pitch, npo = npad_of(y->channels), nf = 2 * npo;
   float* yf = reinterpret_cast<float*>(workspace);
-  launch_dft(*x, p, -pad_left, p.n, x->c_pitch, tw, sf, sft, s);
+  launch_dft(*x, p, tables + T_FS, -pad_left, x->c_pitch, sf, sft, s);
   if (int e = st::gemm_nn_batched(sf, ka, (long)p.rows_pad * ka, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka,
                                   nf, p.bins, s))
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames};
-  hipLaunchKernelGGL(idft_rows_kernel, dim3(p.rows, st::ceil_div(y->c_pitch, CH)), dim3(256), 0, s, yf, p.blocks, p.rows,
-                     p.rows_pad, p.n, p.v, 0, p.bins, npo, tw, out, bias, relu, (const float*)nullptr, 0L, 0);
+  const int nchunks = st::ceil_div(y->c_pitch, 32);
+  hipLaunchKernelGGL(idft_mfma_kernel<1>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4))), dim3(256), 0, s, yf,
+                     tables + T_IY, p.blocks, p.rows, p.rows_pad, p.bins, npo, nchunks, out, bias, relu, (const float*)nullptr,
+                     0L, 0);
   return st::check_launch("conv fft fwd");
 }
 
-int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* gbwd, int width, int pad_left, const st_tensor3* act,
-                                   const st_tensor3* dx, const float* twiddles, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
-  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && gbwd && workspace, "conv fft bwd_data: bad argument");
+int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && tables && zf && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft dz spectra: bad argument");
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  launch_dft(*dz, p, tables + T_FZ, 0, npad_of(dz->channels), zf, nullptr, st::as_stream(stream));
+  return st::check_launch("conv fft dz spectra");
+}
+
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
+                                   const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && zf && gbwd && workspace && tables && width_ok(width), "conv fft bwd_data: bad argument");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames && pad_left >= 0 && pad_left < width, "conv fft bwd_data: stride-1 layers only");
-  ST_REQUIRE(npad_of(dx->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(dx, dz, width), "conv fft bwd_data: workspace / shape");
+  ST_REQUIRE(npad_of(dx->channels) % 128 == 0 && npad_of(dz->channels) % 128 == 0 &&
+                 workspace_bytes >= st_conv1d_fft_ws(dx, dz, width), "conv fft bwd_data: workspace / shape");
   if (act) ST_REQUIRE(tensor_ok(act) && act->batch == dx->batch && act->frames == dx->frames && act->c_pitch >= dx->c_pitch,
                       "conv fft bwd_data: mask tensor mismatch");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  ST_REQUIRE(twiddles, "conv fft: twiddle table missing");
-  const f32x2* tw = reinterpret_cast<const f32x2*>(twiddles);
-  const int kb = 2 * dz->c_pitch, npi = npad_of(dx->channels), nb = 2 * npi;
-  float* df = reinterpret_cast<float*>(workspace);
-  float* xf = df + (size_t)p.bins * p.rows_pad * kb;
-  // overlap-save on dz: segment of block j starts at frame j*V + pad_left - (W - 1); outputs m in [W-1, N)
-  launch_dft(*dz, p, pad_left - (width - 1), p.n, dz->c_pitch, tw, df, nullptr, s);
-  if (int e = st::gemm_nn_batched(df, kb, (long)p.rows_pad * kb, gbwd, (long)kb * nb, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kb,
+  const int kz = 2 * npad_of(dz->channels), npi = npad_of(dx->channels), nb = 2 * npi;
+  float* xf = reinterpret_cast<float*>(workspace);
+  if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gbwd, (long)kz * nb, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
                                   nb, p.bins, s))
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
-  hipLaunchKernelGGL(idft_rows_kernel, dim3(p.rows, st::ceil_div(dx->c_pitch, CH)), dim3(256), 0, s, xf, p.blocks, p.rows,
-                     p.rows_pad, p.n, p.v, width - 1, p.bins, npi, tw, out, (const float*)nullptr, 0,
+  const int nchunks = st::ceil_div(dx->c_pitch, 32);
+  hipLaunchKernelGGL(idft_mfma_kernel<3>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4))), dim3(256), 0, s, xf,
+                     tables + T_IX, p.blocks, p.rows, p.rows_pad, p.bins, npi, nchunks, out, (const float*)nullptr, 0,
                      act ? act->base + (long)act->halo * act->c_pitch : nullptr, act ? (long)act->t_pitch * act->c_pitch : 0L,
                      act ? act->c_pitch : 0);
   return st::check_launch("conv fft bwd_data");
 }
 
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, int width,
-                                     const float* twiddles, float* dpacked, void* workspace, size_t workspace_bytes,
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, const float* zf, int width,
+                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && sft && dpacked && workspace, "conv fft bwd_filter: bad argument");
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && sft && zf && dpacked && workspace && tables && width_ok(width), "conv fft bwd_filter: bad argument");
   ST_REQUIRE(x->batch == dz->batch && x->frames == dz->frames, "conv fft bwd_filter: stride-1 layers only");
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, dz, width), "conv fft bwd_filter: workspace / shape");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  ST_REQUIRE(twiddles, "conv fft: twiddle table missing");
-  const f32x2* tw = reinterpret_cast<const f32x2*>(twiddles);
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_TW);
   const int ka = 2 * x->c_pitch, npo = npad_of(dz->channels), nf = 2 * npo;
-  float* zf = reinterpret_cast<float*>(workspace);
-  float* qf = zf + (size_t)p.bins * p.rows_pad * nf;
-  // Z: the V frames of block j, zero padded to N
-  launch_dft(*dz, p, 0, p.v, npo, tw, zf, nullptr, s);
+  float* qf = reinterpret_cast<float*>(workspace);
   // Q[bin] = SfT[bin] (2 cpi x rows_pad) * Zf[bin] (rows_pad x 2 npo)
   if (int e = st::gemm_nn_batched(sft, p.rows_pad, (long)ka * p.rows_pad, zf, (long)p.rows_pad * nf, qf, nf, (long)ka * nf, ka,
                                   p.rows_pad, nf, p.bins, s))

@@ -324,7 +324,7 @@ class Wav2LetterEngine:
   # ---- frequency-domain layers (csrc/conv_fft.hip) ---------------------------------------------------
   def _use_fft(self, i, batch, t_out):
     l = self.layers[i]
-    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and 16 <= l.width <= 64 and
+    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and 16 <= l.width <= 33 and
             l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
 
   def _alloc_fft(self, batch):
@@ -337,17 +337,15 @@ class Wav2LetterEngine:
       t_in, t_out, pl, pr = self.geo[i]
       if not self._use_fft(i, batch, t_out):
         continue
-      n = ctypes.c_int()
-      call('st_conv1d_fft_plan', l.width, t_out, batch, ctypes.byref(n), None, None, None, None)
       view = lambda name, numel: self._storage.view('fft%d_%s' % (i, name), numel)[0]
-      f = dict(n=n.value,
-               tw=view('tw', 2 * n.value),
-               gfwd=view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, t_out, batch, l.cin_pitch, l.cout_pitch, l.cin, l.cout, 0)),
-               gbwd=view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, t_out, batch, l.cin_pitch, l.cout_pitch, l.cin, l.cout, 1)),
+      f = dict(tables=view('tables', lib.st_conv1d_fft_table_floats()),
+               gfwd=view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 0)),
+               gbwd=view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1)),
                sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
                sft=view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
+               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width)),
                ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64))
-      call('st_conv1d_fft_twiddles_f32', l.width, t_out, batch, self._ptr(f['tw']), f['tw'].numel(), self.stream_ptr)
+      call('st_conv1d_fft_tables_f32', l.width, pl, self._ptr(f['tables']), f['tables'].numel(), self.stream_ptr)
       self.fft[i] = f
     self._gfwd_fresh = False
     self._gbwd_fresh = False
@@ -356,7 +354,7 @@ class Wav2LetterEngine:
     for i, f in self.fft.items():
       l = self.layers[i]
       call('st_conv1d_fft_filters_f32', self._ptr(self._slice(self.params, i)[0]), self._ptr(self.packed_t[i]), l.width,
-           self.geo[i][1], self.X[i].batch, l.cin, l.cout, l.cin_pitch, l.cout_pitch, self._ptr(f['tw']),
+           l.cin, l.cout, l.cin_pitch, l.cout_pitch, self._ptr(f['tables']),
            self._ptr(f['gfwd']) if forward else None, None if forward else self._ptr(f['gbwd']), self.stream_ptr)
     if forward:
       self._gfwd_fresh = True
@@ -573,8 +571,8 @@ class Wav2LetterEngine:
         if not self._gfwd_fresh:
           self._refresh_fft_filters(True)
         call('st_conv1d_nwc_fwd_fft_f32', self.X[i].ref, self._ptr(f['gfwd']), self._ptr(pb), l.width, self.geo[i][2],
-             int(l.relu), self.X[i + 1].ref, self._ptr(f['tw']), self._ptr(f['sf']), self._ptr(f['sft']), self._ptr(f['ws']),
-             f['ws'].numel() * 4, s)
+             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), self._ptr(f['sft']),
+             self._ptr(f['ws']), f['ws'].numel() * 4, s)
       else:
         call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
@@ -723,8 +721,10 @@ class Wav2LetterEngine:
           call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i in self.fft and self.fft_conv:
         f = self.fft[i]
-        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sft']), l.width,
-             self._ptr(f['tw']), self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        # the spectra of dz serve the filter gradient here and back-prop to the input below
+        call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, l.width, self._ptr(f['tables']), self._ptr(f['zf']), s)
+        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sft']), self._ptr(f['zf']),
+             l.width, self._ptr(f['tables']), self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
         if need_bias:
           call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       else:
@@ -746,8 +746,8 @@ class Wav2LetterEngine:
         if not self._gbwd_fresh:
           self._refresh_fft_filters(False)
         act = self.X[i].ref if self.layers[i - 1].relu else None
-        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['gbwd']), l.width, self.geo[i][2], act,
-             self.dZ[i - 1].ref, self._ptr(f['tw']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gbwd']), l.width,
+             self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1

@@ -66,18 +66,17 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
   dzt = dev_tensor(dev, B, T, cout, W - 1 - pl, pl, dz)
   dxt = dev_tensor(dev, B, T, cin, 3, 3)
 
-  n = ctypes.c_int()
-  call('st_conv1d_fft_plan', W, T, B, ctypes.byref(n), None, None, None, None)
-  tw = torch.zeros(2 * n.value, device=dev)
-  call('st_conv1d_fft_twiddles_f32', W, T, B, P(tw), tw.numel(), None)
-  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, T, B, cpi, cpo, cin, cout, 0), device=dev)
-  gbwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, T, B, cpi, cpo, cin, cout, 1), device=dev)
-  call('st_conv1d_fft_filters_f32', P(packed), P(packed_t), W, T, B, cin, cout, cpi, cpo, P(tw), P(gfwd), P(gbwd), None)
+  tables = torch.zeros(lib.st_conv1d_fft_table_floats(), device=dev)
+  call('st_conv1d_fft_tables_f32', W, pl, P(tables), tables.numel(), None)
+  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cin, cout, 0), device=dev)
+  gbwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cin, cout, 1), device=dev)
+  call('st_conv1d_fft_filters_f32', P(packed), P(packed_t), W, cin, cout, cpi, cpo, P(tables), P(gfwd), P(gbwd), None)
   sf = torch.empty(lib.st_conv1d_fft_sf_floats(xt.ref, yt.ref, W), device=dev)
   sft = torch.empty_like(sf)
+  zf = torch.empty(lib.st_conv1d_fft_zf_floats(dzt.ref, W), device=dev)
   ws = torch.empty(lib.st_conv1d_fft_ws(xt.ref, yt.ref, W) // 4 + 64, device=dev)
 
-  call('st_conv1d_nwc_fwd_fft_f32', xt.ref, P(gfwd), P(bias_d), W, pl, int(relu), yt.ref, P(tw), P(sf), P(sft), P(ws),
+  call('st_conv1d_nwc_fwd_fft_f32', xt.ref, P(gfwd), P(bias_d), W, pl, int(relu), yt.ref, P(tables), P(sf), P(sft), P(ws),
        ws.numel() * 4, None)
   y = yt.interior().cpu().numpy()
   assert np.max(np.abs(y - y_ref)) < 2e-5 * np.max(np.abs(y_ref))
@@ -85,13 +84,14 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
   whole = yt.buf.view(B, yt.t_pitch, yt.c_pitch)
   assert float(whole[:, :, cout:].abs().max()) == 0.0 and float(whole[:, :yt.halo].abs().max()) == 0.0
 
-  call('st_conv1d_nwc_bwd_data_fft_f32', dzt.ref, P(gbwd), W, pl, act.ref, dxt.ref, P(tw), P(ws), ws.numel() * 4, None)
+  call('st_conv1d_fft_dz_spectra_f32', dzt.ref, W, P(tables), P(zf), None)
+  call('st_conv1d_nwc_bwd_data_fft_f32', dzt.ref, P(zf), P(gbwd), W, pl, act.ref, dxt.ref, P(tables), P(ws), ws.numel() * 4, None)
   dx = dxt.interior().cpu().numpy()
   assert np.max(np.abs(dx - dx_ref)) < 2e-5 * np.max(np.abs(dx_ref))
 
   call('st_packed_dims', W, cpi, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
   dpacked = torch.full((kp.value * npad.value,), 7.0, device=dev)
-  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sft), W, P(tw), P(dpacked), P(ws), ws.numel() * 4, None)
+  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sft), P(zf), W, P(tables), P(dpacked), P(ws), ws.numel() * 4, None)
   dFd = torch.empty(W * cin * cout, device=dev)
   call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cpi, P(dFd), None)
   dF = dFd.view(W, cin, cout).cpu().numpy()

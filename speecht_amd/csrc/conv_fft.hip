@@ -34,7 +34,8 @@ constexpr int T_FZ = T_FS + KP * KP;         // forward DFT of V-frame, zero-pad
 constexpr int T_IY = T_FZ + KP * KP;         // inverse at m = t'                        [V][KP]
 constexpr int T_IX = T_IY + V * KP;          // inverse at m = t' + pl, t' + V + pl, t' - V + pl   [3][V][KP]
 constexpr int T_TW = T_IX + 3 * V * KP;      // (cos, sin)(2 pi j / N), j < N            [128][2]
-constexpr int T_END = T_TW + 256;
+constexpr int T_FW = T_TW + 256;             // (cos, sin)(2 pi k w / N), k < bins, w < W: [HB][W][2] (filter kernels: one
+constexpr int T_END = T_FW + HB * 34 * 2;    // contiguous row per bin, read with wide scalar loads)
 
 int npad_of(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)st::round_up(c, 128)); }
 
@@ -52,7 +53,7 @@ Plan make_plan(int width, int frames, int batch) {
 }
 
 __global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
-  const int bins = n / 2 + 1;
+  const int bins = n / 2 + 1, width = n - V + 1;
   const float inv_n = 1.f / (float)n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T_END; i += gridDim.x * blockDim.x) {
     float val = 0.f;
@@ -79,12 +80,19 @@ __global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
         sincospif(2.0f * (float)((k * m) % n) * inv_n, &sn, &cs);
         val = col < HB ? wk * cs : -wk * sn;
       }
-    } else {
+    } else if (i < T_FW) {
       const int j = (i - T_TW) / 2;
       if (j < n) {
         float sn, cs;
         sincospif(2.0f * (float)j * inv_n, &sn, &cs);
         val = (i - T_TW) % 2 ? sn : cs;
+      }
+    } else {
+      const int e = (i - T_FW) / 2, k = e / width, w = e % width;
+      if (k < bins) {
+        float sn, cs;
+        sincospif(2.0f * (float)((k * w) % n) * inv_n, &sn, &cs);
+        val = (i - T_FW) % 2 ? sn : cs;
       }
     }
     t[i] = val;
@@ -243,14 +251,12 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
   const long plane = (long)2 * cpi * 2 * npo;
   for (int k = 0; k < bins; ++k) {
     float gr = 0.f, gi = 0.f;
-    int idx = 0;
+    const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
 #pragma unroll
     for (int w = 0; w < width; ++w) {
-      const f32x2 t = tw[idx];
+      const f32x2 t = row[w];
       gr = fmaf(f[w], t[0], gr);
       gi = fmaf(-f[w], t[1], gi);
-      idx += k;
-      if (idx >= n) idx -= n;
     }
     float* g = gfwd + (long)k * plane;
     g[(long)c * 2 * npo + o] = gr;
@@ -277,14 +283,12 @@ __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __res
   const long plane = (long)2 * npo * 2 * npi;
   for (int k = 0; k < bins; ++k) {
     float gr = 0.f, gi = 0.f;
-    int idx = 0;
+    const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
 #pragma unroll
     for (int w = 0; w < width; ++w) {
-      const f32x2 t = tw[idx];
+      const f32x2 t = row[w];
       gr = fmaf(f[w], t[0], gr);
       gi = fmaf(-f[w], t[1], gi);
-      idx += k;
-      if (idx >= n) idx -= n;
     }
     float* g = gbwd + (long)k * plane;
     g[(long)o * 2 * npi + c] = gr;
@@ -316,14 +320,12 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
       const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;      // DC (and the Nyquist bin of an even N) count once
       const float re = (p[(long)c * 2 * npo + o] + p[(long)(cpi + c) * 2 * npo + npo + o]) * wk;
       const float im = (p[(long)(cpi + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
-      int idx = 0;
+      const f32x2* row = tw + k * width;                   // uniform: wide scalar loads
 #pragma unroll
       for (int w = 0; w < width; ++w) {
-        const f32x2 t = tw[idx];
+        const f32x2 t = row[w];
         acc[w] = fmaf(re, t[0], acc[w]);
         acc[w] = fmaf(-im, t[1], acc[w]);
-        idx += k;
-        if (idx >= n) idx -= n;
       }
     }
   }
@@ -395,7 +397,7 @@ int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int wi
   ST_REQUIRE(npad_of(cout) % 128 == 0 && npad_of(cin) % 128 == 0, "fft filters: both channel counts must pack to multiples of 128");
   hipStream_t s = st::as_stream(stream);
   const int n = V + width - 1, bins = n / 2 + 1;
-  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_TW);
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int npo = npad_of(cout), npi = npad_of(cin);
   if (gfwd) {
     ST_REQUIRE(packed, "fft filters: packed filters missing");
@@ -496,7 +498,7 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, dz, width), "conv fft bwd_filter: workspace / shape");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_TW);
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int ka = 2 * x->c_pitch, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace);
   // Q[bin] = SfT[bin] (2 cpi x rows_pad) * Zf[bin] (rows_pad x 2 npo)

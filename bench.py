@@ -77,46 +77,74 @@ DOMINANT = 'gemm_nn_kernel<128,128,2,2,0,true>'
 
 
 def measure_dominant_kernel(eng, batch, reps=10):
-  """HIP-event timing of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0,true>: the forward
-  convolution of every layer whose packed width is a multiple of 128 and whose k-tiles are all whole
-  (L1..L9 = 95.8 % of the forward MACs; 9 launches per step, the same launches rocprofv3 --stats averages;
-  L0's 80-channel input takes the clamped-address variant of the same kernel).  Events are recorded on
-  the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
+  """HIP-event timing of every launch of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0,true> that one
+  training step makes (the same launches rocprofv3 --stats averages under that name):
+    * the forward convolution of the layers whose k-tiles are all whole and whose packed width is a multiple of 128
+      and that run as W-tap implicit GEMMs (L1..L7, L9; L8 too when the frequency-domain path is off);
+    * the three batched per-bin GEMMs of a frequency-domain layer (forward, back-prop to the input, filter gradient
+      of L8: 48 bins each), timed on the engine's own spectra buffers.
+  FLOPs are the algorithmic ones of each launch: 2*B*T'*W*Cin*Cout for a W-tap launch, 2 * rows * 2Cin * 2Cout * bins
+  for a per-bin product (complex as 4 real multiplies; unpadded channel counts, real row count).  Events are recorded
+  on the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
   from speecht_amd._lib import call
   flops = conv_flops(eng, batch)
-  wide = [i for i, l in enumerate(eng.layers) if l.n_pad % 128 == 0 and l.cin_pitch % 32 == 0]
-  if not wide:
-    return None
   s = eng.stream_ptr
+  launches = []                                  # (label, flops, bytes, fn)
 
-  def launch(i):
+  def conv_fwd(i):
     l = eng.layers[i]
     pf, pb = eng._slice(eng.params, i)
-    call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
-         eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
+    return lambda: call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
+                        eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
+  for i, l in enumerate(eng.layers):
+    if l.n_pad % 128 == 0 and l.cin_pitch % 32 == 0 and not (i in eng.fft and eng.fft_conv):
+      nbytes = 4.0 * (batch * eng.geo[i][0] * l.cin + l.width * l.cin * l.cout + batch * eng.geo[i][1] * l.cout)
+      launches.append(('L%d fwd' % i, flops[i], nbytes, conv_fwd(i)))
+  for i, f in (eng.fft.items() if eng.fft_conv else []):
+    l = eng.layers[i]
+    import ctypes
+    n, blocks, bins, rows_pad = (ctypes.c_int() for _ in range(4))
+    call('st_conv1d_fft_plan', l.width, eng.geo[i][1], batch, ctypes.byref(n), None, ctypes.byref(blocks), ctypes.byref(bins),
+         ctypes.byref(rows_pad))
+    rows, nb, rp = batch * blocks.value, bins.value, rows_pad.value
+    ka, nf, nbk = 2 * l.cin_pitch, 2 * l.n_pad, 2 * l.nt_pad
+    P = eng._ptr
+    shapes = [('fwd', f['sf'], ka, rp * ka, f['gfwd'], ka * nf, f['ws'], nf, rp * nf, rp, ka, nf, rows, 2 * l.cin, 2 * l.cout),
+              ('bwd', f['zf'], nf, rp * nf, f['gbwd'], nf * nbk, f['ws'], nbk, rp * nbk, rp, nf, nbk, rows, 2 * l.cout, 2 * l.cin),
+              ('wgrad', f['sft'], rp, ka * rp, f['zf'], rp * nf, f['ws'], nf, ka * nf, ka, rp, nf, 2 * l.cin, rows, 2 * l.cout)]
+    for name, A, lda, ab, B, bb, C, ldc, cb, M, K, N, m_real, k_real, n_real in shapes:
+      fl = 2.0 * m_real * k_real * n_real * nb
+      nbytes = 4.0 * nb * (m_real * k_real + k_real * n_real + m_real * n_real)
+      launches.append(('L%d %s x%d bins' % (i, name, nb), fl, nbytes,
+                       (lambda A=A, lda=lda, ab=ab, B=B, bb=bb, C=C, ldc=ldc, cb=cb, M=M, K=K, N=N, nb=nb:
+                        call('st_gemm_nn_batched_f32', P(A), lda, ab, P(B), bb, P(C), ldc, cb, M, K, N, nb, s))))
+  if not launches:
+    return None
   for _ in range(2):
-    for i in wide:
-      launch(i)
+    for _, _, _, fn in launches:
+      fn()
   evs = []
   for _ in range(reps):
-    for i in wide:
+    for k, (_, _, _, fn) in enumerate(launches):
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       e0.record()
-      launch(i)
+      fn()
       e1.record()
-      evs.append((i, e0, e1))
+      evs.append((k, e0, e1))
   torch.cuda.synchronize()
-  tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in evs) / reps
-  tot_flops = sum(flops[i] for i in wide)
-  tot_bytes = sum(4.0 * (batch * eng.geo[i][0] * eng.layers[i].cin + eng.layers[i].width * eng.layers[i].cin *
-                         eng.layers[i].cout + batch * eng.geo[i][1] * eng.layers[i].cout) for i in wide)
-  n = len(wide)
-  avg_ms = tot_ms / n
+  per = [0.0] * len(launches)
+  for k, e0, e1 in evs:
+    per[k] += e0.elapsed_time(e1) / reps
+  tot_ms = sum(per)
+  tot_flops = sum(l[1] for l in launches)
+  tot_bytes = sum(l[2] for l in launches)
+  n = len(launches)
   achieved = tot_flops / (tot_ms * 1e-3) / 1e12
-  return dict(bound='mfma', kernel=DOMINANT + ' (conv forward, layers %s)' % ','.join('L%d' % i for i in wide),
+  return dict(bound='mfma', kernel=DOMINANT + ' (%s)' % '; '.join(l[0] for l in launches),
               achieved=round(achieved, 2), peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
               frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, traffic_unit='bytes/launch (PMC, see profiles/)',
-              avg_launch_ms=round(avg_ms, 4), launches_per_step=n,
+              avg_launch_ms=round(tot_ms / n, 4), launches_per_step=n,
+              per_launch={l[0]: dict(ms=round(t, 4), tflops=round(l[1] / (t * 1e-3) / 1e12, 1)) for l, t in zip(launches, per)},
               algorithmic_gflop_per_launch=round(tot_flops / n / 1e9, 2),
               algorithmic_mb_per_launch=round(tot_bytes / n / 1e6, 2),
               hbm_frac_of_peak=round(tot_bytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
@@ -395,6 +423,10 @@ def main():
         'replicas_identical': replicas_identical,
         'per_rank_ms_per_step': [round(v, 3) for v in rank_ms], 'comm': comm,
         'step_tflops_algorithmic': round(step_gflop / ms, 2),
+        'step_tflops_note': ('W-tap FLOPs of the reference formulation (SURVEY 8(d): 71.4 GFLOP per utterance) / step time; '
+                             'the 32-tap layer runs in the frequency domain with ~10x fewer multiplications, so this is an '
+                             'equivalent rate, not a hardware rate (the hardware rate is roofline.achieved)')
+                            if (eng.fft and eng.fft_conv) else None,
     }
     out['roofline'] = measure_dominant_kernel(eng, args.batch)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')

@@ -108,6 +108,10 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
  *   workspace st_conv1d_fft_ws bytes, scratch of one call */
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
+/* the per-bin products themselves: `batches` independent row-major fp32 GEMMs C[i] = A[i] * B[i] (A [m][lda], B [k][n],
+ * C [m][ldc]; k a multiple of 32, n of 128; strides in floats) on the convolution MFMA kernel, bin i on XCD i % 8 */
+int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
+                           int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream);
 size_t st_conv1d_fft_table_floats(void);
 int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
 size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward);

@@ -37,6 +37,8 @@ _SIGNATURES = {
                                           c_void_p]),
     'st_conv1d_fft_plan': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                    POINTER(c_int)]),
+    'st_gemm_nn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                       c_int, c_int, c_void_p]),
     'st_conv1d_fft_table_floats': (c_size_t, []),
     'st_conv1d_fft_tables_f32': (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_fft_filter_floats': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

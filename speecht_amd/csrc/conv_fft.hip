@@ -365,6 +365,11 @@ bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
 
 extern "C" {
 
+int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
+                           int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream) {
+  return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream));
+}
+
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad) {
   ST_REQUIRE(width_ok(width) && frames > 0 && batch > 0, "fft plan: filter width must be in [2, 33]");
   const Plan p = make_plan(width, frames, batch);

@@ -145,6 +145,7 @@ class Wav2LetterEngine:
     # ~10x fewer multiplications, same fp32 arithmetic class; results differ from the W-tap kernels by rounding,
     # ~1e-6 of the tensor scale).  fft_conv=False / ST_FFT_CONV=0 keeps the W-tap kernels everywhere.
     self.fft_conv = (os.environ.get('ST_FFT_CONV', '1') != '0') if fft_conv is None else bool(fft_conv)
+    self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '16'))
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -324,7 +325,7 @@ class Wav2LetterEngine:
   # ---- frequency-domain layers (csrc/conv_fft.hip) ---------------------------------------------------
   def _use_fft(self, i, batch, t_out):
     l = self.layers[i]
-    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and 16 <= l.width <= 33 and
+    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and
             l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
 
   def _alloc_fft(self, batch):

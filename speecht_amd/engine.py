@@ -315,6 +315,8 @@ class Wav2LetterEngine:
     self.dec_ids = self._storage.view('dec_ids', batch * self.t_out, torch.int32)[0][:batch * self.t_out]
     self.dec_lens = self._storage.view('dec_lens', batch, torch.int32)[0][:batch]
     self.dec_score = self._storage.view('dec_score', batch)[0][:batch]
+    # which layers run in the frequency domain is decided first: they leave the bf16x6 plane plumbing alone
+    self._fft_layers = {i for i in range(len(self.layers)) if self._use_fft(i, batch, geo[i][1])}
     if self.conv_mode == 'bf16x6':
       self._alloc_planes()
     if self.conv_mode == 'bf16':
@@ -325,7 +327,7 @@ class Wav2LetterEngine:
   # ---- frequency-domain layers (csrc/conv_fft.hip) ---------------------------------------------------
   def _use_fft(self, i, batch, t_out):
     l = self.layers[i]
-    return (self.fft_conv and self.conv_mode == 'fp32' and i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and
+    return (self.fft_conv and self.conv_mode in ('fp32', 'bf16x6') and i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and
             l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
 
   def _alloc_fft(self, batch):
@@ -429,17 +431,22 @@ class Wav2LetterEngine:
              self.dZ[i - 1].ref, self._ptr(self.dZb[i - 1]), self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4, s)
 
   # ---- bf16x6 (experimental) ------------------------------------------------------------------
+  def _in_fft(self, i):
+    return self.fft_conv and i in getattr(self, '_fft_layers', ())
+
   def _x6_fwd(self, i):
-    return self.conv_mode == 'bf16x6' and self.layers[i].n_pad % 128 == 0
+    return self.conv_mode == 'bf16x6' and self.layers[i].n_pad % 128 == 0 and not self._in_fft(i)
 
   def _x6_bwd(self, i):
     l = self.layers[i]
-    return self.conv_mode == 'bf16x6' and i > 0 and l.nt_pad % 128 == 0 and l.width * l.cout_pitch >= 256
+    return (self.conv_mode == 'bf16x6' and i > 0 and l.nt_pad % 128 == 0 and l.width * l.cout_pitch >= 256 and
+            not self._in_fft(i))
 
   def _x6_wgrad(self, i):
     l = self.layers[i]
     tiles = -(-(l.width * l.cin_pitch) // 128) * (l.n_pad // 128)
-    return self.conv_mode == 'bf16x6' and i > 0 and l.stride == 1 and l.n_pad % 128 == 0 and tiles >= 192
+    return (self.conv_mode == 'bf16x6' and i > 0 and l.stride == 1 and l.n_pad % 128 == 0 and tiles >= 192 and
+            not self._in_fft(i))
 
   def _planes(self, name, numel, n=3):
     """n zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
@@ -461,11 +468,18 @@ class Wav2LetterEngine:
         self.tq[i] = tq
         self.XTp[i] = self._planes('XTp%d' % i, l.cin_pitch * red + 4096)
         self.dZTp[i] = self._planes('dZTp%d' % i, l.n_pad * red)
-    if not hasattr(self, 'Wp'):
-      self.Wp = {i: torch.zeros(3 * l.k_pad * l.n_pad, dtype=torch.bfloat16, device=self.device)
-                 for i, l in enumerate(self.layers) if self._x6_fwd(i)}
-      self.WTp = {i: torch.zeros(3 * l.kt_pad * l.nt_pad, dtype=torch.bfloat16, device=self.device)
-                  for i, l in enumerate(self.layers) if self._x6_bwd(i)}
+    # weight planes of exactly the layers that run on this path for the current shape (the frequency-domain set
+    # depends on the shape); buffers are kept across shapes
+    if not hasattr(self, '_wp_store'):
+      self._wp_store, self._wtp_store = {}, {}
+    def kept(store, i, numel):
+      if i not in store:
+        store[i] = torch.zeros(numel, dtype=torch.bfloat16, device=self.device)
+      return store[i]
+    self.Wp = {i: kept(self._wp_store, i, 3 * l.k_pad * l.n_pad) for i, l in enumerate(self.layers) if self._x6_fwd(i)}
+    self.WTp = {i: kept(self._wtp_store, i, 3 * l.kt_pad * l.nt_pad) for i, l in enumerate(self.layers) if self._x6_bwd(i)}
+    self._wplanes_fresh = False
+    self._wtplanes_fresh = False
 
   def _refresh_wplanes(self):
     for i, wp in self.Wp.items():

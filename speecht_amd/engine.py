@@ -331,27 +331,34 @@ class Wav2LetterEngine:
             l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
 
   def _alloc_fft(self, batch):
-    """Per frequency-domain layer: twiddles, the filter spectra in both operand layouts, the input spectra the
-    forward pass leaves for the filter gradient, and one scratch area.  The plan (DFT length, block count) depends
-    on (batch, frames), so the filter spectra are rebuilt after a shape change."""
+    """Per frequency-domain layer: the transform tables and the filter spectra in both operand layouts (functions of
+    the layer only: kept across shapes), the input / gradient spectra and one scratch area (sized by the shape)."""
     lib = _lib.load()
     self.fft = {}
     for i, l in enumerate(self.layers):
       t_in, t_out, pl, pr = self.geo[i]
-      if not self._use_fft(i, batch, t_out):
+      if i not in self._fft_layers:
         continue
-      view = lambda name, numel: self._storage.view('fft%d_%s' % (i, name), numel)[0]
-      f = dict(tables=view('tables', lib.st_conv1d_fft_table_floats()),
-               gfwd=view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 0)),
-               gbwd=view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1)),
-               sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
-               sft=view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width)),
-               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width)),
-               ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64))
-      call('st_conv1d_fft_tables_f32', l.width, pl, self._ptr(f['tables']), f['tables'].numel(), self.stream_ptr)
+      view = lambda name, numel: self._storage.view('fft%d_%s' % (i, name), numel)
+      tables, fresh_tables = view('tables', lib.st_conv1d_fft_table_floats())
+      gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 0))
+      gbwd, fresh_b = view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1))
+      f = dict(tables=tables, gfwd=gfwd, gbwd=gbwd,
+               sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0],
+               sft=view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0],
+               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width))[0],
+               ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64)[0])
+      if fresh_tables:
+        call('st_conv1d_fft_tables_f32', l.width, pl, self._ptr(tables), tables.numel(), self.stream_ptr)
+      if fresh_f:
+        self._gfwd_fresh = False
+      if fresh_b:
+        self._gbwd_fresh = False
       self.fft[i] = f
-    self._gfwd_fresh = False
-    self._gbwd_fresh = False
+    if set(self.fft) != getattr(self, '_fft_prev', None):     # a layer (re)joined the path: its spectra may be stale
+      self._gfwd_fresh = False
+      self._gbwd_fresh = False
+    self._fft_prev = set(self.fft)
 
   def _refresh_fft_filters(self, forward):
     for i, f in self.fft.items():

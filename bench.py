@@ -206,7 +206,7 @@ def cpu_baseline(n_mels, frames, utts=2, steps=2):
                      'BLAS threads = host cores)'.format(utts, steps))
 
 
-def cpu_baseline_torch(n_mels, frames, batch, budget_s=25.0):
+def cpu_baseline_torch(n_mels, frames, batch, budget_s=40.0):
   """The same training step with torch CPU ops (F.conv1d through oneDNN + native CTC + autograd, fp32), the fastest
   CPU formulation available here (TF1 cannot be installed): median of 3 steps after warm-up.  The intra-op thread count
   is probed (torch's default = physical cores, and half of it: on the 128-core hosts of the GPU boxes half was 1.6x

@@ -848,7 +848,10 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
-    else if (p.batches > 0 && tiles128 < 512) launch_nn<64, 128, 2, 2>(p, epi, s);      // per-bin products with few column tiles (back-prop: 8 per bin): twice the workgroups, +10 %
+    else if (p.batches > 0 && tiles128 < 512) {                                        // per-bin products with few column tiles
+      if (p.cp % 32 == 0 && p.Kvalid % 32 == 0) launch_nn<64, 128, 2, 2, true>(p, epi, s);    // (back-prop: 8 per bin): twice the
+      else launch_nn<64, 128, 2, 2>(p, epi, s);                                               // workgroups, +10 %
+    }
     else if ((tiles128 >= 192 || p.splits > 1) && p.cp % 32 == 0 && p.Kvalid % 32 == 0 && !st::tuning(st::TUNE_NO_FAST))
       launch_nn<128, 128, 2, 2, true>(p, epi, s);                                      // whole k-tiles only: unclamped DMA addresses
     else if (tiles128 >= 192 || p.splits > 1) launch_nn<128, 128, 2, 2>(p, epi, s);   // >= 3/4 of the CUs busy

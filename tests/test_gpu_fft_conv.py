@@ -102,3 +102,43 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
   V = G[:W * cpi].view(W, cpi, npad.value)
   if cpi > cin:
     assert float(V[:, cin:, :].abs().max()) == 0.0
+
+
+def test_frequency_domain_layer_survives_shape_switching_and_weight_updates(dev):
+  """Real training batches change (B, max_T) every step and Adam changes the weights every step: the engine keeps the
+  filter spectra across shapes (they depend on the layer only), rebuilds them on a side stream after every update and
+  re-describes the spectra buffers per shape.  After a walk through shapes and updates the engine must be
+  bit-identical to a fresh engine that is handed the same weights and runs the last step only."""
+  from speecht_amd.engine import Wav2LetterEngine
+  from tests import workloads as WL
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=42, dtype=np.float32)
+  shapes = [[601] * 8, [1001] * 4, [333] * 2, [601] * 8]            # the third is too small for the frequency path
+  eng = Wav2LetterEngine(layers, device=dev)
+  eng.set_weights(params)
+  batches = [WL.make_batch(f, 80, seed=20 + k) for k, f in enumerate(shapes)]
+  used = []
+  for k, (x, seq, labels) in enumerate(batches):
+    if k == len(batches) - 1:
+      before = eng.get_weights()
+    eng.load_batch(x.astype(np.float32), seq)
+    eng.set_labels(labels)
+    eng.forward()
+    used.append(bool(eng.fft))
+    eng.ctc_loss_grad(1.0 / len(labels))
+    eng.backward()
+    if k < len(batches) - 1:
+      eng.apply_update(1e-3)
+  torch.cuda.synchronize()
+  assert used == [True, True, False, True]
+  fresh = Wav2LetterEngine(layers, device=dev)
+  fresh.set_weights(before)
+  x, seq, labels = batches[-1]
+  fresh.load_batch(x.astype(np.float32), seq)
+  fresh.set_labels(labels)
+  fresh.forward()
+  fresh.ctc_loss_grad(1.0 / len(labels))
+  fresh.backward()
+  torch.cuda.synchronize()
+  assert torch.equal(eng.X[-1].buf, fresh.X[-1].buf)
+  assert torch.equal(eng.grads, fresh.grads)

@@ -134,6 +134,14 @@ def test_fullsize_bf16x6_gradients_match_float64_reference(case):
   compare(eng, case['ref'], case)
 
 
+def test_fullsize_bf16x6_with_frequency_domain_l8(case):
+  """bf16x6 mode as it runs by default: the frequency-domain (fp32) L8 between bf16x6 layers -- the planes of its
+  neighbours are split from its fp32 outputs."""
+  eng, trace = run_step(case, 'bf16x6', fft_conv=True)
+  assert sum(1 for l in trace if ' batched bins=48 ' in l) == 3 and any(l.startswith('gemm_nn_bf16<256,NP=3>') for l in trace)
+  compare(eng, case['ref'], case)
+
+
 def test_fullsize_update_matches_reference_adam(case):
   """clip_by_global_norm(5) + TF-Adam at full size: the global norm and the first update of every tensor against
   the oracle's optimizer (speech_model.py:77-82) fed the device's own gradients (whose parity is the tests above)."""

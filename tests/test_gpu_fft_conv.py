@@ -113,7 +113,7 @@ def test_frequency_domain_layer_survives_shape_switching_and_weight_updates(dev)
   from tests import workloads as WL
   layers = WL.w2l_layers(80)
   params = WL.xavier_params(layers, seed=42, dtype=np.float32)
-  shapes = [[601] * 8, [1001] * 4, [333] * 2, [601] * 8]            # the third is too small for the frequency path
+  shapes = [[601] * 8, [1001] * 5, [333] * 2, [601] * 8]            # the third is too small for the frequency path
   eng = Wav2LetterEngine(layers, device=dev)
   eng.set_weights(params)
   batches = [WL.make_batch(f, 80, seed=20 + k) for k, f in enumerate(shapes)]

@@ -90,6 +90,8 @@ def measure_dominant_kernel(eng, batch, reps=10):
   flops = conv_flops(eng, batch)
   s = eng.stream_ptr
   launches = []                                  # (label, flops, bytes, fn)
+  if eng.conv_mode == 'bf16':
+    return measure_dominant_kernel_bf16(eng, batch, flops, reps)
 
   def conv_fwd(i):
     l = eng.layers[i]
@@ -148,6 +150,42 @@ def measure_dominant_kernel(eng, batch, reps=10):
               algorithmic_gflop_per_launch=round(tot_flops / n / 1e9, 2),
               algorithmic_mb_per_launch=round(tot_bytes / n / 1e6, 2),
               hbm_frac_of_peak=round(tot_bytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+
+
+def measure_dominant_kernel_bf16(eng, batch, flops, reps):
+  """configs[3] arithmetic: the forward launches of gemm_nn_bf16_kernel<256,...> (L8, L9) against the dense bf16 MFMA
+  peak (2.5 PFLOP/s nominal; the board sustains ~1.8 on random operands and clocks down to ~2.0 GHz under this
+  kernel)."""
+  from speecht_amd._lib import call
+  s = eng.stream_ptr
+  L = len(eng.layers)
+  wide = [i for i, l in enumerate(eng.layers) if l.n_pad >= 256 and batch * eng.geo[i][1] >= 4096]
+  if not wide:
+    return None
+
+  def launch(i):
+    l = eng.layers[i]
+    last = i + 1 == L
+    call('st_conv1d_nwc_fwd_ws_bf16', eng.X[i].ref, eng._ptr(eng.Xb[i]), eng._ptr(eng.Wb[i]), eng._ptr(eng._slice(eng.params, i)[1]),
+         l.width, l.stride, eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, None if last else eng._ptr(eng.Xb[i + 1]),
+         eng._ptr(eng.X[i + 1].buf) if last else None, eng._ptr(eng.wgrad_ws_b), eng.wgrad_ws_b.numel() * 4, s)
+  for _ in range(2):
+    for i in wide:
+      launch(i)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    for i in wide:
+      launch(i)
+  e1.record()
+  e1.synchronize()
+  ms = e0.elapsed_time(e1) / reps
+  fl = sum(flops[i] for i in wide)
+  achieved = fl / (ms * 1e-3) / 1e12
+  return dict(bound='mfma', kernel='gemm_nn_bf16_kernel<256,2,4,32,1,4,true,true> (conv forward, layers %s)' % ','.join('L%d' % i for i in wide),
+              achieved=round(achieved, 1), peak=2500.0, unit='TFLOP/s', frac=round(achieved / 2500.0, 4), traffic=None,
+              avg_launch_ms=round(ms / len(wide), 4), launches_per_step=len(wide),
+              algorithmic_gflop_per_launch=round(fl / len(wide) / 1e9, 2))
 
 
 def measure_mel(dev, batch, seconds, n_mels, reps=5):
@@ -433,12 +471,12 @@ def main():
     }
     out['roofline'] = measure_dominant_kernel(eng, args.batch)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if out['roofline'] and os.path.exists(traffic_file):
+    if out['roofline'] and eng.conv_mode != 'bf16' and os.path.exists(traffic_file):
       out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
       out['roofline']['traffic_source'] = ('profiles/traffic.json: TCC_EA0_RDREQ/WRREQ PMC passes of rocprofv3 over this '
                                            'command (scripts/gpu_traffic.sh); counters cannot be read from inside the run')
     util_file = os.path.join(ROOT, 'profiles', 'mfma_util.json')
-    if out['roofline'] and os.path.exists(util_file):      # PMC pass (scripts/gpu_mfma_util.sh), padded work included
+    if out['roofline'] and eng.conv_mode != 'bf16' and os.path.exists(util_file):      # PMC pass (scripts/gpu_mfma_util.sh), padded work included
       out['roofline']['mfma_busy_pmc'] = json.load(open(util_file)).get('gemm_nn_kernel<128, 128, 2, 2, 0, true>', {}).get('mfma_busy_frac_at_2p4ghz')
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)

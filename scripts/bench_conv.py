@@ -57,8 +57,8 @@ def main():
     flops = 2.0 * args.batch * t_out * l.width * l.cin * l.cout
     pf, pb = eng._slice(eng.params, i)
     gf, gb = eng._slice(eng.grads, i)
-    f = 0.0 if args.only not in ('', 'fwd') else timeit(lambda: call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride, pl,
-                            int(l.relu), eng.X[i + 1].ref, s), args.reps)
+    f = 0.0 if args.only not in ('', 'fwd') else timeit(lambda: call('st_conv1d_nwc_fwd_ws_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride, pl,
+                            int(l.relu), eng.X[i + 1].ref, eng._ptr(eng.wgrad_ws), eng.wgrad_ws.numel() * 4, s), args.reps)
     w = 0.0 if args.only not in ('', 'filter') else timeit(lambda: call('st_conv1d_nwc_bwd_filter_f32', eng.X[i].ref, eng.dZ[i].ref, l.width, l.stride, pl,
                             eng._ptr(gf), eng._ptr(gb), eng._ptr(eng.wgrad_ws), eng.wgrad_ws.numel() * 4, s), args.reps)
     d = 0.0

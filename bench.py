@@ -113,7 +113,7 @@ def measure_dominant_kernel(eng, batch, reps=10):
     P = eng._ptr
     shapes = [('fwd', f['sf'], ka, rp * ka, f['gfwd'], ka * nf, f['ws'], nf, rp * nf, rp, ka, nf, rows, 2 * l.cin, 2 * l.cout),
               ('bwd', f['zf'], nf, rp * nf, f['gbwd'], nf * nbk, f['ws'], nbk, rp * nbk, rp, nf, nbk, rows, 2 * l.cout, 2 * l.cin),
-              ('wgrad', f['sft'], rp, ka * rp, f['zf'], rp * nf, f['ws'], nf, ka * nf, ka, rp, nf, 2 * l.cin, rows, 2 * l.cout)]
+              ]
     for name, A, lda, ab, B, bb, C, ldc, cb, M, K, N, m_real, k_real, n_real in shapes:
       fl = 2.0 * m_real * k_real * n_real * nb
       nbytes = 4.0 * nb * (m_real * k_real + k_real * n_real + m_real * n_real)

@@ -102,8 +102,9 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  *   tables    st_conv1d_fft_table_floats() floats, filled once per (width, pad_left) by st_conv1d_fft_tables_f32
  *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats), rebuilt by
  *             st_conv1d_fft_filters_f32 whenever the weights change (gbwd from the flipped / transposed copy)
- *   sf/sft    spectra of the layer input (st_conv1d_fft_sf_floats floats each), written by the forward call, sft
- *             read by the filter-gradient call
+ *   sf/sft    spectra of the layer input (st_conv1d_fft_sf_floats floats each), written by the forward call and read by
+ *             the filter-gradient call; the transposed copy sft is only needed (else NULL in both calls) when
+ *             2 * x->c_pitch is not a multiple of 128
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
  *   workspace st_conv1d_fft_ws bytes, scratch of one call */
@@ -112,6 +113,10 @@ int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int
  * C [m][ldc]; k a multiple of 32, n of 128; strides in floats) on the convolution MFMA kernel, bin i on XCD i % 8 */
 int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                            int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream);
+/* out[i] = A[i]^T * Z[i]: A [m][lda] (k columns), Z [m][ldz] (n columns), out [k][n]; the reduction runs over the m rows
+ * (m a multiple of 32, k and n of 128) -- the lag products of the filter gradient */
+int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
+                           float* out, int64_t out_batch, int m, int k, int n, int batches, void* stream);
 size_t st_conv1d_fft_table_floats(void);
 int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
 size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward);
@@ -127,9 +132,9 @@ int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* t
 int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
                                    const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
                                    size_t workspace_bytes, void* stream);
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, const float* zf, int width,
-                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
-                                     void* stream);
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* sft,
+                                     const float* zf, int width, const float* tables, float* dpacked, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),

@@ -25,3 +25,20 @@ for name, M, K, N in shapes:
   fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, args.bins, None)
   ms = timeit(fn, 20)
   print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s' % (name, M, K, N, args.bins, ms, 2.0 * M * K * N * args.bins / ms / 1e9))
+# the 7-tap 250 -> 250 layers: 36 bins
+for name, M, K, N in [('fwd7', args.rows, 512, 512), ('wgrad7', 512, args.rows, 512)]:
+  bins = 36
+  A = torch.randn(bins * M * K, device=dev); B = torch.randn(bins * K * N, device=dev); C = torch.empty(bins * M * N, device=dev)
+  fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, None)
+  ms = timeit(fn, 20)
+  print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s' % (name, M, K, N, bins, ms, 2.0 * M * K * N * bins / ms / 1e9))
+
+# filter-gradient lag products on the TN kernel (no transposed spectra needed): out = A^T Z
+import numpy as np
+for name, M, K, N, bins in [('tn8', args.rows, 512, 4096, 48), ('tn7', args.rows, 512, 512, 36)]:
+  A = torch.randn(bins * M * K, device=dev); Z = torch.randn(bins * M * N, device=dev); C = torch.empty(bins * K * N, device=dev)
+  fn = lambda: call('st_gemm_tn_batched_f32', P(A), K, M * K, P(Z), N, M * N, P(C), K * N, M, K, N, bins, None)
+  ms = timeit(fn, 20)
+  ref = A.view(bins, M, K)[1].double().T @ Z.view(bins, M, N)[1].double()
+  err = float((C.view(bins, K, N)[1].double() - ref).abs().max() / ref.abs().max())
+  print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s  (check %.1e)' % (name, M, K, N, bins, ms, 2.0 * M * K * N * bins / ms / 1e9, err))

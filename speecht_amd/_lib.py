@@ -39,6 +39,8 @@ _SIGNATURES = {
                                    POINTER(c_int)]),
     'st_gemm_nn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                        c_int, c_int, c_void_p]),
+    'st_gemm_tn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int,
+                                       c_int, c_int, c_void_p]),
     'st_conv1d_fft_table_floats': (c_size_t, []),
     'st_conv1d_fft_tables_f32': (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_fft_filter_floats': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -52,8 +54,8 @@ _SIGNATURES = {
     'st_conv1d_fft_dz_spectra_f32': (c_int, [_T3P, c_int, c_void_p, c_void_p, c_void_p]),
     'st_conv1d_nwc_bwd_data_fft_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p, c_size_t,
                                                c_void_p]),
-    'st_conv1d_nwc_bwd_filter_fft_f32': (c_int, [_T3P, _T3P, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                 c_void_p]),
+    'st_conv1d_nwc_bwd_filter_fft_f32': (c_int, [_T3P, _T3P, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                 c_size_t, c_void_p]),
     'st_conv1d_bwd_data_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_data_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_bwd_data_bias_ws': (c_size_t, [_T3P, _T3P, c_int]),

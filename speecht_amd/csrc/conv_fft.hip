@@ -121,45 +121,40 @@ __global__ __launch_bounds__(256, 2) void dft_mfma_kernel(RowsIn x, const float*
   for (int i = threadIdx.x; i < KP * KP; i += 256) wl[i / KP][i % KP] = wm[i];
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half;
-  for (int item = gw; item < rows_pad * nchunks; item += total) {
-    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
-    f32x16 acc[3];
+  // item = (row, 32 channels, one 32-row tile of the DFT matrix): three times the items of a (row, channels) split --
+  // narrow tensors (256 channels) still fill the chip and a wave's dependent chain is 48 loads + 48 MFMAs
+  for (int item = gw; item < rows_pad * nchunks * 3; item += total) {
+    const int i = item % 3, rc = item / 3;
+    const int row = rc / nchunks, c = (rc - row * nchunks) * 32 + l31;
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (row < rows) {
       const int b = row / blocks, j = row - b * blocks;
       const int t0 = j * V + start + h;
       const bool cok = c < x.channels_read;
       const float* src = x.base + (long)b * x.batch_stride + c;
-      float bf[KP / 2];
+      float bf[KP / 2], a[KP / 2];
 #pragma unroll
       for (int s = 0; s < KP / 2; ++s) {
         const int t = t0 + 2 * s;
         bf[s] = (cok && t >= x.t_lo && t < x.t_hi) ? src[(long)t * x.c_pitch] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float a[KP / 2];
+      for (int s = 0; s < KP / 2; ++s) a[s] = wl[i * 32 + l31][2 * s + h];
 #pragma unroll
-        for (int s = 0; s < KP / 2; ++s) a[s] = wl[i * 32 + l31][2 * s + h];
-#pragma unroll
-        for (int s = 0; s < KP / 2; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc[i], 0, 0, 0);
-      }
+      for (int s = 0; s < KP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
     }
     if (c < half) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
-          if (bin < bins) {
-            out[(long)bin * plane + (long)row * 2 * half + col] = acc[i][r];
-            if (outT) outT[(long)bin * plane + (long)col * rows_pad + row] = acc[i][r];
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
+        if (bin < bins) {
+          out[(long)bin * plane + (long)row * 2 * half + col] = acc[r];
+          if (outT) outT[(long)bin * plane + (long)col * rows_pad + row] = acc[r];
         }
+      }
     }
   }
 }
@@ -185,20 +180,22 @@ __global__ __launch_bounds__(256, 2) void idft_mfma_kernel(const float* __restri
   for (int i = threadIdx.x; i < TERMS * V * KP; i += 256) wl[i / (V * KP)][(i / KP) % V][i % KP] = winv[i];
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half_in;
-  for (int item = gw; item < rows * nchunks; item += total) {
-    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
+  // item = (row, 32 channels, frames [32 i, 32 i + 32) of the block)
+  for (int item = gw; item < rows * nchunks * 2; item += total) {
+    const int i = item & 1, rc = item >> 1;
+    const int row = rc / nchunks, c = (rc - row * nchunks) * 32 + l31;
     const int b = row / blocks, j = row - b * blocks;
-    f32x16 acc[2];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int term = 0; term < TERMS; ++term) {
       const int off = term == 0 ? 0 : (term == 1 ? -1 : 1);
       if (j + off < 0 || j + off >= blocks) continue;                 // wave-uniform
+      // the neighbours only reach W - 1 frames into this block: frames [0, 32) never see block j + 1, [32, 64) never j - 1
+      if (TERMS > 1 && ((term == 1 && i == 1) || (term == 2 && i == 0))) continue;
       const float* src = in + (long)(row + off) * 2 * half_in + c;
-      float bf[KP / 2];
+      float bf[KP / 2], a[KP / 2];
 #pragma unroll
       for (int s = 0; s < KP / 2; ++s) {
         const int kk = 2 * s + h;
@@ -206,28 +203,22 @@ __global__ __launch_bounds__(256, 2) void idft_mfma_kernel(const float* __restri
         bf[s] = (c < half_in && bin < bins) ? src[(long)bin * plane + (kk < HB ? 0 : half_in)] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float a[KP / 2];
+      for (int s = 0; s < KP / 2; ++s) a[s] = wl[term][i * 32 + l31][2 * s + h];
 #pragma unroll
-        for (int s = 0; s < KP / 2; ++s) a[s] = wl[term][i * 32 + l31][2 * s + h];
-#pragma unroll
-        for (int s = 0; s < KP / 2; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc[i], 0, 0, 0);
-      }
+      for (int s = 0; s < KP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
     }
     if (c < y.c_pitch) {
       const float bv = (bias && c < y.channels) ? bias[c] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (t < y.frames) {
-            float val = c < y.channels ? acc[i][r] + bv : 0.f;       // pad channels stay zero
-            if (relu) val = fmaxf(val, 0.f);
-            if (mask) val = mask[(long)b * mask_batch_stride + (long)t * mask_c_pitch + c] > 0.f ? val : 0.f;
-            y.base[(long)b * y.batch_stride + (long)t * y.c_pitch + c] = val;
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (t < y.frames) {
+          float val = c < y.channels ? acc[r] + bv : 0.f;         // pad channels stay zero
+          if (relu) val = fmaxf(val, 0.f);
+          if (mask) val = mask[(long)b * mask_batch_stride + (long)t * mask_c_pitch + c] > 0.f ? val : 0.f;
+          y.base[(long)b * y.batch_stride + (long)t * y.c_pitch + c] = val;
         }
+      }
     }
   }
 }
@@ -354,7 +345,7 @@ constexpr int TRANSFORM_WGS = 512;               // persistent: two workgroups p
 void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int half, float* out, float* outT,
                 hipStream_t s) {
   const int nchunks = st::ceil_div(half, 32);
-  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks, 4));
+  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks * 3, 4));
   hipLaunchKernelGGL(dft_mfma_kernel, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start,
                      pl.bins, half, nchunks, out, outT);
 }
@@ -368,6 +359,11 @@ extern "C" {
 int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                            int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream) {
   return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream));
+}
+
+int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch, float* out,
+                           int64_t out_batch, int m, int k, int n, int batches, void* stream) {
+  return st::gemm_tn_batched(a, lda, a_batch, z, ldz, z_batch, out, out_batch, m, k, n, batches, st::as_stream(stream));
 }
 
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad) {
@@ -409,12 +405,14 @@ int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int wi
     // rows of pad channels (c in [cin, cin_pitch)) are written as zeros by the kernel's `live` test
     const dim3 grid(st::ceil_div(npo, 256), cin_pitch);
     if (width == 32) hipLaunchKernelGGL(filters_dft_fwd_kernel<32>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
+    else if (width == 7) hipLaunchKernelGGL(filters_dft_fwd_kernel<7>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
     else hipLaunchKernelGGL(filters_dft_fwd_kernel<0>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
   }
   if (gbwd) {
     ST_REQUIRE(packed_t, "fft filters: flipped / transposed filters missing");
     const dim3 grid(st::ceil_div(npi, 256), npo);
     if (width == 32) hipLaunchKernelGGL(filters_dft_bwd_kernel<32>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
+    else if (width == 7) hipLaunchKernelGGL(filters_dft_bwd_kernel<7>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
     else hipLaunchKernelGGL(filters_dft_bwd_kernel<0>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
   }
   return st::check_launch("fft filters");
@@ -457,7 +455,7 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
-  hipLaunchKernelGGL(idft_mfma_kernel<1>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4))), dim3(256), 0, s, yf,
+  hipLaunchKernelGGL(idft_mfma_kernel<1>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks * 2, 4))), dim3(256), 0, s, yf,
                      tables + T_IY, p.blocks, p.rows, p.rows_pad, p.bins, npo, nchunks, out, bias, relu, (const float*)nullptr,
                      0L, 0);
   return st::check_launch("conv fft fwd");
@@ -488,17 +486,19 @@ int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const 
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
-  hipLaunchKernelGGL(idft_mfma_kernel<3>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4))), dim3(256), 0, s, xf,
+  hipLaunchKernelGGL(idft_mfma_kernel<3>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks * 2, 4))), dim3(256), 0, s, xf,
                      tables + T_IX, p.blocks, p.rows, p.rows_pad, p.bins, npi, nchunks, out, (const float*)nullptr, 0,
                      act ? act->base + (long)act->halo * act->c_pitch : nullptr, act ? (long)act->t_pitch * act->c_pitch : 0L,
                      act ? act->c_pitch : 0);
   return st::check_launch("conv fft bwd_data");
 }
 
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sft, const float* zf, int width,
-                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
-  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && sft && zf && dpacked && workspace && tables && width_ok(width), "conv fft bwd_filter: bad argument");
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* sft,
+                                     const float* zf, int width, const float* tables, float* dpacked, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && zf && dpacked && workspace && tables && width_ok(width), "conv fft bwd_filter: bad argument");
+  ST_REQUIRE(((2 * x->c_pitch) % 128 == 0) ? sf != nullptr : sft != nullptr,
+             "conv fft bwd_filter: needs sf (2 * c_pitch a multiple of 128) or the transposed spectra sft");
   ST_REQUIRE(x->batch == dz->batch && x->frames == dz->frames, "conv fft bwd_filter: stride-1 layers only");
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, dz, width), "conv fft bwd_filter: workspace / shape");
   hipStream_t s = st::as_stream(stream);
@@ -506,12 +506,19 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int ka = 2 * x->c_pitch, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace);
-  // Q[bin] = SfT[bin] (2 cpi x rows_pad) * Zf[bin] (rows_pad x 2 npo)
-  if (int e = st::gemm_nn_batched(sft, p.rows_pad, (long)ka * p.rows_pad, zf, (long)p.rows_pad * nf, qf, nf, (long)ka * nf, ka,
-                                  p.rows_pad, nf, p.bins, s))
+  // Q[bin] = Sf[bin]^T (2 cpi x rows_pad) * Zf[bin] (rows_pad x 2 npo): the reduction-major kernel of the W-tap filter
+  // gradient takes both spectra as they are; widths it cannot tile fall back to the transposed copy
+  if (ka % 128 == 0) {
+    if (int e = st::gemm_tn_batched(sf, ka, (long)p.rows_pad * ka, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf,
+                                    p.bins, s))
+      return e;
+  } else if (int e = st::gemm_nn_batched(sft, p.rows_pad, (long)ka * p.rows_pad, zf, (long)p.rows_pad * nf, qf, nf, (long)ka * nf,
+                                         ka, p.rows_pad, nf, p.bins, s)) {
     return e;
+  }
   const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
   if (width == 32) hipLaunchKernelGGL(filters_idft_kernel<32>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
+  else if (width == 7) hipLaunchKernelGGL(filters_idft_kernel<7>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
   else hipLaunchKernelGGL(filters_idft_kernel<0>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
   return st::check_launch("conv fft bwd_filter");
 }

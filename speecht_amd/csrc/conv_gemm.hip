@@ -424,6 +424,7 @@ struct TNParams {
   int tiles_k, tiles_n;
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
+  long a_batch, z_batch, o_batch;   // blockIdx.z: independent products of the same shape (csrc/conv_fft.hip), float strides
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
@@ -469,6 +470,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   }
   const int k0 = tile_k * BKO, n0 = tile_n * BN;
   const int split = blockIdx.y;
+  const float* __restrict__ Ab = p.A + (long)blockIdx.z * p.a_batch;
+  const float* __restrict__ Zb = p.Z + (long)blockIdx.z * p.z_batch;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
 
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   auto issue_slice = [&](int sl, int mb, int buf) {
     const bool plain = !tiny && stt + BMR <= p.amap.frames && mb + BMR <= m_end;
     if (plain) {
-      const char* sa = reinterpret_cast<const char*>(p.A + ((long)sb * p.amap.batch_stride + p.amap.row0 + (long)stt * p.amap.row_stride));
-      const char* sz = reinterpret_cast<const char*>(p.Z + ((long)sb * p.zmap.batch_stride + p.zmap.row0 + (long)stt * p.zmap.row_stride));
+      const char* sa = reinterpret_cast<const char*>(Ab + ((long)sb * p.amap.batch_stride + p.amap.row0 + (long)stt * p.amap.row_stride));
+      const char* sz = reinterpret_cast<const char*>(Zb + ((long)sb * p.zmap.batch_stride + p.zmap.row0 + (long)stt * p.zmap.row_stride));
 #pragma unroll
       for (int i = sl; i < A_PW; i += 4) {
         const int pc = wave * A_PW + i;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
         if (pc >= (isA ? A_PIECES : Z_PIECES)) continue;
         const int r = isA ? pc * (64 / A_LPR) + arow : pc * (64 / Z_LPR) + zrow;
         const int m = min(mb + r, p.M - 1);
-        const float* g = isA ? p.A + p.amap.off(m) + acol : p.Z + p.zmap.off(m) + zcol;
+        const float* g = isA ? Ab + p.amap.off(m) + acol : Zb + p.zmap.off(m) + zcol;
         if (mb + r >= m_end) g = g_zero_row;            // rows past the split end contribute zero
         float* dst = isA ? As + buf * A_SZ + pc * 256 : Zs + buf * Z_SZ + pc * 256;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
     __syncthreads();
   }
 
-  float* out = p.out + (long)split * p.Kp * p.Np;
+  float* out = p.out + (long)split * p.Kp * p.Np + (long)blockIdx.z * p.o_batch;
   const int col0 = n0 + wn * WTN + NT * l31;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -893,6 +896,37 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
   p.batches = batches;
   p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
   return run_nn(p, 0, s);
+}
+
+// Plain batched out[b] = A[b]^T * Z[b] on the filter-gradient kernel: A [M][lda] (K <= lda columns used), Z [M][ldz]
+// (N columns), out [K][N]; the reduction runs over the M rows.  K a multiple of 128, N of 128, M of 32.
+int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out,
+                        long o_batch, int M, int K, int N, int batches, hipStream_t s) {
+  if (!(A && Z && out && M > 0 && M % 32 == 0 && K % 128 == 0 && N % 128 == 0 && batches > 0)) {
+    st::set_error("gemm_tn_batched: bad shape M=%d K=%d N=%d", M, K, N);
+    return ST_EINVAL;
+  }
+  TNParams p{};
+  p.A = A;
+  p.amap.frames = M; p.amap.row_stride = (int)lda; p.amap.batch_stride = 0; p.amap.row0 = 0;
+  p.Z = Z;
+  p.zmap.frames = M; p.zmap.row_stride = (int)ldz; p.zmap.batch_stride = 0; p.zmap.row0 = 0;
+  p.M = M;
+  p.Kvalid = K;
+  p.Kp = K;
+  p.Np = N;
+  p.z_cols = N;
+  p.rows_per_split = M;
+  p.out = out;
+  p.tiles_k = K / 128;
+  p.tiles_n = N / 128;
+  p.amap_batches = 1;
+  p.adv_b = 32 / M;
+  p.adv_t = 32 % M;
+  p.a_batch = a_batch; p.z_batch = z_batch; p.o_batch = o_batch;
+  st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d", batches, M, K, N);
+  hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), 0, s, p);
+  return st::check_launch("gemm_tn_batched");
 }
 
 namespace {

@@ -20,6 +20,8 @@ int tuning(int key);
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,
                     int M, int K, int N, int batches, hipStream_t s);
+int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
+                    int M, int K, int N, int batches, hipStream_t s);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -345,7 +345,9 @@ class Wav2LetterEngine:
       gbwd, fresh_b = view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1))
       f = dict(tables=tables, gfwd=gfwd, gbwd=gbwd,
                sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0],
-               sft=view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0],
+               # the transposed copy only where the filter-gradient kernel cannot tile the spectra as they are
+               sft=(view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0]
+                    if (2 * l.cin_pitch) % 128 else None),
                zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width))[0],
                ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64)[0])
       if fresh_tables:
@@ -593,8 +595,8 @@ class Wav2LetterEngine:
         if not self._gfwd_fresh:
           self._refresh_fft_filters(True)
         call('st_conv1d_nwc_fwd_fft_f32', self.X[i].ref, self._ptr(f['gfwd']), self._ptr(pb), l.width, self.geo[i][2],
-             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), self._ptr(f['sft']),
-             self._ptr(f['ws']), f['ws'].numel() * 4, s)
+             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']),
+             self._ptr(f['sft']) if f['sft'] is not None else None, self._ptr(f['ws']), f['ws'].numel() * 4, s)
       else:
         call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
@@ -745,8 +747,9 @@ class Wav2LetterEngine:
         f = self.fft[i]
         # the spectra of dz serve the filter gradient here and back-prop to the input below
         call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, l.width, self._ptr(f['tables']), self._ptr(f['zf']), s)
-        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sft']), self._ptr(f['zf']),
-             l.width, self._ptr(f['tables']), self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sf']),
+             self._ptr(f['sft']) if f['sft'] is not None else None, self._ptr(f['zf']), l.width, self._ptr(f['tables']),
+             self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
         if need_bias:
           call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       else:

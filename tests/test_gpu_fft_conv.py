@@ -91,7 +91,7 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
 
   call('st_packed_dims', W, cpi, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
   dpacked = torch.full((kp.value * npad.value,), 7.0, device=dev)
-  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sft), P(zf), W, P(tables), P(dpacked), P(ws), ws.numel() * 4, None)
+  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sf), P(sft), P(zf), W, P(tables), P(dpacked), P(ws), ws.numel() * 4, None)
   dFd = torch.empty(W * cin * cout, device=dev)
   call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cpi, P(dFd), None)
   dF = dFd.view(W, cin, cout).cpu().numpy()

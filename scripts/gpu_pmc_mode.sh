@@ -25,8 +25,10 @@ for tag in ('a', 'b'):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(cc[0])):
         name = r['Kernel_Name']
-        if 'gemm_' not in name: continue
-        key = name[name.index('gemm_'):name.index('>') + 1]
+        import re as _re
+        m = _re.search(os.environ.get('KERNEL_FILTER', r'gemm_\w+<[^>]*>'), name)
+        if not m: continue
+        key = m.group(0)
         agg[key][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'SQ_WAVE_CYCLES':
             agg[key]['seconds'] += dur.get(r['Dispatch_Id'], 0.0); agg[key]['launches'] += 1

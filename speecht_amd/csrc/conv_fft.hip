@@ -112,7 +112,7 @@ struct RowsIn {                  // a padded NWC tensor, read frame-wise
 // channels_read give zeros.  outT (optional): the same values as [bins][2 * half][rows_pad].
 // A wavefront takes (row, 32 channels) items: 48 frame pairs as B fragments straight from the tensor, the DFT matrix
 // as A fragments from LDS (one 32-row tile at a time), 3 x 48 MFMAs.
-__global__ __launch_bounds__(256, 4) void dft_mfma_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
+__global__ __launch_bounds__(256, 2) void dft_mfma_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
                                                           float* __restrict__ out, float* __restrict__ outT) {
   __shared__ float wl[KP][KP + 1];                         // the DFT matrix, row pitch 97: fragment reads hit 32 banks
@@ -169,22 +169,15 @@ struct RowsOut {
   int c_pitch, channels, frames;
 };
 template <int TERMS>
-__global__ __launch_bounds__(256, 3) void idft_mfma_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
+__global__ __launch_bounds__(256, 2) void idft_mfma_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
                                                            int rows, int rows_pad, int bins, int half_in, int nchunks,
                                                            RowsOut y, const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ mask, long mask_batch_stride,
                                                            int mask_c_pitch) {
-  // term 0: all 64 rows; terms 1 / 2 (the neighbours) only ever touch frames [0, 32) / [32, 64): 32 rows each
-  constexpr int LROWS = TERMS == 1 ? V : 2 * V;
-  __shared__ float wl[LROWS][KP + 1];
+  __shared__ float wl[TERMS][V][KP + 1];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
-  for (int i = threadIdx.x; i < LROWS * KP; i += 256) {
-    const int lr = i / KP, col = i % KP;
-    // LDS row lr < 64: term 0 row lr; 64..95: term 1 rows 0..31; 96..127: term 2 rows 32..63
-    const int src = lr < V ? lr * KP : (lr < V + 32 ? (V + (lr - V)) * KP : (2 * V + 32 + (lr - V - 32)) * KP);
-    wl[lr][col] = winv[src + col];
-  }
+  for (int i = threadIdx.x; i < TERMS * V * KP; i += 256) wl[i / (V * KP)][(i / KP) % V][i % KP] = winv[i];
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half_in;
   // item = (row, 32 channels, frames [32 i, 32 i + 32) of the block)
@@ -210,7 +203,7 @@ __global__ __launch_bounds__(256, 3) void idft_mfma_kernel(const float* __restri
         bf[s] = (c < half_in && bin < bins) ? src[(long)bin * plane + (kk < HB ? 0 : half_in)] : 0.f;
       }
 #pragma unroll
-      for (int s = 0; s < KP / 2; ++s) a[s] = wl[(term == 0 ? i * 32 : (term == 1 ? V : V + 32)) + l31][2 * s + h];
+      for (int s = 0; s < KP / 2; ++s) a[s] = wl[term][i * 32 + l31][2 * s + h];
 #pragma unroll
       for (int s = 0; s < KP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
     }
@@ -347,7 +340,7 @@ RowsIn rows_in(const st_tensor3& t) {
   return r;
 }
 
-constexpr int TRANSFORM_WGS = 1024;              // persistent: up to four workgroups per CU, every wave walks its share of the items
+constexpr int TRANSFORM_WGS = 512;               // persistent: two workgroups per CU, every wave walks its share of the items
 
 void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int half, float* out, float* outT,
                 hipStream_t s) {

@@ -145,7 +145,7 @@ class Wav2LetterEngine:
     # ~10x fewer multiplications, same fp32 arithmetic class; results differ from the W-tap kernels by rounding,
     # ~1e-6 of the tensor scale).  fft_conv=False / ST_FFT_CONV=0 keeps the W-tap kernels everywhere.
     self.fft_conv = (os.environ.get('ST_FFT_CONV', '1') != '0') if fft_conv is None else bool(fft_conv)
-    self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '16'))
+    self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '7'))
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')

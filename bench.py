@@ -19,6 +19,7 @@ event timing) and `cpu_baseline` (the numpy oracle timed on the host cores, N=1 
 """
 import argparse
 import json
+import re
 import os
 import socket
 import subprocess
@@ -65,7 +66,7 @@ class HostFeed:
 
 def train_step(eng, feed, reducer, lr, global_batch):
   feed.next()
-  eng.forward()
+  eng.forward(training=True)
   eng.ctc_loss_grad(1.0 / global_batch)
   eng.backward(reducer.on_layer_done if reducer else None)
   if reducer:
@@ -73,58 +74,68 @@ def train_step(eng, feed, reducer, lr, global_batch):
   eng.apply_update(lr)
 
 
-DOMINANT = 'gemm_nn_kernel<128,128,2,2,0,true>'
-
-
 def measure_dominant_kernel(eng, batch, reps=10):
-  """HIP-event timing of every launch of the dominant kernel symbol gemm_nn_kernel<128,128,2,2,0,true> that one
-  training step makes (the same launches rocprofv3 --stats averages under that name):
-    * the forward convolution of the layers whose k-tiles are all whole and whose packed width is a multiple of 128
-      and that run as W-tap implicit GEMMs (L1..L7, L9; L8 too when the frequency-domain path is off);
-    * the three batched per-bin GEMMs of a frequency-domain layer (forward, back-prop to the input, filter gradient
-      of L8: 48 bins each), timed on the engine's own spectra buffers.
-  FLOPs are the algorithmic ones of each launch: 2*B*T'*W*Cin*Cout for a W-tap launch, 2 * rows * 2Cin * 2Cout * bins
-  for a per-bin product (complex as 4 real multiplies; unpadded channel counts, real row count).  Events are recorded
-  on the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
-  from speecht_amd._lib import call
-  flops = conv_flops(eng, batch)
-  s = eng.stream_ptr
-  launches = []                                  # (label, flops, bytes, fn)
-  if eng.conv_mode == 'bf16':
-    return measure_dominant_kernel_bf16(eng, batch, flops, reps)
+  """HIP-event timing of every matrix-pipe launch of one training step, grouped by kernel symbol; `roofline` is the
+  symbol with the largest total time (the dominant kernel), `roofline.by_kernel` lists the others.
 
-  def conv_fwd(i):
-    l = eng.layers[i]
-    pf, pb = eng._slice(eng.params, i)
-    return lambda: call('st_conv1d_nwc_fwd_f32', eng.X[i].ref, eng._ptr(pf), eng._ptr(pb), l.width, l.stride,
-                        eng.geo[i][2], int(l.relu), eng.X[i + 1].ref, s)
+  Launches: per layer the forward, back-prop-to-input and filter-gradient launch -- the W-tap implicit-GEMM entry
+  points, or for a frequency-domain layer the three batched per-bin products on the engine's own spectra buffers
+  (st_gemm_nn_batched_f32 / st_gemm_tn_batched_f32).  Which kernel instantiation a call runs is read from the
+  library's launch trace, not assumed.  FLOPs are the algorithmic ones of each launch: 2*B*T'*W*Cin*Cout for a W-tap
+  launch, 2 * rows * 2Cin * 2Cout * bins for a per-bin product (complex as 4 real multiplies; unpadded channel counts,
+  real row count).  Filter-gradient timings include the small slab-sum kernel that finishes a split launch.
+  Events are recorded on the stream the kernels are launched on; two untimed passes first so clocks are ramped."""
+  import ctypes
+  from speecht_amd._lib import call, launch_trace
+  if eng.conv_mode == 'bf16':
+    return measure_dominant_kernel_bf16(eng, batch, conv_flops(eng, batch), reps)
+  flops = conv_flops(eng, batch)
+  s, P = eng.stream_ptr, eng._ptr
+  ws, wsb = P(eng.wgrad_ws), eng.wgrad_ws.numel() * 4
+  launches = []                                  # (label, flops, bytes, fn)
   for i, l in enumerate(eng.layers):
-    if l.n_pad % 128 == 0 and l.cin_pitch % 32 == 0 and not (i in eng.fft and eng.fft_conv):
-      nbytes = 4.0 * (batch * eng.geo[i][0] * l.cin + l.width * l.cin * l.cout + batch * eng.geo[i][1] * l.cout)
-      launches.append(('L%d fwd' % i, flops[i], nbytes, conv_fwd(i)))
-  for i, f in (eng.fft.items() if eng.fft_conv else []):
-    l = eng.layers[i]
-    import ctypes
-    n, blocks, bins, rows_pad = (ctypes.c_int() for _ in range(4))
-    call('st_conv1d_fft_plan', l.width, eng.geo[i][1], batch, ctypes.byref(n), None, ctypes.byref(blocks), ctypes.byref(bins),
-         ctypes.byref(rows_pad))
-    rows, nb, rp = batch * blocks.value, bins.value, rows_pad.value
-    ka, nf, nbk = 2 * l.cin_pitch, 2 * l.n_pad, 2 * l.nt_pad
-    P = eng._ptr
-    shapes = [('fwd', f['sf'], ka, rp * ka, f['gfwd'], ka * nf, f['ws'], nf, rp * nf, rp, ka, nf, rows, 2 * l.cin, 2 * l.cout),
-              ('bwd', f['zf'], nf, rp * nf, f['gbwd'], nf * nbk, f['ws'], nbk, rp * nbk, rp, nf, nbk, rows, 2 * l.cout, 2 * l.cin),
-              ]
-    for name, A, lda, ab, B, bb, C, ldc, cb, M, K, N, m_real, k_real, n_real in shapes:
-      fl = 2.0 * m_real * k_real * n_real * nb
-      nbytes = 4.0 * nb * (m_real * k_real + k_real * n_real + m_real * n_real)
-      launches.append(('L%d %s x%d bins' % (i, name, nb), fl, nbytes,
-                       (lambda A=A, lda=lda, ab=ab, B=B, bb=bb, C=C, ldc=ldc, cb=cb, M=M, K=K, N=N, nb=nb:
-                        call('st_gemm_nn_batched_f32', P(A), lda, ab, P(B), bb, P(C), ldc, cb, M, K, N, nb, s))))
+    pl = eng.geo[i][2]
+    pf, pb = eng._slice(eng.params, i)
+    gf, gb = eng._slice(eng.grads, i)
+    io_bytes = 4.0 * (batch * eng.geo[i][0] * l.cin + l.width * l.cin * l.cout + batch * eng.geo[i][1] * l.cout)
+    if i in eng.fft and eng.fft_conv:
+      f = eng.fft[i]                             # (layer 0 runs on its polyphase view: f['width'] taps over f['cin'] channels)
+      blocks, bins, rows_pad = (ctypes.c_int() for _ in range(3))
+      call('st_conv1d_fft_plan', f['width'], eng.geo[i][1], batch, None, None, ctypes.byref(blocks), ctypes.byref(bins),
+           ctypes.byref(rows_pad))
+      rows, nb, rp = batch * blocks.value, bins.value, rows_pad.value
+      ka, nf, nbk = 2 * (-(-f['cin_pitch'] // 64) * 64), 2 * l.n_pad, 2 * l.nt_pad
+      cin_real = l.cin * (l.stride if f['shift'] is not None else 1)
+      fl = 2.0 * rows * (2 * cin_real) * (2 * l.cout) * nb
+      nbytes = 4.0 * nb * (rows * 2 * cin_real + 4 * cin_real * l.cout + rows * 2 * l.cout)
+      launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb: call(
+          'st_gemm_nn_batched_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, P(f['ws']), nf, rp * nf, rp, ka, nf, nb, s)))
+      if i > 0:
+        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, nbk=nbk, nf=nf, rp=rp, nb=nb: call(
+            'st_gemm_nn_batched_f32', P(f['zf']), nf, rp * nf, P(f['gbwd']), nf * nbk, P(f['ws']), nbk, rp * nbk, rp, nf, nbk, nb, s)))
+      launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb: call(
+          'st_gemm_tn_batched_f32', P(f['sf']), ka, rp * ka, P(f['zf']), nf, rp * nf, P(f['ws']), ka * nf, rp, ka, nf, nb, s)))
+      continue
+    if l.n_pad % 128:
+      continue                                   # the 29-class output layer: an HBM stream, not a matrix-pipe launch
+    launches.append(('L%d fwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, pf=pf, pb=pb: call(
+        'st_conv1d_nwc_fwd_ws_f32', eng.X[i].ref, P(pf), P(pb), l.width, l.stride, pl, int(l.relu), eng.X[i + 1].ref, ws, wsb, s)))
+    if i > 0:
+      launches.append(('L%d bwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl: call(
+          'st_conv1d_nwc_bwd_data_bias_f32', eng.dZ[i].ref, P(eng.packed_t[i]), l.width, pl,
+          eng.X[i].ref if eng.layers[i - 1].relu else None, eng.dZ[i - 1].ref, P(eng._slice(eng.grads, i - 1)[1]), ws, wsb, s)))
+    launches.append(('L%d wgrad' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, gf=gf: call(
+        'st_conv1d_nwc_bwd_filter_f32', eng.X[i].ref, eng.dZ[i].ref, l.width, l.stride, pl, P(gf), None, ws, wsb, s)))
   if not launches:
     return None
-  for _ in range(2):
-    for _, _, _, fn in launches:
+  symbols = []
+  for _, _, _, fn in launches:
+    with launch_trace() as tr:
       fn()
+    first = tr.lines[0].split()
+    symbols.append(first[0] + (' epi=1' if (len(first) > 1 and first[1] == 'epi=1') else (' epi=0' if first[0].startswith('gemm_nn<') else '')))
+  for _, _, _, fn in launches:
+    fn()
   evs = []
   for _ in range(reps):
     for k, (_, _, _, fn) in enumerate(launches):
@@ -134,22 +145,30 @@ def measure_dominant_kernel(eng, batch, reps=10):
       e1.record()
       evs.append((k, e0, e1))
   torch.cuda.synchronize()
-  per = [0.0] * len(launches)
+  samples = [[] for _ in launches]
   for k, e0, e1 in evs:
-    per[k] += e0.elapsed_time(e1) / reps
-  tot_ms = sum(per)
-  tot_flops = sum(l[1] for l in launches)
-  tot_bytes = sum(l[2] for l in launches)
-  n = len(launches)
-  achieved = tot_flops / (tot_ms * 1e-3) / 1e12
-  return dict(bound='mfma', kernel=DOMINANT + ' (%s)' % '; '.join(l[0] for l in launches),
-              achieved=round(achieved, 2), peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-              frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, traffic_unit='bytes/launch (PMC, see profiles/)',
-              avg_launch_ms=round(tot_ms / n, 4), launches_per_step=n,
-              per_launch={l[0]: dict(ms=round(t, 4), tflops=round(l[1] / (t * 1e-3) / 1e12, 1)) for l, t in zip(launches, per)},
-              algorithmic_gflop_per_launch=round(tot_flops / n / 1e9, 2),
-              algorithmic_mb_per_launch=round(tot_bytes / n / 1e6, 2),
-              hbm_frac_of_peak=round(tot_bytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+    samples[k].append(e0.elapsed_time(e1))
+  per = [float(np.median(v)) for v in samples]   # median over the repetitions: one disturbed interval does not move a launch
+
+  def group(sym):
+    idx = [k for k, s_ in enumerate(symbols) if s_ == sym]
+    ms, fl, by = sum(per[k] for k in idx), sum(launches[k][1] for k in idx), sum(launches[k][2] for k in idx)
+    tf = fl / (ms * 1e-3) / 1e12
+    return dict(kernel=sym, launches_per_step=len(idx), ms_per_step=round(ms, 4), achieved=round(tf, 2), frac=round(tf / PEAK_F32_TFLOPS, 4),
+                avg_launch_ms=round(ms / len(idx), 4), algorithmic_gflop_per_launch=round(fl / len(idx) / 1e9, 2),
+                algorithmic_mb_per_launch=round(by / len(idx) / 1e6, 2),
+                per_launch={launches[k][0]: dict(ms=round(per[k], 4), tflops=round(launches[k][1] / (per[k] * 1e-3) / 1e12, 1)) for k in idx})
+  groups = sorted((group(sym) for sym in sorted(set(symbols))), key=lambda g: -g['ms_per_step'])
+  dom = groups[0]
+  all_ms, all_fl = sum(per), sum(l[1] for l in launches)
+  out = dict(bound='mfma', peak=PEAK_F32_TFLOPS, unit='TFLOP/s', traffic=None, traffic_unit='bytes/launch (PMC, see profiles/)')
+  out.update(dom)
+  out['hbm_frac_of_peak'] = round(dom['algorithmic_mb_per_launch'] * 1e6 / (dom['avg_launch_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+  out['by_kernel'] = [{k: v for k, v in g.items() if k != 'per_launch'} for g in groups[1:]]
+  out['all_matrix_launches'] = dict(launches_per_step=len(launches), ms_per_step=round(all_ms, 3),
+                                    achieved=round(all_fl / (all_ms * 1e-3) / 1e12, 2),
+                                    frac=round(all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4))
+  return out
 
 
 def measure_dominant_kernel_bf16(eng, batch, flops, reps):
@@ -344,7 +363,11 @@ def main():
                   help='arithmetic of the timed loop (default fp32 = BASELINE configs[1]; bf16 = configs[3] arithmetic)')
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
                   help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
+  ap.add_argument('--tune', action='append', default=[], help='name=value override of a library policy (st_set_tuning; experiments only)')
   args = ap.parse_args()
+  for kv in args.tune:
+    from speecht_amd._lib import set_tuning
+    set_tuning(kv.split('=')[0], int(kv.split('=')[1]))
 
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(self_launch(args))
@@ -472,12 +495,15 @@ def main():
     out['roofline'] = measure_dominant_kernel(eng, args.batch)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
     if out['roofline'] and eng.conv_mode != 'bf16' and os.path.exists(traffic_file):
-      out['roofline']['traffic'] = json.load(open(traffic_file)).get('bytes_per_launch')
-      out['roofline']['traffic_source'] = ('profiles/traffic.json: TCC_EA0_RDREQ/WRREQ PMC passes of rocprofv3 over this '
+      out['roofline']['traffic'] = json.load(open(traffic_file)).get('by_kernel', {}).get(out['roofline']['kernel'], {}).get('bytes_per_launch')
+      out['roofline']['traffic_source'] = ('profiles/traffic.json: FETCH_SIZE / WRITE_SIZE PMC passes of rocprofv3 over this '
                                            'command (scripts/gpu_traffic.sh); counters cannot be read from inside the run')
     util_file = os.path.join(ROOT, 'profiles', 'mfma_util.json')
     if out['roofline'] and eng.conv_mode != 'bf16' and os.path.exists(util_file):      # PMC pass (scripts/gpu_mfma_util.sh), padded work included
-      out['roofline']['mfma_busy_pmc'] = json.load(open(util_file)).get('gemm_nn_kernel<128, 128, 2, 2, 0, true>', {}).get('mfma_busy_frac_at_2p4ghz')
+      m = re.match(r'gemm_nn<(\d+),(\d+),(\d+),(\d+),(fast|clamped)> epi=(\d)', out['roofline']['kernel'])
+      key = ('gemm_nn_kernel<%s, %s, %s, %s, %s, %s>' % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(6), 'true' if m.group(5) == 'fast' else 'false')
+             if m else 'gemm_tn_kernel<128, 2, 2>')
+      out['roofline']['mfma_busy_pmc'] = json.load(open(util_file)).get(key, {}).get('mfma_busy_frac_at_2p4ghz')
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:

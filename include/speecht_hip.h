@@ -92,19 +92,21 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
                              int stride, int pad_left, int relu, const st_tensor3* y, void* workspace,
                              size_t workspace_bytes, void* stream);
 
-/* ---- frequency-domain form of the same three operations for long, wide filters (csrc/conv_fft.hip) ----------
- * For the model's 32-tap 250 -> 2000 layer (speech_model.py:285; 66 % of the step's MACs) time is cut into blocks of
- * 64 frames, every block is taken to the frequency domain by a length-(63 + W) DFT, the W taps become one complex
- * channel-contraction per frequency bin -- run as real GEMMs on the exact-fp32 MFMA kernel -- and the result comes
- * back by an inverse DFT fused with the bias / ReLU / mask epilogue: ~10x fewer multiplications than the W-tap
- * form, same fp32 arithmetic class (tests/test_gpu_fft_conv.py).  stride 1, W <= 33; both channel counts must pack
- * to multiples of 128.
+/* ---- frequency-domain form of the same three operations (csrc/conv_fft.hip) ---------------------------------
+ * Time is cut into blocks of 64 frames, every block is taken to the frequency domain by a length-(63 + W) DFT, the W
+ * taps become one complex channel-contraction per frequency bin -- run as real GEMMs on the exact-fp32 MFMA kernel --
+ * and the result comes back by an inverse DFT fused with the bias / ReLU / mask epilogue: for the model's 32-tap
+ * 250 -> 2000 layer (speech_model.py:285; 66 % of the step's MACs) ~10x fewer multiplications than the W-tap form,
+ * same fp32 arithmetic class (tests/test_gpu_fft_conv.py).  stride 1, W <= 33; the output channels must pack to a
+ * multiple of 128 (and the input channels too for back-prop to the input).  A stride-2 layer of even-ish width runs
+ * through the same entry points on its polyphase view: the input read as [B][T/2][2 * c_pitch] (frame pairs as
+ * channels), W/2 + 1 taps, the packed filters shifted by one c_pitch block (engine.py does this for
+ * the model's first layer).
  *   tables    st_conv1d_fft_table_floats() floats, filled once per (width, pad_left) by st_conv1d_fft_tables_f32
  *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats), rebuilt by
  *             st_conv1d_fft_filters_f32 whenever the weights change (gbwd from the flipped / transposed copy)
- *   sf/sft    spectra of the layer input (st_conv1d_fft_sf_floats floats each), written by the forward call and read by
- *             the filter-gradient call; the transposed copy sft is only needed (else NULL in both calls) when
- *             2 * x->c_pitch is not a multiple of 128
+ *   sf        spectra of the layer input (st_conv1d_fft_sf_floats floats), written by the forward call and read by
+ *             the filter-gradient call
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
  *   workspace st_conv1d_fft_ws bytes, scratch of one call */
@@ -126,15 +128,18 @@ size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int wid
 size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width);
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width);
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
-                              const st_tensor3* y, const float* tables, float* sf, float* sft, void* workspace,
+                              const st_tensor3* y, const float* tables, float* sf, void* workspace,
                               size_t workspace_bytes, void* stream);
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream);
+/* dbias[o] = sum_{b,t} dz[b,t,o] read off bin 0 of the spectra zf (npad floats written, pads zero): the bias gradient of a
+ * frequency-domain layer without another pass over dz */
+int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf, float* dbias, void* stream);
 int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
                                    const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
                                    size_t workspace_bytes, void* stream);
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* sft,
-                                     const float* zf, int width, const float* tables, float* dpacked, void* workspace,
-                                     size_t workspace_bytes, void* stream);
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* zf, int width,
+                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
+                                     void* stream);
 
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),

@@ -42,3 +42,14 @@ for name, M, K, N, bins in [('tn8', args.rows, 512, 4096, 48), ('tn7', args.rows
   ref = A.view(bins, M, K)[1].double().T @ Z.view(bins, M, N)[1].double()
   err = float((C.view(bins, K, N)[1].double() - ref).abs().max() / ref.abs().max())
   print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s  (check %.1e)' % (name, M, K, N, bins, ms, 2.0 * M * K * N * bins / ms / 1e9, err))
+
+# where the time of the small per-bin products goes: fixed cost (K -> 0), the slope per k-tile, and the step at
+# 8-bin boundaries (bins are dealt to the 8 XCDs)
+if os.environ.get('SWEEP'):
+  for bins in (32, 36, 40, 64):
+    for K in (32, 128, 256, 512, 1024):
+      M, N = args.rows, 512
+      A = torch.randn(bins * M * K, device=dev); B = torch.randn(bins * K * N, device=dev); C = torch.empty(bins * M * N, device=dev)
+      fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, None)
+      ms = timeit(fn, 20)
+      print('sweep  bins=%d M=%d K=%d N=%d: %.1f us  %.1f TF/s' % (bins, M, K, N, ms * 1e3, 2.0 * M * K * N * bins / ms / 1e9))

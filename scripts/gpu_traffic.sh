@@ -8,22 +8,40 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline > $OUT/$C.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
-import csv, glob, json, os
+import collections, csv, glob, json, os, re
 root = os.environ['GRAFT_REPO_ROOT']
-vals = {}
+
+
+def bench_key(name):
+    """rocprof symbol -> the key bench.py's roofline uses (the library's launch-trace name)."""
+    m = re.search(r'gemm_nn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>', name)
+    if m:
+        return 'gemm_nn<%s,%s,%s,%s,%s> epi=%s' % (m.group(1), m.group(2), m.group(3), m.group(4),
+                                                     'fast' if m.group(6) == 'true' else 'clamped', m.group(5))
+    m = re.search(r'gemm_tn_kernel<(\d+),', name)
+    return 'gemm_tn<%s>' % m.group(1) if m else None
+
+
+vals = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(os.path.join(root, 'gpurun_out/traffic', c, '**', '*counter_collection.csv'), recursive=True)
-    rows = [r for r in csv.DictReader(open(f[0])) if 'gemm_nn_kernel<128, 128, 2, 2, 0, true>' in r['Kernel_Name'] and r['Counter_Name'] == c]
-    vals[c] = (sum(float(r['Counter_Value']) for r in rows) / len(rows), len(rows))
-fetch = vals['FETCH_SIZE'][0] * 1024 * 2      # gfx950 correction (MI355X_MICROARCH.md, HBM section)
-write = vals['WRITE_SIZE'][0] * 1024
-out = dict(kernel='gemm_nn_kernel<128,128,2,2,0,true>', launches=vals['FETCH_SIZE'][1],
-           fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, bytes_per_launch=fetch + write,
-           note='FETCH_SIZE x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE x 1024, averaged over all launches of the symbol')
+    for r in csv.DictReader(open(f[0])):
+        k = bench_key(r['Kernel_Name'])
+        if k and r['Counter_Name'] == c:
+            vals[k][c][0] += float(r['Counter_Value'])
+            vals[k][c][1] += 1
+by = {}
+for k, d in vals.items():
+    fetch = d['FETCH_SIZE'][0] / max(d['FETCH_SIZE'][1], 1) * 1024 * 2      # gfx950 correction (MI355X_MICROARCH.md, HBM section)
+    write = d['WRITE_SIZE'][0] / max(d['WRITE_SIZE'][1], 1) * 1024
+    by[k] = dict(launches=d['FETCH_SIZE'][1], fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, bytes_per_launch=fetch + write)
+out = dict(by_kernel=by, command='bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline',
+           note='FETCH_SIZE x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE x 1024, averaged over all launches of the symbol '
+                '(the training steps and the roofline-measurement launches of the same command: the same launch mix)')
 json.dump(out, open(os.path.join(root, 'gpurun_out/traffic/traffic.json'), 'w'), indent=1)
 print(json.dumps(out))
 PY

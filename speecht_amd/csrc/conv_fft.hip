@@ -23,6 +23,7 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int V = 64;                        // output frames per block
@@ -38,6 +39,9 @@ constexpr int T_FW = T_TW + 256;             // (cos, sin)(2 pi k w / N), k < bi
 constexpr int T_END = T_FW + HB * 34 * 2;    // contiguous row per bin, read with wide scalar loads)
 
 int npad_of(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)st::round_up(c, 128)); }
+// spectra of a tensor with channel pitch cp keep `half_of(cp)` columns for the real and for the imaginary parts: a
+// multiple of 64, so that [re | im] rows tile the filter-gradient kernel (128 columns) whatever the pitch
+int half_of(int cp) { return (int)st::round_up(cp, 64); }
 
 struct Plan {
   int n, blocks, bins, rows, rows_pad;
@@ -109,52 +113,91 @@ struct RowsIn {                  // a padded NWC tensor, read frame-wise
 // ---- forward DFT of time segments on the matrix pipe ----------------------------------------------------------
 // row = b * blocks + j:  out[k][row][c] = sum_n Wm[(re | im, k)][n] * x[b][j * V + start + n][c], stored
 // [bins][rows_pad][2 * half] with re at column c and im at column half + c; rows >= rows and channels >=
-// channels_read give zeros.  outT (optional): the same values as [bins][2 * half][rows_pad].
-// A wavefront takes (row, 32 channels) items: 48 frame pairs as B fragments straight from the tensor, the DFT matrix
-// as A fragments from LDS (one 32-row tile at a time), 3 x 48 MFMAs.
-__global__ __launch_bounds__(256, 2) void dft_mfma_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
+// channels_read give zeros.
+// One (row, 32 channels) item per wavefront.
+// The frames are loaded ONCE for the three 32-row tiles of the DFT matrix (three independent accumulator chains), only
+// the `nstages * CH` frame pairs the matrix has non-zero columns for, and in stages of CH pairs: the loads of stage
+// st + 1 are in flight while the 3 * CH MFMAs of stage st run.  The matrix sits in LDS pair-interleaved
+// ((2s, 2s + 1) of every row adjacent), so an A fragment is one ds_read_b32 at consecutive addresses across the wave.
+constexpr int CH = 12;                       // frame (bin) pairs per pipeline stage; KP / 2 = 4 * CH
+
+template <int R>
+__device__ inline void stage_matrix(float* __restrict__ dst, const float* __restrict__ src) {      // src [R][KP] row-major
+  for (int i = threadIdx.x; i < R * KP / 4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    const int row = (i * 4) / KP, k = (i * 4) % KP;          // KP % 4 == 0: four columns of one row
+    f32x2* d = reinterpret_cast<f32x2*>(dst) + ((k >> 1) * R + row);
+    d[0] = f32x2{v[0], v[1]};
+    d[R] = f32x2{v[2], v[3]};
+  }
+}
+
+template <int NST>                           // stages of CH frame pairs: the matrix has no columns past 2 * NST * CH
+__global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
-                                                          float* __restrict__ out, float* __restrict__ outT) {
-  __shared__ float wl[KP][KP + 1];                         // the DFT matrix, row pitch 97: fragment reads hit 32 banks
+                                                          float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float wl[KP * KP];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
-  for (int i = threadIdx.x; i < KP * KP; i += 256) wl[i / KP][i % KP] = wm[i];
+  stage_matrix<KP>(wl, wm);
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half;
-  // item = (row, 32 channels, one 32-row tile of the DFT matrix): three times the items of a (row, channels) split --
-  // narrow tensors (256 channels) still fill the chip and a wave's dependent chain is 48 loads + 48 MFMAs
-  for (int item = gw; item < rows_pad * nchunks * 3; item += total) {
-    const int i = item % 3, rc = item / 3;
-    const int row = rc / nchunks, c = (rc - row * nchunks) * 32 + l31;
-    f32x16 acc;
+  const float* afrag = wl + 2 * l31 + h;
+  for (int item = gw; item < rows_pad * nchunks; item += total) {
+    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
+    f32x16 acc[3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     if (row < rows) {
       const int b = row / blocks, j = row - b * blocks;
       const int t0 = j * V + start + h;
       const bool cok = c < x.channels_read;
-      const float* src = x.base + (long)b * x.batch_stride + c;
-      float bf[KP / 2], a[KP / 2];
+      const float* src = x.base + (long)b * x.batch_stride + min(c, x.channels_read - 1);
+      // branch-free: every lane loads from a clamped, readable address; what it must not see is masked off when the
+      // value is consumed (a select next to the load would make the wave wait for it there)
+      auto load = [&](float (&bf)[CH], int st) {
 #pragma unroll
-      for (int s = 0; s < KP / 2; ++s) {
-        const int t = t0 + 2 * s;
-        bf[s] = (cok && t >= x.t_lo && t < x.t_hi) ? src[(long)t * x.c_pitch] : 0.f;
+        for (int s = 0; s < CH; ++s) {
+          const int t = t0 + 2 * (st * CH + s);
+          bf[s] = src[(long)min(max(t, x.t_lo), x.t_hi - 1) * x.c_pitch];
+        }
+      };
+      auto mac = [&](const float (&bf)[CH], int st) {
+        const float* a = afrag + st * (CH * KP * 2);
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+          const int t = t0 + 2 * (st * CH + s);
+          const unsigned keep = (cok && t >= x.t_lo && t < x.t_hi) ? 0xffffffffu : 0u;
+          const float v = __uint_as_float(__float_as_uint(bf[s]) & keep);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(s * KP + i * 32) * 2], v, acc[i], 0, 0, 0);
+        }
+      };
+      // the scheduling fences keep the compiler from hoisting later stages' loads (and their address registers)
+      // above the MFMAs of this one; the stage loop is unrolled at compile time so that the waits are exact counts
+      // (`vmcnt(12 + k)`: the older stage has landed, the newer one stays in flight)
+      float bfr[2][CH];
+      load(bfr[0], 0);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        if (st + 1 < NST) load(bfr[(st + 1) & 1], st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bfr[st & 1], st);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int s = 0; s < KP / 2; ++s) a[s] = wl[i * 32 + l31][2 * s + h];
-#pragma unroll
-      for (int s = 0; s < KP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
     }
     if (c < half) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
-        if (bin < bins) {
-          out[(long)bin * plane + (long)row * 2 * half + col] = acc[r];
-          if (outT) outT[(long)bin * plane + (long)col * rows_pad + row] = acc[r];
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
+          if (bin < bins) out[(long)bin * plane + (long)row * 2 * half + col] = acc[i][r];
         }
-      }
     }
   }
 }
@@ -168,69 +211,121 @@ struct RowsOut {
   long batch_stride;
   int c_pitch, channels, frames;
 };
-template <int TERMS>
-__global__ __launch_bounds__(256, 2) void idft_mfma_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
+// One (row, 32 channels) item per wavefront: both 32-frame halves of the block from one pass over
+// the spectra (HP bin pairs of real parts, HP of imaginary parts: 2 * HP >= bins), loads one stage ahead of the MFMAs
+// across the terms; a neighbour term only feeds the half of the block it reaches.
+template <int TERMS, int HP>
+__global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
                                                            int rows, int rows_pad, int bins, int half_in, int nchunks,
                                                            RowsOut y, const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ mask, long mask_batch_stride,
                                                            int mask_c_pitch) {
-  __shared__ float wl[TERMS][V][KP + 1];
+  constexpr int NST = 2 * HP / CH;                      // stages per term
+  static_assert(2 * HP % CH == 0 && HP <= HB / 2, "pairs per term must fill whole stages");
+  __shared__ __attribute__((aligned(16))) float wl[TERMS * V * KP];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
-  for (int i = threadIdx.x; i < TERMS * V * KP; i += 256) wl[i / (V * KP)][(i / KP) % V][i % KP] = winv[i];
+#pragma unroll
+  for (int term = 0; term < TERMS; ++term) stage_matrix<V>(wl + term * V * KP, winv + term * V * KP);
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half_in;
-  // item = (row, 32 channels, frames [32 i, 32 i + 32) of the block)
-  for (int item = gw; item < rows * nchunks * 2; item += total) {
-    const int i = item & 1, rc = item >> 1;
-    const int row = rc / nchunks, c = (rc - row * nchunks) * 32 + l31;
+  const float* afrag = wl + 2 * l31 + h;
+  for (int item = gw; item < rows * nchunks; item += total) {
+    const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
     const int b = row / blocks, j = row - b * blocks;
-    f32x16 acc;
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int term = 0; term < TERMS; ++term) {
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // the ReLU mask of the 64 frames first, branch-free (clamped addresses): gathered next to the stores each load would
+    // expose a full memory latency -- for all the compiler knows the output aliases the mask
+    float mk[2][16];
+    if (mask) {
+      const float* mp = mask + (long)b * mask_batch_stride + min(c, mask_c_pitch - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          mk[i][r] = mp[(long)min(j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, y.frames - 1) * mask_c_pitch];
+    }
+    const float* src = in + (long)row * 2 * half_in + min(c, half_in - 1);
+    const bool cok = c < half_in;
+    // global stage g = term * NST + st; pair p = st * CH + s of a term: p < HP -> real parts of bins (2p, 2p + 1),
+    // else imaginary parts of bins (2 (p - HP), 2 (p - HP) + 1)
+    auto load = [&](float (&bf)[CH], int g) {
+      const int term = g / NST, st = g % NST;
       const int off = term == 0 ? 0 : (term == 1 ? -1 : 1);
-      if (j + off < 0 || j + off >= blocks) continue;                 // wave-uniform
-      // the neighbours only reach W - 1 frames into this block: frames [0, 32) never see block j + 1, [32, 64) never j - 1
-      if (TERMS > 1 && ((term == 1 && i == 1) || (term == 2 && i == 0))) continue;
-      const float* src = in + (long)(row + off) * 2 * half_in + c;
-      float bf[KP / 2], a[KP / 2];
+      const bool there = j + off >= 0 && j + off < blocks;                 // wave-uniform
+      const float* sp = src + (there ? (long)off * 2 * half_in : 0L);
+      // branch-free: clamped, readable addresses; what must not be seen is masked off in mac()
 #pragma unroll
-      for (int s = 0; s < KP / 2; ++s) {
-        const int kk = 2 * s + h;
-        const int bin = kk < HB ? kk : kk - HB;
-        bf[s] = (c < half_in && bin < bins) ? src[(long)bin * plane + (kk < HB ? 0 : half_in)] : 0.f;
+      for (int s = 0; s < CH; ++s) {
+        const int p = st * CH + s;
+        const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+        bf[s] = sp[(long)min(bin, bins - 1) * plane + (p < HP ? 0 : half_in)];
       }
+    };
+    auto mac = [&](const float (&bf)[CH], int g) {
+      const int term = g / NST, st = g % NST;
+      const int off = term == 0 ? 0 : (term == 1 ? -1 : 1);
+      const bool live = cok && j + off >= 0 && j + off < blocks;
+      const float* a = afrag + term * (V * KP);
 #pragma unroll
-      for (int s = 0; s < KP / 2; ++s) a[s] = wl[term][i * 32 + l31][2 * s + h];
+      for (int s = 0; s < CH; ++s) {
+        const int p = st * CH + s;
+        const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+        const unsigned keep = (live && bin < bins) ? 0xffffffffu : 0u;
+        const float v = __uint_as_float(__float_as_uint(bf[s]) & keep);
+        const int sidx = p < HP ? p : HB / 2 + (p - HP);                    // pair index into the [V][KP] matrix
+        // the neighbours only reach W - 1 frames into this block: frames [0, 32) never see block j + 1, [32, 64) never j - 1
+        if (term != 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(sidx * V) * 2], v, acc[0], 0, 0, 0);
+        if (term != 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(sidx * V + 32) * 2], v, acc[1], 0, 0, 0);
+      }
+    };
+    float bfr[2][CH];
+    load(bfr[0], 0);
 #pragma unroll
-      for (int s = 0; s < KP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
+    for (int g = 0; g < TERMS * NST; ++g) {                       // fences: see dft_rows_kernel
+      if (g + 1 < TERMS * NST) load(bfr[(g + 1) & 1], g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(bfr[g & 1], g);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (c < y.c_pitch) {
       const float bv = (bias && c < y.channels) ? bias[c] : 0.f;
+      // all values first, then nothing but stores: a load-dependent select next to a predicated store makes the
+      // compiler wait for every earlier store as well
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (t < y.frames) {
-          float val = c < y.channels ? acc[r] + bv : 0.f;         // pad channels stay zero
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float val = c < y.channels ? acc[i][r] + bv : 0.f;           // pad channels stay zero
           if (relu) val = fmaxf(val, 0.f);
-          if (mask) val = mask[(long)b * mask_batch_stride + (long)t * mask_c_pitch + c] > 0.f ? val : 0.f;
-          y.base[(long)b * y.batch_stride + (long)t * y.c_pitch + c] = val;
+          if (mask) val = mk[i][r] > 0.f ? val : 0.f;
+          asm volatile("" : "+v"(val));                               // pinned here: not sunk into the store's predicate block
+          acc[i][r] = val;
         }
-      }
+      float* yp = y.base + (long)b * y.batch_stride + c;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (t < y.frames) yp[(long)t * y.c_pitch] = acc[i][r];
+        }
     }
   }
 }
 
 // ---- filters -> their spectra in the two GEMM operand layouts -------------------------------------------------
 // G[k][c][o] = sum_w F[w][c][o] e^{-2 pi i k w / N}.
-//  forward operand  gfwd [bins][2 cpi][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G))
-//  from packed [w * cpi + c][npo]; one thread per (c, o), o fastest (coalesced reads and writes).
+//  forward operand  gfwd [bins][2 cph][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G); cph = spectra half width)
+//  from packed [w * cpi + c][npo]; one thread per (c, o), o fastest (coalesced reads and writes); rows c >= cin zero.
 // (WT = compile-time width: the taps stay in registers; WT = 0: run-time width, taps in scratch)
 template <int WT>
 __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __restrict__ packed, int width_rt, int cin, int cout,
-                                                              int cpi, int npo, int n, int bins,
+                                                              int cpi, int cph, int npo, int n, int bins,
                                                               const f32x2* __restrict__ tw, float* __restrict__ gfwd) {
   const int width = WT ? WT : width_rt;
   const int o = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
@@ -239,7 +334,7 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
   const bool live = c < cin && o < cout;
 #pragma unroll
   for (int w = 0; w < width; ++w) f[w] = live ? packed[((long)w * cpi + c) * npo + o] : 0.f;
-  const long plane = (long)2 * cpi * 2 * npo;
+  const long plane = (long)2 * cph * 2 * npo;
   for (int k = 0; k < bins; ++k) {
     float gr = 0.f, gi = 0.f;
     const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
@@ -252,8 +347,8 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
     float* g = gfwd + (long)k * plane;
     g[(long)c * 2 * npo + o] = gr;
     g[(long)c * 2 * npo + npo + o] = -gi;
-    g[(long)(cpi + c) * 2 * npo + o] = gi;
-    g[(long)(cpi + c) * 2 * npo + npo + o] = gr;
+    g[(long)(cph + c) * 2 * npo + o] = gi;
+    g[(long)(cph + c) * 2 * npo + npo + o] = gr;
   }
 }
 
@@ -290,10 +385,10 @@ __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __res
 }
 
 // ---- filter gradient: spectra of the lag products back to the W taps ---------------------------------------------
-// q [bins][2 cpi][2 npo] = [S_r | S_i]^T [Z_r | Z_i]:  Re = P00 + P11, Im = P10 - P01;
+// q [bins][2 cph][2 npo] = [S_r | S_i]^T [Z_r | Z_i]:  Re = P00 + P11, Im = P10 - P01;
 // dF[w][c][o] = (1 / N) sum_k w_k (Re cos(2 pi k w / N) - Im sin(2 pi k w / N)) into dpacked [w * cpi + c][npo].
 template <int WT>
-__global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restrict__ q, int width_rt, int cin, int cout, int cpi,
+__global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restrict__ q, int width_rt, int cin, int cout, int cpi, int cph,
                                                            int npo, int n, int bins, const f32x2* __restrict__ tw,
                                                            float* __restrict__ dpacked) {
   const int width = WT ? WT : width_rt;
@@ -303,14 +398,14 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
 #pragma unroll
   for (int w = 0; w < width; ++w) acc[w] = 0.f;
   const bool live = c < cin && o < cout;
-  const long plane = (long)2 * cpi * 2 * npo;
+  const long plane = (long)2 * cph * 2 * npo;
   const float inv_n = 1.f / (float)n;
   if (live) {
     for (int k = 0; k < bins; ++k) {
       const float* p = q + (long)k * plane;
       const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;      // DC (and the Nyquist bin of an even N) count once
-      const float re = (p[(long)c * 2 * npo + o] + p[(long)(cpi + c) * 2 * npo + npo + o]) * wk;
-      const float im = (p[(long)(cpi + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
+      const float re = (p[(long)c * 2 * npo + o] + p[(long)(cph + c) * 2 * npo + npo + o]) * wk;
+      const float im = (p[(long)(cph + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
       const f32x2* row = tw + k * width;                   // uniform: wide scalar loads
 #pragma unroll
       for (int w = 0; w < width; ++w) {
@@ -322,6 +417,27 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
   }
 #pragma unroll
   for (int w = 0; w < width; ++w) dpacked[((long)w * cpi + c) * npo + o] = acc[w];
+}
+
+// ---- bias gradient from the spectra of dz: bin 0 of a block is the plain sum of its 64 frames, so
+// dbias[o] = sum_rows Z[0][row][o] -- 256 x n floats instead of a pass over the whole gradient tensor.
+// 32 columns x 8 row-lanes per block, fixed summation order.
+__global__ __launch_bounds__(256) void bias_from_spectra_kernel(const float* __restrict__ zf, int rows, int ld, int channels, int np,
+                                                                float* __restrict__ dbias) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < channels)
+    for (int k = r; k < rows; k += 8) s += zf[(long)k * ld + c];
+  red[r][cl] = s;
+  __syncthreads();
+  if (r == 0 && c < np) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][cl];
+    dbias[c] = t;
+  }
 }
 
 bool tensor_ok(const st_tensor3* t) {
@@ -342,12 +458,28 @@ RowsIn rows_in(const st_tensor3& t) {
 
 constexpr int TRANSFORM_WGS = 512;               // persistent: two workgroups per CU, every wave walks its share of the items
 
-void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int half, float* out, float* outT,
+void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
                 hipStream_t s) {
   const int nchunks = st::ceil_div(half, 32);
-  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks * 3, 4));
-  hipLaunchKernelGGL(dft_mfma_kernel, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start,
-                     pl.bins, half, nchunks, out, outT);
+  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks, 4));
+  if (frames_used <= 6 * CH)                                               // the matrix has no columns past frames_used
+    hipLaunchKernelGGL(dft_rows_kernel<3>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
+                       half, nchunks, out);
+  else
+    hipLaunchKernelGGL(dft_rows_kernel<4>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
+                       half, nchunks, out);
+}
+
+template <int TERMS>
+void launch_idft(const float* in, const float* winv, const Plan& p, int half_in, int nchunks, const RowsOut& out, const float* bias,
+                 int relu, const float* mask, long mask_batch_stride, int mask_c_pitch, hipStream_t s) {
+  const dim3 grid(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4)));
+  if (p.bins <= 36)
+    hipLaunchKernelGGL((idft_rows_kernel<TERMS, 18>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
+                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
+  else
+    hipLaunchKernelGGL((idft_rows_kernel<TERMS, 24>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
+                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
@@ -389,40 +521,45 @@ int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t tabl
 size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward) {
   if (!width_ok(width)) return 0;
   const size_t bins = (V + width - 1) / 2 + 1;
-  return backward ? bins * 2 * npad_of(cout) * 2 * npad_of(cin) : bins * 2 * cin_pitch * 2 * npad_of(cout);
+  return backward ? bins * 2 * npad_of(cout) * 2 * npad_of(cin) : bins * 2 * half_of(cin_pitch) * 2 * npad_of(cout);
 }
 
 int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int cin, int cout, int cin_pitch,
                               int cout_pitch, const float* tables, float* gfwd, float* gbwd, void* stream) {
   ST_REQUIRE(width_ok(width) && cin_pitch % 16 == 0 && cout_pitch % 16 == 0 && tables, "fft filters: bad shape");
-  ST_REQUIRE(npad_of(cout) % 128 == 0 && npad_of(cin) % 128 == 0, "fft filters: both channel counts must pack to multiples of 128");
+  ST_REQUIRE(npad_of(cout) % 128 == 0, "fft filters: the output channels must pack to a multiple of 128");
   hipStream_t s = st::as_stream(stream);
   const int n = V + width - 1, bins = n / 2 + 1;
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int npo = npad_of(cout), npi = npad_of(cin);
+  // compile-time widths for the layers of the model (taps in registers); any other width runs the generic form
+#define ST_FFT_WIDTH_DISPATCH(KERNEL, ...)                                                                   \
+  do {                                                                                                       \
+    if (width == 32) hipLaunchKernelGGL(KERNEL<32>, grid, dim3(256), 0, s, __VA_ARGS__);                     \
+    else if (width == 25) hipLaunchKernelGGL(KERNEL<25>, grid, dim3(256), 0, s, __VA_ARGS__);                \
+    else if (width == 7) hipLaunchKernelGGL(KERNEL<7>, grid, dim3(256), 0, s, __VA_ARGS__);                  \
+    else hipLaunchKernelGGL(KERNEL<0>, grid, dim3(256), 0, s, __VA_ARGS__);                                  \
+  } while (0)
   if (gfwd) {
     ST_REQUIRE(packed, "fft filters: packed filters missing");
-    // rows of pad channels (c in [cin, cin_pitch)) are written as zeros by the kernel's `live` test
-    const dim3 grid(st::ceil_div(npo, 256), cin_pitch);
-    if (width == 32) hipLaunchKernelGGL(filters_dft_fwd_kernel<32>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
-    else if (width == 7) hipLaunchKernelGGL(filters_dft_fwd_kernel<7>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
-    else hipLaunchKernelGGL(filters_dft_fwd_kernel<0>, grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, npo, n, bins, tw, gfwd);
+    // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
+    const dim3 grid(st::ceil_div(npo, 256), half_of(cin_pitch));
+    ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd);
   }
   if (gbwd) {
     ST_REQUIRE(packed_t, "fft filters: flipped / transposed filters missing");
+    ST_REQUIRE(npad_of(cin) % 128 == 0, "fft filters: the input channels must pack to a multiple of 128 for back-prop");
     const dim3 grid(st::ceil_div(npi, 256), npo);
-    if (width == 32) hipLaunchKernelGGL(filters_dft_bwd_kernel<32>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
-    else if (width == 7) hipLaunchKernelGGL(filters_dft_bwd_kernel<7>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
-    else hipLaunchKernelGGL(filters_dft_bwd_kernel<0>, grid, dim3(256), 0, s, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
+    ST_FFT_WIDTH_DISPATCH(filters_dft_bwd_kernel, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
   }
   return st::check_launch("fft filters");
 }
 
-// floats of the input spectra sf / sft (each) and of the dz spectra zf
+// floats of the input spectra sf and of the dz spectra zf
 size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width) {
   if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
-  return (size_t)p.bins * p.rows_pad * 2 * x->c_pitch;
+  return (size_t)p.bins * p.rows_pad * 2 * half_of(x->c_pitch);
 }
 
 size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
@@ -434,38 +571,45 @@ size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
   if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
-  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)x->c_pitch, nb = 2 * (size_t)npad_of(x->channels);
+  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)half_of(x->c_pitch), nb = 2 * (size_t)npad_of(x->channels);
   const size_t yf = (size_t)p.bins * p.rows_pad * nf, xf = (size_t)p.bins * p.rows_pad * nb, qf = (size_t)p.bins * ka * nf;
   return (std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
 }
 
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
-                              const st_tensor3* y, const float* tables, float* sf, float* sft, void* workspace,
+                              const st_tensor3* y, const float* tables, float* sf, void* workspace,
                               size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && gfwd && sf && workspace && tables && width_ok(width), "conv fft fwd: bad argument");
   ST_REQUIRE(x->batch == y->batch && x->frames == y->frames && pad_left >= 0 && pad_left < width, "conv fft fwd: stride-1 SAME layers only");
   ST_REQUIRE(npad_of(y->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, y, width), "conv fft fwd: workspace / shape");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, y->frames, y->batch);
-  const int ka = 2 * x->c_pitch, npo = npad_of(y->channels), nf = 2 * npo;
+  const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
   float* yf = reinterpret_cast<float*>(workspace);
-  launch_dft(*x, p, tables + T_FS, -pad_left, x->c_pitch, sf, sft, s);
+  launch_dft(*x, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), sf, s);
   if (int e = st::gemm_nn_batched(sf, ka, (long)p.rows_pad * ka, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka,
                                   nf, p.bins, s))
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
-  hipLaunchKernelGGL(idft_mfma_kernel<1>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks * 2, 4))), dim3(256), 0, s, yf,
-                     tables + T_IY, p.blocks, p.rows, p.rows_pad, p.bins, npo, nchunks, out, bias, relu, (const float*)nullptr,
-                     0L, 0);
+  launch_idft<1>(yf, tables + T_IY, p, npo, nchunks, out, bias, relu, nullptr, 0L, 0, s);
   return st::check_launch("conv fft fwd");
 }
 
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tables && zf && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft dz spectra: bad argument");
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  launch_dft(*dz, p, tables + T_FZ, 0, npad_of(dz->channels), zf, nullptr, st::as_stream(stream));
+  launch_dft(*dz, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, st::as_stream(stream));
   return st::check_launch("conv fft dz spectra");
+}
+
+int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf, float* dbias, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && zf && dbias && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft bias grad: bad argument");
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const int np = npad_of(dz->channels);
+  hipLaunchKernelGGL(bias_from_spectra_kernel, dim3(st::ceil_div(np, 32)), dim3(256), 0, st::as_stream(stream), zf, p.rows, 2 * np,
+                     dz->channels, np, dbias);
+  return st::check_launch("conv fft bias grad");
 }
 
 int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
@@ -486,40 +630,28 @@ int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const 
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
-  hipLaunchKernelGGL(idft_mfma_kernel<3>, dim3(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks * 2, 4))), dim3(256), 0, s, xf,
-                     tables + T_IX, p.blocks, p.rows, p.rows_pad, p.bins, npi, nchunks, out, (const float*)nullptr, 0,
-                     act ? act->base + (long)act->halo * act->c_pitch : nullptr, act ? (long)act->t_pitch * act->c_pitch : 0L,
-                     act ? act->c_pitch : 0);
+  launch_idft<3>(xf, tables + T_IX, p, npi, nchunks, out, nullptr, 0, act ? act->base + (long)act->halo * act->c_pitch : nullptr,
+                 act ? (long)act->t_pitch * act->c_pitch : 0L, act ? act->c_pitch : 0, s);
   return st::check_launch("conv fft bwd_data");
 }
 
-int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* sft,
-                                     const float* zf, int width, const float* tables, float* dpacked, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && zf && dpacked && workspace && tables && width_ok(width), "conv fft bwd_filter: bad argument");
-  ST_REQUIRE(((2 * x->c_pitch) % 128 == 0) ? sf != nullptr : sft != nullptr,
-             "conv fft bwd_filter: needs sf (2 * c_pitch a multiple of 128) or the transposed spectra sft");
+int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* zf, int width,
+                                     const float* tables, float* dpacked, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && sf && zf && dpacked && workspace && tables && width_ok(width), "conv fft bwd_filter: bad argument");
   ST_REQUIRE(x->batch == dz->batch && x->frames == dz->frames, "conv fft bwd_filter: stride-1 layers only");
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, dz, width), "conv fft bwd_filter: workspace / shape");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
-  const int ka = 2 * x->c_pitch, npo = npad_of(dz->channels), nf = 2 * npo;
+  const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace);
-  // Q[bin] = Sf[bin]^T (2 cpi x rows_pad) * Zf[bin] (rows_pad x 2 npo): the reduction-major kernel of the W-tap filter
-  // gradient takes both spectra as they are; widths it cannot tile fall back to the transposed copy
-  if (ka % 128 == 0) {
-    if (int e = st::gemm_tn_batched(sf, ka, (long)p.rows_pad * ka, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf,
-                                    p.bins, s))
-      return e;
-  } else if (int e = st::gemm_nn_batched(sft, p.rows_pad, (long)ka * p.rows_pad, zf, (long)p.rows_pad * nf, qf, nf, (long)ka * nf,
-                                         ka, p.rows_pad, nf, p.bins, s)) {
+  // Q[bin] = Sf[bin]^T (2 half x rows_pad) * Zf[bin] (rows_pad x 2 npo): the reduction-major kernel of the W-tap filter
+  // gradient takes both spectra as they are
+  if (int e = st::gemm_tn_batched(sf, ka, (long)p.rows_pad * ka, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf,
+                                  p.bins, s))
     return e;
-  }
   const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
-  if (width == 32) hipLaunchKernelGGL(filters_idft_kernel<32>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
-  else if (width == 7) hipLaunchKernelGGL(filters_idft_kernel<7>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
-  else hipLaunchKernelGGL(filters_idft_kernel<0>, grid, dim3(256), 0, s, qf, width, x->channels, dz->channels, x->c_pitch, npo, p.n, p.bins, tw, dpacked);
+  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked);
   return st::check_launch("conv fft bwd_filter");
 }
 

@@ -146,6 +146,8 @@ class Wav2LetterEngine:
     # ~1e-6 of the tensor scale).  fft_conv=False / ST_FFT_CONV=0 keeps the W-tap kernels everywhere.
     self.fft_conv = (os.environ.get('ST_FFT_CONV', '1') != '0') if fft_conv is None else bool(fft_conv)
     self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '7'))
+    # the stride-2 first layer (48 taps over 80 mel channels) on its polyphase view: 25 taps over 160 channels
+    self.fft_first_layer = os.environ.get('ST_FFT_FIRST_LAYER', '1') != '0'
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -293,9 +295,14 @@ class Wav2LetterEngine:
     self.geo = geo
     for i, l in enumerate(self.layers):
       t_in, t_out, pl, pr = geo[i]
-      halo_r = max(pr, (t_out - 1) * l.stride + l.width - pl - t_in)
+      halo_l, halo_r = pl, max(pr, (t_out - 1) * l.stride + l.width - pl - t_in)
+      if l.stride == 2:
+        # a stride-2 layer may run on its polyphase view (frame pairs as channels, `_polyphase`): that view needs an
+        # even left halo and an even frame pitch
+        halo_l += halo_l & 1
+        halo_r += (halo_l + t_in + halo_r) & 1
       # X[0]'s pad channels are not written by any kernel: clear the whole view on re-use
-      self.X.append(self._tensor('X%d' % i, batch, t_in, l.cin, pl, halo_r, clear=(i == 0)))
+      self.X.append(self._tensor('X%d' % i, batch, t_in, l.cin, halo_l, halo_r, clear=(i == 0)))
       # gradient wrt this layer's pre-activation output; halo for its own back-prop-to-input conv
       self.dZ.append(self._tensor('dZ%d' % i, batch, t_out, l.cout, l.width - 1 - pl, pl))
     last = self.layers[-1]
@@ -325,10 +332,27 @@ class Wav2LetterEngine:
     self._shape = (batch, frames)
 
   # ---- frequency-domain layers (csrc/conv_fft.hip) ---------------------------------------------------
+  def _polyphase(self, i):
+    """A stride-2 layer as a stride-1 layer on the polyphase view of its input: x read as [B][T/2][2 * c_pitch] (frame
+    pairs as channels), y[t] = sum_w F[w] x[2t + w - pl] = sum_{j,p} F[2j + p - shift] X2[t + j - pl2][p] with
+    pl2 = ceil(pl / 2), shift = 2 pl2 - pl: width2 = ceil((W + shift) / 2) taps whose packed filters are the layer's
+    own rows moved down by `shift` channel blocks (zeros around them).  Returns (width2, pl2, shift) or None."""
+    l = self.layers[i]
+    if l.stride != 2:
+      return None
+    pl = self.geo[i][2]
+    pl2 = (pl + 1) // 2
+    shift = 2 * pl2 - pl
+    return (l.width + shift + 1) // 2, pl2, shift
+
   def _use_fft(self, i, batch, t_out):
     l = self.layers[i]
-    return (self.fft_conv and self.conv_mode in ('fp32', 'bf16x6') and i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and
-            l.n_pad % 128 == 0 and l.nt_pad % 128 == 0 and batch * t_out >= 2048)
+    if not (self.fft_conv and self.conv_mode in ('fp32', 'bf16x6') and l.n_pad % 128 == 0 and batch * t_out >= 2048):
+      return False
+    if l.stride == 2:        # first layer of the model (48 taps, stride 2): 25 polyphase taps over 2 x 80 channels
+      width2 = self._polyphase(i)[0]
+      return i == 0 and self.fft_first_layer and self.fft_min_width <= width2 <= 33
+    return i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and l.nt_pad % 128 == 0
 
   def _alloc_fft(self, batch):
     """Per frequency-domain layer: the transform tables and the filter spectra in both operand layouts (functions of
@@ -340,18 +364,32 @@ class Wav2LetterEngine:
       if i not in self._fft_layers:
         continue
       view = lambda name, numel: self._storage.view('fft%d_%s' % (i, name), numel)
+      f = dict(x=self.X[i].desc, width=l.width, pl=pl, cin=l.cin, cin_pitch=l.cin_pitch, shift=None)
+      if l.stride == 2:
+        width2, pl2, shift = self._polyphase(i)
+        x = self.X[i]
+        assert x.halo % 2 == 0 and x.t_pitch % 2 == 0
+        cp2 = 2 * x.c_pitch
+        f.update(x=Tensor3(x.buf.data_ptr(), batch, t_out, cp2, x.halo // 2, x.t_pitch // 2, cp2), width=width2, pl=pl2,
+                 cin=cp2, cin_pitch=cp2, shift=shift)
+        # the layer's packed filters between zero blocks, and the gradient in the same layout
+        rows = 2 * width2 * x.c_pitch * l.n_pad
+        f['packed2'], fresh_p = view('packed2', rows)
+        f['dpacked2'] = view('dpacked2', rows)[0]
+        if fresh_p:
+          f['packed2'].zero_()
+          self._gfwd_fresh = False
+      f['xref'] = ctypes.byref(f['x'])
       tables, fresh_tables = view('tables', lib.st_conv1d_fft_table_floats())
-      gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 0))
-      gbwd, fresh_b = view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1))
-      f = dict(tables=tables, gfwd=gfwd, gbwd=gbwd,
-               sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0],
-               # the transposed copy only where the filter-gradient kernel cannot tile the spectra as they are
-               sft=(view('sft', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width))[0]
-                    if (2 * l.cin_pitch) % 128 else None),
-               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width))[0],
-               ws=view('ws', lib.st_conv1d_fft_ws(self.X[i].ref, self.X[i + 1].ref, l.width) // 4 + 64)[0])
+      gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(f['width'], f['cin_pitch'], f['cin'], l.cout, 0))
+      gbwd, fresh_b = (view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1)) if i > 0
+                       else (None, False))
+      f.update(tables=tables, gfwd=gfwd, gbwd=gbwd,
+               sf=view('sf', lib.st_conv1d_fft_sf_floats(f['xref'], self.X[i + 1].ref, f['width']))[0],
+               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, f['width']))[0],
+               ws=view('ws', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0])
       if fresh_tables:
-        call('st_conv1d_fft_tables_f32', l.width, pl, self._ptr(tables), tables.numel(), self.stream_ptr)
+        call('st_conv1d_fft_tables_f32', f['width'], f['pl'], self._ptr(tables), tables.numel(), self.stream_ptr)
       if fresh_f:
         self._gfwd_fresh = False
       if fresh_b:
@@ -363,11 +401,28 @@ class Wav2LetterEngine:
     self._fft_prev = set(self.fft)
 
   def _refresh_fft_filters(self, forward):
+    """Filter spectra of every frequency-domain layer from the current weights, in layer order; after each forward
+    operand an event is recorded so that the forward pass waits for the layer it is about to run, not for all."""
+    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    if forward:
+      self._gfwd_ready = {}
     for i, f in self.fft.items():
       l = self.layers[i]
-      call('st_conv1d_fft_filters_f32', self._ptr(self._slice(self.params, i)[0]), self._ptr(self.packed_t[i]), l.width,
-           l.cin, l.cout, l.cin_pitch, l.cout_pitch, self._ptr(f['tables']),
-           self._ptr(f['gfwd']) if forward else None, None if forward else self._ptr(f['gbwd']), self.stream_ptr)
+      pf = self._slice(self.params, i)[0]
+      if forward and f['shift'] is not None:
+        cp = self.X[i].c_pitch
+        n = l.width * cp * l.n_pad
+        with torch.cuda.stream(stream):
+          f['packed2'][f['shift'] * cp * l.n_pad:f['shift'] * cp * l.n_pad + n].copy_(pf[:n], non_blocking=True)
+        pf = f['packed2']
+      if forward or i > 0:
+        call('st_conv1d_fft_filters_f32', self._ptr(pf), self._ptr(self.packed_t[i]) if i > 0 else None, f['width'],
+             f['cin'], l.cout, f['cin_pitch'], l.cout_pitch, self._ptr(f['tables']),
+             self._ptr(f['gfwd']) if forward else None, None if forward else self._ptr(f['gbwd']), self.stream_ptr)
+      if forward:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._gfwd_ready[i] = ev
     if forward:
       self._gfwd_fresh = True
     else:
@@ -376,6 +431,23 @@ class Wav2LetterEngine:
   def _refresh_gfwd(self):
     if self.fft and self._shape is not None:
       self._refresh_fft_filters(True)
+
+  def _wait_gfwd(self, i=None):
+    """The compute stream waits for the forward filter spectra of layer i (None: of every layer) if they were rebuilt on
+    the side stream after the update.  The side stream works bottom layer first: the first three frequency-domain layers
+    wait for their own spectra, the fourth for all that remain (by then the side stream is through, and every wait
+    costs the compute stream a few microseconds)."""
+    ready = getattr(self, '_gfwd_ready', None)
+    if not ready:
+      return
+    order = sorted(self.fft)
+    if i is not None and i in order and order.index(i) >= 3:
+      i = None
+    keys = [k for k in ready if i is None or k <= i]
+    if keys:
+      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(ready[max(keys)])
+      for k in keys:
+        del ready[k]
 
   # ---- bf16 activations (config 4) ------------------------------------------------------------------
   def _alloc_bf16(self):
@@ -572,7 +644,8 @@ class Wav2LetterEngine:
       slot[1].record(stream)
     return dev
 
-  def forward(self):
+  def forward(self, training=False):
+    """The eleven layers (``training`` is accepted for callers that distinguish the two uses; the pass is the same)."""
     if self.conv_mode == 'bf16':
       return self._forward_bf16()
     s = self.stream_ptr
@@ -591,12 +664,13 @@ class Wav2LetterEngine:
              l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref, yp, s)
       elif i in self.fft and self.fft_conv:
         f = self.fft[i]
-        self._join_side_stream()                         # the filter spectra may still be on their way
         if not self._gfwd_fresh:
+          self._join_side_stream()
           self._refresh_fft_filters(True)
-        call('st_conv1d_nwc_fwd_fft_f32', self.X[i].ref, self._ptr(f['gfwd']), self._ptr(pb), l.width, self.geo[i][2],
-             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']),
-             self._ptr(f['sft']) if f['sft'] is not None else None, self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        self._wait_gfwd(i)                               # the filter spectra may still be on their way (side stream)
+        call('st_conv1d_nwc_fwd_fft_f32', f['xref'], self._ptr(f['gfwd']), self._ptr(pb), f['width'], f['pl'],
+             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), self._ptr(f['ws']),
+             f['ws'].numel() * 4, s)
       else:
         call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
@@ -617,6 +691,7 @@ class Wav2LetterEngine:
     self._join_side_stream()
     if self.fft and self.fft_conv and not self._gfwd_fresh:
       self._refresh_fft_filters(True)
+    self._wait_gfwd()                              # no waits on outside events inside a capture
     key = (self._shape, self._storage.generation)
     graph = self._graphs.get(key)
     if graph is None:
@@ -703,31 +778,65 @@ class Wav2LetterEngine:
     call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
 
   def _refresh_backward_operands(self):
-    if not self._packed_t_fresh:
-      self.refresh_packed_t()
-    if self.fft and self.fft_conv and not self._gbwd_fresh:
-      self._refresh_fft_filters(False)
+    """The filter operands of back-prop to the input from the current weights -- the flipped / transposed copy of every
+    layer and, for a frequency-domain layer, its spectra in the back-prop layout -- top layer first, the order
+    back-prop consumes them in; an event after each layer lets the compute stream wait for what it is about to use
+    only (the 32-tap layer's 0.15 ms are needed 2 ms into the backward pass)."""
+    s = self.stream_ptr
+    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    flips, spectra = not self._packed_t_fresh, bool(self.fft) and self.fft_conv and not self._gbwd_fresh
+    self._bwd_ready = {}
+    for i in reversed(range(1, len(self.layers))):
+      l = self.layers[i]
+      if flips:
+        call('st_filters_flip_transpose_f32', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
+             l.cout_pitch, self._ptr(self.packed_t[i]), s)
+      if spectra and i in self.fft:
+        f = self.fft[i]
+        call('st_conv1d_fft_filters_f32', None, self._ptr(self.packed_t[i]), f['width'], f['cin'], l.cout, f['cin_pitch'],
+             l.cout_pitch, self._ptr(f['tables']), None, self._ptr(f['gbwd']), s)
+      ev = torch.cuda.Event()
+      ev.record(stream)
+      self._bwd_ready[i] = ev
+    if flips:
+      self._packed_t_fresh = True
+      self._wtplanes_fresh = False
+    if spectra:
+      self._gbwd_fresh = True
 
   def refresh_packed_t(self):
-    s = self.stream_ptr
-    for i, l in enumerate(self.layers):
-      if i == 0:
-        continue
-      pf, _ = self._slice(self.params, i)
-      call('st_filters_flip_transpose_f32', self._ptr(pf), l.width, l.cin, l.cout, l.cin_pitch, l.cout_pitch,
-           self._ptr(self.packed_t[i]), s)
-    self._packed_t_fresh = True
-    self._wtplanes_fresh = False
+    if not self._packed_t_fresh:
+      gb, self._gbwd_fresh = self._gbwd_fresh, True          # the flips only
+      try:
+        self._refresh_backward_operands()
+      finally:
+        self._gbwd_fresh = gb
+
+  def _wait_bwd_operands(self, i=None):
+    """The compute stream waits for the back-prop operands of layer i (None: of every layer) if they were rebuilt on the
+    side stream.  The side stream works top layer first, so a lower layer's event covers the ones above it."""
+    ready = getattr(self, '_bwd_ready', None)
+    if not ready:
+      return
+    keys = [k for k in ready if i is None or k >= i]
+    if keys:
+      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(ready[min(keys)])
+      for k in keys:
+        del ready[k]
 
   def backward(self, on_layer_done=None):
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
     called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce)."""
     s = self.stream_ptr
-    self._join_side_stream()
     if self.conv_mode == 'bf16':
+      self._join_side_stream()
       return self._backward_bf16(on_layer_done)
-    if not self._packed_t_fresh:
-      self.refresh_packed_t()
+    if not self._packed_t_fresh or (self.fft and self.fft_conv and not self._gbwd_fresh):
+      self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad)
+    if self.conv_mode == 'bf16x6':
+      self._wait_bwd_operands()                   # the split planes are derived from all transposed copies at once
+    # waits per layer; after the two layers on top one wait covers everything below (by then the side stream is through)
+    wait_all_below = len(self.layers) - 3
     bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
@@ -746,12 +855,17 @@ class Wav2LetterEngine:
       elif i in self.fft and self.fft_conv:
         f = self.fft[i]
         # the spectra of dz serve the filter gradient here and back-prop to the input below
-        call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, l.width, self._ptr(f['tables']), self._ptr(f['zf']), s)
-        call('st_conv1d_nwc_bwd_filter_fft_f32', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sf']),
-             self._ptr(f['sft']) if f['sft'] is not None else None, self._ptr(f['zf']), l.width, self._ptr(f['tables']),
-             self._ptr(gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
-        if need_bias:
-          call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+        call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, f['width'], self._ptr(f['tables']), self._ptr(f['zf']), s)
+        polyphase = f['shift'] is not None       # the gradient comes out in the shifted layout of the polyphase taps
+        call('st_conv1d_nwc_bwd_filter_fft_f32', f['xref'], self.dZ[i].ref, self._ptr(f['sf']), self._ptr(f['zf']), f['width'],
+             self._ptr(f['tables']), self._ptr(f['dpacked2'] if polyphase else gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        if polyphase:
+          cp = self.X[i].c_pitch
+          n, o = l.width * cp * l.n_pad, f['shift'] * cp * l.n_pad
+          with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream(self.device)):
+            gf[:n].copy_(f['dpacked2'][o:o + n], non_blocking=True)
+        if need_bias:      # bin 0 of the spectra is the sum over the frames
+          call('st_conv1d_fft_bias_grad_f32', self.dZ[i].ref, f['width'], self._ptr(f['zf']), self._ptr(gb), s)
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
@@ -768,8 +882,7 @@ class Wav2LetterEngine:
              self.geo[i][2], act, self.dZ[i - 1].ref, dxp, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i > 0 and i in self.fft and self.fft_conv:
         f = self.fft[i]
-        if not self._gbwd_fresh:
-          self._refresh_fft_filters(False)
+        self._wait_bwd_operands(i if i > wait_all_below else None)
         act = self.X[i].ref if self.layers[i - 1].relu else None
         call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gbwd']), l.width,
              self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
@@ -777,6 +890,7 @@ class Wav2LetterEngine:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1
         act = self.X[i].ref if self.layers[i - 1].relu else None
+        self._wait_bwd_operands(i if i > wait_all_below else None)
         call('st_conv1d_nwc_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
              act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
              self.wgrad_ws.numel() * 4, s)

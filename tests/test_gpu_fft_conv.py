@@ -28,13 +28,13 @@ def dev_tensor(dev, batch, frames, channels, halo_l, halo_r, data=None):
   return t
 
 
-@pytest.mark.parametrize('B,T,cin,cout,relu', [(3, 77, 130, 200, True), (2, 200, 250, 300, False), (5, 63, 250, 129, True)])
-def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
+@pytest.mark.parametrize('W,B,T,cin,cout,relu', [(32, 3, 77, 130, 200, True), (32, 2, 200, 250, 300, False), (32, 5, 63, 250, 129, True),
+                                                 (7, 4, 150, 250, 250, True), (7, 2, 64, 130, 129, False), (12, 3, 100, 200, 250, True)])
+def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
   from speecht_amd import _lib
   from speecht_amd._lib import call
   from speecht_amd.engine import channel_pitch
   lib = _lib.load()
-  W = 32
   rng = np.random.default_rng(B * 100 + T)
   x = rng.standard_normal((B, T, cin))
   F = rng.standard_normal((W, cin, cout)) / np.sqrt(W * cin)
@@ -72,11 +72,10 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
   gbwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cin, cout, 1), device=dev)
   call('st_conv1d_fft_filters_f32', P(packed), P(packed_t), W, cin, cout, cpi, cpo, P(tables), P(gfwd), P(gbwd), None)
   sf = torch.empty(lib.st_conv1d_fft_sf_floats(xt.ref, yt.ref, W), device=dev)
-  sft = torch.empty_like(sf)
   zf = torch.empty(lib.st_conv1d_fft_zf_floats(dzt.ref, W), device=dev)
   ws = torch.empty(lib.st_conv1d_fft_ws(xt.ref, yt.ref, W) // 4 + 64, device=dev)
 
-  call('st_conv1d_nwc_fwd_fft_f32', xt.ref, P(gfwd), P(bias_d), W, pl, int(relu), yt.ref, P(tables), P(sf), P(sft), P(ws),
+  call('st_conv1d_nwc_fwd_fft_f32', xt.ref, P(gfwd), P(bias_d), W, pl, int(relu), yt.ref, P(tables), P(sf), P(ws),
        ws.numel() * 4, None)
   y = yt.interior().cpu().numpy()
   assert np.max(np.abs(y - y_ref)) < 2e-5 * np.max(np.abs(y_ref))
@@ -91,7 +90,7 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
 
   call('st_packed_dims', W, cpi, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
   dpacked = torch.full((kp.value * npad.value,), 7.0, device=dev)
-  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sf), P(sft), P(zf), W, P(tables), P(dpacked), P(ws), ws.numel() * 4, None)
+  call('st_conv1d_nwc_bwd_filter_fft_f32', xt.ref, dzt.ref, P(sf), P(zf), W, P(tables), P(dpacked), P(ws), ws.numel() * 4, None)
   dFd = torch.empty(W * cin * cout, device=dev)
   call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cpi, P(dFd), None)
   dF = dFd.view(W, cin, cout).cpu().numpy()
@@ -102,6 +101,75 @@ def test_fft_conv_matches_oracle(dev, B, T, cin, cout, relu):
   V = G[:W * cpi].view(W, cpi, npad.value)
   if cpi > cin:
     assert float(V[:, cin:, :].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,T,cin,cout', [(4, 1001, 80, 250), (3, 400, 128, 250), (2, 333, 40, 130)])
+def test_stride2_layer_on_its_polyphase_view(dev, B, T, cin, cout):
+  """The model's first layer (48 taps, stride 2; speech_model.py:279) through the stride-1 entry points: the input read
+  as [B][T/2][2 * c_pitch] (frame pairs as channels), y[t] = sum_w F[w] x[2t + w - pl] = sum_{j,p} F[2j + p - shift]
+  X2[t + j - pl2][p], i.e. ceil((W + shift) / 2) taps whose packed filters are the layer's own rows moved down by
+  `shift` channel blocks.  Forward and filter gradient against the oracle's strided convolution."""
+  from speecht_amd import _lib
+  from speecht_amd._lib import call, Tensor3
+  from speecht_amd.engine import channel_pitch
+  lib = _lib.load()
+  W, relu = 48, True
+  rng = np.random.default_rng(B + T)
+  x = rng.standard_normal((B, T, cin))
+  F = rng.standard_normal((W, cin, cout)) / np.sqrt(W * cin)
+  bias = rng.standard_normal(cout) * 0.1
+  y_ref = O.conv1d_same_fwd(x, F, bias, 2, relu)
+  dy = rng.standard_normal(y_ref.shape)
+  _, dF_ref, _ = O.conv1d_same_bwd(x, F, y_ref, dy, 2, relu)
+  dz = dy * (y_ref > 0)
+  t_out, pl, pr = O.same_padding(T, W, 2)
+  pl2 = (pl + 1) // 2
+  shift = 2 * pl2 - pl
+  W2 = (W + shift + 1) // 2
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  cp, cpo = channel_pitch(cin), channel_pitch(cout)
+  halo_l = pl + (pl & 1)
+  halo_r = pr + ((halo_l + T + pr) & 1)
+  xt = dev_tensor(dev, B, T, cin, halo_l, halo_r, x)
+  x2 = Tensor3(xt.buf.data_ptr(), B, t_out, 2 * cp, xt.halo // 2, xt.t_pitch // 2, 2 * cp)
+  x2ref = ctypes.byref(x2)
+  yt = dev_tensor(dev, B, t_out, cout, 3, 2)
+  dzt = dev_tensor(dev, B, t_out, cout, 3, 2, dz)
+  kv, kp, npad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  call('st_packed_dims', W, cp, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+  packed = torch.zeros(kp.value * npad.value, device=dev)
+  Fd = torch.as_tensor(F, dtype=torch.float32).to(dev).contiguous()
+  call('st_pack_filters_f32', P(Fd), W, cin, cout, cp, P(packed), None)
+  n, o = W * cp * npad.value, shift * cp * npad.value
+  packed2 = torch.zeros(2 * W2 * cp * npad.value, device=dev)
+  packed2[o:o + n] = packed[:n]
+  bias_d = torch.zeros(2048, device=dev)
+  bias_d[:cout] = torch.as_tensor(bias, dtype=torch.float32)
+  tables = torch.zeros(lib.st_conv1d_fft_table_floats(), device=dev)
+  call('st_conv1d_fft_tables_f32', W2, pl2, P(tables), tables.numel(), None)
+  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W2, 2 * cp, 2 * cp, cout, 0), device=dev)
+  call('st_conv1d_fft_filters_f32', P(packed2), None, W2, 2 * cp, cout, 2 * cp, cpo, P(tables), P(gfwd), None, None)
+  sf = torch.empty(lib.st_conv1d_fft_sf_floats(x2ref, yt.ref, W2), device=dev)
+  zf = torch.empty(lib.st_conv1d_fft_zf_floats(dzt.ref, W2), device=dev)
+  ws = torch.empty(lib.st_conv1d_fft_ws(x2ref, yt.ref, W2) // 4 + 64, device=dev)
+  call('st_conv1d_nwc_fwd_fft_f32', x2ref, P(gfwd), P(bias_d), W2, pl2, int(relu), yt.ref, P(tables), P(sf), P(ws),
+       ws.numel() * 4, None)
+  y = yt.interior().cpu().numpy()
+  assert np.max(np.abs(y - y_ref)) < 2e-5 * np.max(np.abs(y_ref))
+  call('st_conv1d_fft_dz_spectra_f32', dzt.ref, W2, P(tables), P(zf), None)
+  dpacked2 = torch.full((2 * W2 * cp * npad.value,), 7.0, device=dev)
+  call('st_conv1d_nwc_bwd_filter_fft_f32', x2ref, dzt.ref, P(sf), P(zf), W2, P(tables), P(dpacked2), P(ws), ws.numel() * 4, None)
+  dpacked = torch.zeros(kp.value * npad.value, device=dev)
+  dpacked[:n] = dpacked2[o:o + n]
+  dFd = torch.empty(W * cin * cout, device=dev)
+  call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cp, P(dFd), None)
+  dF = dFd.view(W, cin, cout).cpu().numpy()
+  assert np.max(np.abs(dF - dF_ref)) < 2e-5 * np.max(np.abs(dF_ref))
+  # the pad channels of the packed gradient are exactly zero
+  G = dpacked[:n].view(W, cp, npad.value)
+  assert float(G[:, :, cout:].abs().max()) == 0.0
+  if cp > cin:
+    assert float(G[:, cin:, :].abs().max()) == 0.0
 
 
 def test_frequency_domain_layer_survives_shape_switching_and_weight_updates(dev):

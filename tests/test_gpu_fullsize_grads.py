@@ -129,6 +129,10 @@ def test_fullsize_fp32_frequency_domain_l8_gradients_match_float64_reference(cas
   assert sum(1 for l in trace if l.startswith('gemm_nn<') and ' batched bins=36 ' in l) == 14, text
   assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=36 ' in l) == 7, text
   assert not any('Kp=8192' in l or 'Kp=64512' in l or 'Kp=1792' in l for l in trace if 'batched' not in l), text   # no W-tap launch of L1..L8
+  # the stride-2 first layer on its polyphase view (25 taps over 2 x 80 channels, 45 bins): forward + filter gradient
+  assert sum(1 for l in trace if l.startswith('gemm_nn<') and ' batched bins=45 ' in l) == 1, text
+  assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=45 ' in l) == 1, text
+  assert not any('Kp=3840' in l for l in trace if 'batched' not in l), text
   compare(eng, case['ref'], case)
 
 

@@ -414,9 +414,17 @@ def main():
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times for the median
   t0 = time.perf_counter()
   marks[0].record()
+  host_ms = []
+  # the host keeps at most two steps in flight (measured: one leaves the GPU waiting for launches between steps, +0.13 ms;
+  # an unbounded burst after the sync runs the first three steps 0.3-2 ms slow each)
+  ahead = int(os.environ.get('ST_BENCH_AHEAD', '2'))
   for k in range(args.steps):
+    h0 = time.perf_counter()
+    if ahead and k >= ahead:
+      marks[k + 1 - ahead].synchronize()
     train_step(eng, feed, reducer, lr, global_batch)
     marks[k + 1].record()
+    host_ms.append((time.perf_counter() - h0) * 1e3)
   sync()
   elapsed = time.perf_counter() - t0
   step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
@@ -471,6 +479,10 @@ def main():
         'value': round(global_batch / (elapsed / args.steps), 2), 'unit': 'utterances/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'ms_per_step_median': round(median_ms, 3),
+        'ms_per_step_quantiles': [round(step_ms[int(q * (len(step_ms) - 1))], 3) for q in (0.0, 0.25, 0.5, 0.75, 1.0)],
+        'ms_each_step': [round(marks[k].elapsed_time(marks[k + 1]), 3) for k in range(args.steps)],
+        'host_ms_each_step': [round(v, 2) for v in host_ms],
+        'host_enqueue_ms_per_step': [round(float(np.median(host_ms)), 3), round(float(np.max(host_ms)), 3)],   # median, max (the host runs ahead of the GPU)
         'step_includes': 'pinned H2D of the feature batch (copy stream, double-buffered) + label upload + forward + '
                          'CTC loss/grad + back-prop' + (' + gradient all-reduce' if reducer else '') + ' + clip + Adam',
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x6': 'f32 (bf16x6 split)', 'bf16': 'bf16 activations, f32 accumulate/CTC/Adam'}[eng.conv_mode],

@@ -428,8 +428,19 @@ __global__ __launch_bounds__(256) void bias_from_spectra_kernel(const float* __r
   const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < channels)
-    for (int k = r; k < rows; k += 8) s += zf[(long)k * ld + c];
+  if (c < channels) {
+    // four independent partial sums: the loads of a pass are in flight together (one dependent chain would expose
+    // a cache latency per row)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int k = r;
+    for (; k + 24 < rows; k += 32) {
+      const float a = zf[(long)k * ld + c], b = zf[(long)(k + 8) * ld + c], d = zf[(long)(k + 16) * ld + c],
+                  e = zf[(long)(k + 24) * ld + c];
+      p0 += a; p1 += b; p2 += d; p3 += e;
+    }
+    for (; k < rows; k += 8) p0 += zf[(long)k * ld + c];
+    s = (p0 + p1) + (p2 + p3);
+  }
   red[r][cl] = s;
   __syncthreads();
   if (r == 0 && c < np) {

@@ -148,6 +148,7 @@ class Wav2LetterEngine:
     self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '7'))
     # the stride-2 first layer (48 taps over 80 mel channels) on its polyphase view: 25 taps over 160 channels
     self.fft_first_layer = os.environ.get('ST_FFT_FIRST_LAYER', '1') != '0'
+    self.side_filter_gradient = os.environ.get('ST_WGRAD_SIDE', '1') != '0'
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
@@ -388,6 +389,8 @@ class Wav2LetterEngine:
                sf=view('sf', lib.st_conv1d_fft_sf_floats(f['xref'], self.X[i + 1].ref, f['width']))[0],
                zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, f['width']))[0],
                ws=view('ws', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0])
+      if self.side_filter_gradient and i > 0 and l.cout <= 512:      # (the wide 32-tap layer: measured, no gain)
+        f['ws2'] = view('ws2', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0]
       if fresh_tables:
         call('st_conv1d_fft_tables_f32', f['width'], f['pl'], self._ptr(tables), tables.numel(), self.stream_ptr)
       if fresh_f:
@@ -837,6 +840,7 @@ class Wav2LetterEngine:
       self._wait_bwd_operands()                   # the split planes are derived from all transposed copies at once
     # waits per layer; after the two layers on top one wait covers everything below (by then the side stream is through)
     wait_all_below = len(self.layers) - 3
+    side_wgrad, deferred = False, None     # a filter gradient is in flight on the side stream; its layer's hook is due
     bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
@@ -857,19 +861,31 @@ class Wav2LetterEngine:
         # the spectra of dz serve the filter gradient here and back-prop to the input below
         call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, f['width'], self._ptr(f['tables']), self._ptr(f['zf']), s)
         polyphase = f['shift'] is not None       # the gradient comes out in the shifted layout of the polyphase taps
-        call('st_conv1d_nwc_bwd_filter_fft_f32', f['xref'], self.dZ[i].ref, self._ptr(f['sf']), self._ptr(f['zf']), f['width'],
-             self._ptr(f['tables']), self._ptr(f['dpacked2'] if polyphase else gf), self._ptr(f['ws']), f['ws'].numel() * 4, s)
-        if polyphase:
-          cp = self.X[i].c_pitch
-          n, o = l.width * cp * l.n_pad, f['shift'] * cp * l.n_pad
-          with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream(self.device)):
-            gf[:n].copy_(f['dpacked2'][o:o + n], non_blocking=True)
-        if need_bias:      # bin 0 of the spectra is the sum over the frames
-          call('st_conv1d_fft_bias_grad_f32', self.dZ[i].ref, f['width'], self._ptr(f['zf']), self._ptr(gb), s)
+
+        def filter_gradient(f=f, l=l, i=i, gf=gf, gb=gb, need_bias=need_bias, polyphase=polyphase, ws=f.get('ws2', f['ws'])):
+          call('st_conv1d_nwc_bwd_filter_fft_f32', f['xref'], self.dZ[i].ref, self._ptr(f['sf']), self._ptr(f['zf']), f['width'],
+               self._ptr(f['tables']), self._ptr(f['dpacked2'] if polyphase else gf), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+          if polyphase:
+            cp = self.X[i].c_pitch
+            n, o = l.width * cp * l.n_pad, f['shift'] * cp * l.n_pad
+            with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream(self.device)):
+              gf[:n].copy_(f['dpacked2'][o:o + n], non_blocking=True)
+          if need_bias:      # bin 0 of the spectra is the sum over the frames
+            call('st_conv1d_fft_bias_grad_f32', self.dZ[i].ref, f['width'], self._ptr(f['zf']), self._ptr(gb), self.stream_ptr)
+        if 'ws2' in f:
+          # The filter gradient (lag products, inverse transform of the filters, bias sum) and back-prop to the input
+          # (products, inverse transform) both hang off the spectra of dz and are independent: on two streams.  The
+          # narrow layers' products (36 bins x 16 tiles) leave a quarter of the CU slots of their last round empty --
+          # side by side they fill each other's gaps -- and the HBM-bound transforms of one chain run under the
+          # matrix-pipe-bound products of the other (measured: 7.84 -> 7.43 ms per step).
+          self._on_side_stream(filter_gradient)
+          side_wgrad, deferred = True, i
+        else:
+          filter_gradient()
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
-      if on_layer_done is not None:
+      if on_layer_done is not None and deferred != i:
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):
         act = self.X[i].ref if self.layers[i - 1].relu else None
@@ -895,6 +911,16 @@ class Wav2LetterEngine:
              act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
              self.wgrad_ws.numel() * 4, s)
         bias_from_above = True
+      if deferred == i and on_layer_done is not None:
+        # the gradient of this layer is complete when the side stream is: hand it to the all-reduce only now, with
+        # back-prop to the input already enqueued beside it
+        self._join_side_stream()
+        side_wgrad = False
+        on_layer_done(i)
+      if deferred == i:
+        deferred = None
+    if side_wgrad:
+      self._join_side_stream()
 
   def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
     """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""

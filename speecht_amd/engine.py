@@ -389,7 +389,9 @@ class Wav2LetterEngine:
                sf=view('sf', lib.st_conv1d_fft_sf_floats(f['xref'], self.X[i + 1].ref, f['width']))[0],
                zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, f['width']))[0],
                ws=view('ws', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0])
-      if self.side_filter_gradient and i > 0 and l.cout <= 512:      # (the wide 32-tap layer: measured, no gain)
+      # (the wide 32-tap layer stays on one stream: its chain side by side, or only its HBM-bound inverse transform of the
+      # lag products beside back-prop's products, both measured slower: 7.37 -> 7.43 ms)
+      if self.side_filter_gradient and i > 0 and l.cout <= 512:
         f['ws2'] = view('ws2', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0]
       if fresh_tables:
         call('st_conv1d_fft_tables_f32', f['width'], f['pl'], self._ptr(tables), tables.numel(), self.stream_ptr)

@@ -500,7 +500,7 @@ def main():
         'per_rank_ms_per_step': [round(v, 3) for v in rank_ms], 'comm': comm,
         'step_tflops_algorithmic': round(step_gflop / ms, 2),
         'step_tflops_note': ('W-tap FLOPs of the reference formulation (SURVEY 8(d): 71.4 GFLOP per utterance) / step time; '
-                             'the 32-tap layer runs in the frequency domain with ~10x fewer multiplications, so this is an '
+                             'nine of the eleven layers run in the frequency domain with 3-10x fewer multiplications, so this is an '
                              'equivalent rate, not a hardware rate (the hardware rate is roofline.achieved)')
                             if (eng.fft and eng.fft_conv) else None,
     }

@@ -1,5 +1,6 @@
-// Frequency-domain convolution for long, wide filters (the model's L8: 32 taps, 250 -> 2000 channels, 66 % of the
-// MACs of the step; speech_model.py:285, tf.nn.conv1d 'SAME' + bias + relu and its gradients).
+// Frequency-domain convolution (speech_model.py:279-285, tf.nn.conv1d 'SAME' + bias + relu and its gradients): the
+// model's 32-tap 250 -> 2000 layer (66 % of the MACs of the step), its seven 7-tap layers and -- on its polyphase view,
+// see include/speecht_hip.h -- the stride-2 48-tap first layer.
 //
 // Time is cut into blocks of V = 64 output frames; a block's receptive window has N = V + W - 1 frames (95 for 32
 // taps).  With the length-N DFT along time (real input: bins k = 0 .. N/2), per bin and per (row = utterance x block):
@@ -7,14 +8,16 @@
 //     to input   X[k] = Z[k] . G[k]             Z = DFT of dz[jV + t'], t' < V, zero padded      (overlap-add: frame
 //                                               jV + t' sums block j at m = t' + pad_left and its two neighbours)
 //     filters    Q[k] = sum_rows S[k]^T conj(Z[k]),  lags w < W
+//     bias       sum_rows Z[0]                  (bin 0 is the plain sum of the block's frames)
 // (G = DFT of the zero-padded filter): one complex [rows x Cin] x [Cin x Cout] product per bin instead of W taps per
-// frame -- 48 bins x 8 flops per 64 frames against 64 flops per frame, a 10x cut of the multiplications.
-// The complex products run as REAL GEMMs on the exact-fp32 MFMA convolution kernel (st::gemm_nn_batched, one bin per
-// XCD at a time) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]].  The transforms are dense DFTs on the
-// same matrix instruction (v_mfma_f32_32x32x2_f32): a wavefront owns 32 channels of one row, keeps the 96 x 96
-// (forward) or 64 x 96 (inverse) DFT matrix in registers as MFMA A fragments, loads the frames straight from the
-// NWC tensor as B fragments (128-byte runs per frame) and writes 128-byte runs -- no LDS, no barriers; the inverse
-// carries the bias / ReLU / mask epilogue.  They are bound by the 200 MB of spectra they move, not by arithmetic.
+// frame -- for 32 taps 48 bins x 8 flops per 64 frames against 64 flops per frame, a 10x cut of the multiplications.
+// The complex products run as REAL GEMMs on the exact-fp32 MFMA convolution kernels (st::gemm_nn_batched, one bin per
+// XCD at a time; st::gemm_tn_batched for the lag products) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]].
+// The transforms are dense DFTs on the same matrix instruction (v_mfma_f32_32x32x2_f32): a wavefront owns 32 channels
+// of one row, reads the 96 x 96 (forward) or 64 x 96 (inverse) DFT matrix from LDS as MFMA A fragments, loads the
+// frames straight from the NWC tensor as B fragments (128-byte runs per frame) in stages that stay one ahead of the
+// MFMAs, and writes 128-byte runs; the inverse carries the bias / ReLU / mask epilogue.  The wide layer's transforms
+// are bound by the 330 MB they move (3.5 TB/s), the narrow ones by latency (35 MB in 15-18 us).
 // Accuracy: fp32 throughout, exact products, N-term sums: ~1e-6 of the tensor scale (tests/test_gpu_fft_conv.py).
 #include <algorithm>
 

@@ -467,6 +467,11 @@ class Wav2LetterEngine:
     ws = max([ws] + [lib.st_conv1d_fwd_bf16_ws(self.X[i].ref, self.X[i + 1].ref, l.width)
                      for i, l in enumerate(self.layers)])
     self.wgrad_ws_b, _ = self._storage.view('wgrad_ws_b', ws // 4 + 64)
+    # the narrow layers' filter gradients run beside back-prop to the input on the side stream: their own scratch
+    self._side_wgrad_bf16 = [i for i, l in enumerate(self.layers) if self.side_filter_gradient and i > 0 and l.cout <= 512 and l.cin <= 512]
+    ws2 = max([0] + [lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, self.layers[i].width, self.layers[i].stride,
+                                                      self.geo[i][2]) for i in self._side_wgrad_bf16])
+    self.wgrad_ws_b2 = self._storage.view('wgrad_ws_b2', ws2 // 4 + 64)[0] if ws2 else None
     if not hasattr(self, 'Wb'):
       z = lambda n: torch.zeros(n, dtype=torch.bfloat16, device=self.device)
       self.Wb = [z(l.k_pad * l.n_pad) for l in self.layers]
@@ -487,6 +492,7 @@ class Wav2LetterEngine:
 
   def _forward_bf16(self):
     s, L = self.stream_ptr, len(self.layers)
+    self._join_side_stream()                       # the bf16 filter copies are rebuilt on the side stream after the update
     if not self._wplanes_fresh:
       self._refresh_bf16_filters(False)
     call('st_cast_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xb[0]), s)
@@ -502,19 +508,33 @@ class Wav2LetterEngine:
     if not self._wtplanes_fresh:
       self._refresh_bf16_filters(True)
     call('st_cast_bf16', self._ptr(self.dZ[L - 1].buf), self.dZ[L - 1].buf.numel(), self._ptr(self.dZb[L - 1]), s)
+    side = False
     for i in reversed(range(L)):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
-      call('st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]),
-           l.width, l.stride, self.geo[i][2], self._ptr(gf), self._ptr(gb), self._ptr(self.wgrad_ws_b),
-           self.wgrad_ws_b.numel() * 4, s)
-      if on_layer_done is not None:
-        on_layer_done(i)
+      beside = i in self._side_wgrad_bf16      # this layer's filter gradient runs beside its back-prop to the input
+
+      def filter_gradient(i=i, l=l, gf=gf, gb=gb, ws=self.wgrad_ws_b2 if beside else self.wgrad_ws_b):
+        call('st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]),
+             l.width, l.stride, self.geo[i][2], self._ptr(gf), self._ptr(gb), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+      if beside:
+        self._on_side_stream(filter_gradient)
+        side = True
+      else:
+        filter_gradient()
+        if on_layer_done is not None:
+          on_layer_done(i)
       if i > 0:
         relu_in = self.layers[i - 1].relu
         call('st_conv1d_nwc_bwd_data_bf16', self.dZ[i].ref, self._ptr(self.dZb[i]), self._ptr(self.WTb[i]), l.width,
              self.geo[i][2], self.X[i].ref if relu_in else None, self._ptr(self.Xb[i]) if relu_in else None,
              self.dZ[i - 1].ref, self._ptr(self.dZb[i - 1]), self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4, s)
+      if beside and on_layer_done is not None:
+        self._join_side_stream()
+        side = False
+        on_layer_done(i)
+    if side:
+      self._join_side_stream()
 
   # ---- bf16x6 (experimental) ------------------------------------------------------------------
   def _in_fft(self, i):
@@ -937,9 +957,10 @@ class Wav2LetterEngine:
     self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
     self.mark_weights_changed()
     if self.fft:
-      # the forward filter spectra of the frequency-domain layers, on the side stream: they are first needed eight
-      # layers into the next forward pass
+      # the forward filter spectra of the frequency-domain layers, on the side stream, bottom layer first
       self._on_side_stream(self._refresh_gfwd)
+    elif self.conv_mode == 'bf16' and hasattr(self, 'Wb'):
+      self._on_side_stream(lambda: self._refresh_bf16_filters(False))   # the bf16 copies the next forward pass reads
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

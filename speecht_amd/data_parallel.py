@@ -37,7 +37,13 @@ def default_buckets(layer_sizes, layer_offsets):
   if big + 1 < n:
     groups.append((big + 1, n - 1))
   groups.append((big, big))
-  if big > 0:
+  if big >= 4:
+    # the layers below the big one finish last: the exchange of the final bucket is the part of the communication that
+    # no kernel hides, so they go in two halves and only the lower one is left over at the end of back-prop
+    mid = big // 2
+    groups.append((mid, big - 1))
+    groups.append((0, mid - 1))
+  elif big > 0:
     groups.append((0, big - 1))
   return [(lo, layer_offsets[lo][0], layer_offsets[hi][1]) for lo, hi in groups]
 

@@ -172,6 +172,14 @@ def test_shard_range_and_buckets():
     shard_range(10, 0, 4)
   offs = [(0, 10), (10, 20), (20, 120), (120, 140), (140, 145)]
   assert default_buckets([e - s for s, e in offs], offs) == [(3, 120, 145), (2, 20, 120), (0, 0, 20)]
+  # the Wav2Letter shape: the big layer is the ninth; the eight layers below it go in two halves, the lower one last
+  sizes = [10, 4, 4, 4, 4, 4, 4, 4, 100, 30, 1]
+  offs, o = [], 0
+  for n in sizes:
+    offs.append((o, o + n))
+    o += n
+  assert default_buckets(sizes, offs) == [(9, offs[9][0], offs[10][1]), (8, offs[8][0], offs[8][1]), (4, offs[4][0], offs[7][1]),
+                                          (0, 0, offs[3][1])]
 
 
 DP_WORKER = r'''

@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
 #pragma unroll
   for (int w = 0; w < width; ++w) f[w] = live ? packed[((long)w * cpi + c) * npo + o] : 0.f;
   const long plane = (long)2 * cph * 2 * npo;
-  for (int k = 0; k < bins; ++k) {
+  // blockIdx.z: a share of the bins (narrow layers have too few (c, o) pairs to fill the chip with one thread each)
+  const int per = (bins + gridDim.z - 1) / gridDim.z, k_lo = blockIdx.z * per, k_hi = min(bins, k_lo + per);
+  for (int k = k_lo; k < k_hi; ++k) {
     float gr = 0.f, gi = 0.f;
     const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
 #pragma unroll
@@ -370,7 +372,8 @@ __global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __res
 #pragma unroll
   for (int w = 0; w < width; ++w) f[w] = live ? packed_t[((long)(width - 1 - w) * cpo + o) * npi + c] : 0.f;
   const long plane = (long)2 * npo * 2 * npi;
-  for (int k = 0; k < bins; ++k) {
+  const int per = (bins + gridDim.z - 1) / gridDim.z, k_lo = blockIdx.z * per, k_hi = min(bins, k_lo + per);
+  for (int k = k_lo; k < k_hi; ++k) {
     float gr = 0.f, gi = 0.f;
     const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
 #pragma unroll
@@ -557,13 +560,15 @@ int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int wi
   if (gfwd) {
     ST_REQUIRE(packed, "fft filters: packed filters missing");
     // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
-    const dim3 grid(st::ceil_div(npo, 256), half_of(cin_pitch));
+    const int gx = st::ceil_div(npo, 256), gy = half_of(cin_pitch);
+    const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
     ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd);
   }
   if (gbwd) {
     ST_REQUIRE(packed_t, "fft filters: flipped / transposed filters missing");
     ST_REQUIRE(npad_of(cin) % 128 == 0, "fft filters: the input channels must pack to a multiple of 128 for back-prop");
-    const dim3 grid(st::ceil_div(npi, 256), npo);
+    const int gx = st::ceil_div(npi, 256);
+    const dim3 grid(gx, npo, gx * npo < 1024 ? 4 : 1);
     ST_FFT_WIDTH_DISPATCH(filters_dft_bwd_kernel, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
   }
   return st::check_launch("fft filters");

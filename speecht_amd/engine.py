@@ -405,37 +405,42 @@ class Wav2LetterEngine:
       self._gbwd_fresh = False
     self._fft_prev = set(self.fft)
 
-  def _refresh_fft_filters(self, forward):
-    """Filter spectra of every frequency-domain layer from the current weights, in layer order; after each forward
-    operand an event is recorded so that the forward pass waits for the layer it is about to run, not for all."""
+  def _refresh_fft_filters(self, layers=None):
+    """Forward filter spectra of the frequency-domain layers (all, or the given ones) from the current weights, in layer
+    order; on a side stream an event is recorded after each layer so that the forward pass waits for the layer it is
+    about to run, not for all.  (The back-prop operands: `_refresh_backward_operands`.)"""
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    if forward:
+    if layers is None:
       self._gfwd_ready = {}
     for i, f in self.fft.items():
+      if layers is not None and i not in layers:
+        continue
       l = self.layers[i]
       pf = self._slice(self.params, i)[0]
-      if forward and f['shift'] is not None:
+      if f['shift'] is not None:
         cp = self.X[i].c_pitch
         n = l.width * cp * l.n_pad
         with torch.cuda.stream(stream):
           f['packed2'][f['shift'] * cp * l.n_pad:f['shift'] * cp * l.n_pad + n].copy_(pf[:n], non_blocking=True)
         pf = f['packed2']
-      if forward or i > 0:
-        call('st_conv1d_fft_filters_f32', self._ptr(pf), self._ptr(self.packed_t[i]) if i > 0 else None, f['width'],
-             f['cin'], l.cout, f['cin_pitch'], l.cout_pitch, self._ptr(f['tables']),
-             self._ptr(f['gfwd']) if forward else None, None if forward else self._ptr(f['gbwd']), self.stream_ptr)
-      if forward:
+      call('st_conv1d_fft_filters_f32', self._ptr(pf), None, f['width'], f['cin'], l.cout, f['cin_pitch'], l.cout_pitch,
+           self._ptr(f['tables']), self._ptr(f['gfwd']), None, self.stream_ptr)
+      if stream is getattr(self, '_side', None):
         ev = torch.cuda.Event()
         ev.record(stream)
         self._gfwd_ready[i] = ev
-    if forward:
-      self._gfwd_fresh = True
-    else:
-      self._gbwd_fresh = True
+    self._gfwd_fresh = True
 
   def _refresh_gfwd(self):
+    """After an update: the bottom layer's spectra on the compute stream (the next step needs them at once; a
+    cross-stream wait there costs more than the 25 us of work), the others on the side stream, bottom layer first."""
     if self.fft and self._shape is not None:
-      self._refresh_fft_filters(True)
+      first = min(self.fft)
+      self._gfwd_ready = {}
+      self._refresh_fft_filters(layers=[first])
+      rest = [i for i in self.fft if i != first]
+      if rest:
+        self._on_side_stream(lambda: self._refresh_fft_filters(layers=rest))
 
   def _wait_gfwd(self, i=None):
     """The compute stream waits for the forward filter spectra of layer i (None: of every layer) if they were rebuilt on
@@ -660,14 +665,27 @@ class Wav2LetterEngine:
     if slot[0] is None or slot[0].numel() < n:
       slot[0] = torch.empty(max(n, 1024), dtype=torch.int32, pin_memory=True)
     slot[0][:n].copy_(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int32)))
-    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    with torch.cuda.stream(stream):
+    # on the copy stream: the consumers (CTC, the decoders) come a whole forward pass later and wait for the event
+    # there (`_wait_uploads`); on the compute stream three such copies cost the start of every step ~40 us
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    if not hasattr(self, '_up_stream'):
+      self._up_stream, self._uploads = torch.cuda.Stream(self.device), []
+    with torch.cuda.stream(self._up_stream):
       dev = torch.empty(n, dtype=torch.int32, device=self.device)
       dev.copy_(slot[0][:n], non_blocking=True)
       if slot[1] is None:
         slot[1] = torch.cuda.Event()
-      slot[1].record(stream)
+      slot[1].record(self._up_stream)
+    dev.record_stream(main)
+    self._uploads.append(slot[1])
     return dev
+
+  def _wait_uploads(self):
+    """The compute stream waits for the int32 uploads (lengths, labels) issued since the last call."""
+    ups = getattr(self, '_uploads', None)
+    if ups:
+      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(ups[-1])
+      del ups[:]
 
   def forward(self, training=False):
     """The eleven layers (``training`` is accepted for callers that distinguish the two uses; the pass is the same)."""
@@ -691,7 +709,7 @@ class Wav2LetterEngine:
         f = self.fft[i]
         if not self._gfwd_fresh:
           self._join_side_stream()
-          self._refresh_fft_filters(True)
+          self._refresh_fft_filters()
         self._wait_gfwd(i)                               # the filter spectra may still be on their way (side stream)
         call('st_conv1d_nwc_fwd_fft_f32', f['xref'], self._ptr(f['gfwd']), self._ptr(pb), f['width'], f['pl'],
              int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), self._ptr(f['ws']),
@@ -715,7 +733,7 @@ class Wav2LetterEngine:
       self._refresh_wplanes()
     self._join_side_stream()
     if self.fft and self.fft_conv and not self._gfwd_fresh:
-      self._refresh_fft_filters(True)
+      self._refresh_fft_filters()
     self._wait_gfwd()                              # no waits on outside events inside a capture
     key = (self._shape, self._storage.generation)
     graph = self._graphs.get(key)
@@ -797,6 +815,7 @@ class Wav2LetterEngine:
         self._on_side_stream(lambda: self._refresh_bf16_filters(True))
     elif not self._packed_t_fresh or (self.fft and not self._gbwd_fresh):
       self._on_side_stream(self._refresh_backward_operands)
+    self._wait_uploads()
     call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
          self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
@@ -957,13 +976,13 @@ class Wav2LetterEngine:
     self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
     self.mark_weights_changed()
     if self.fft:
-      # the forward filter spectra of the frequency-domain layers, on the side stream, bottom layer first
-      self._on_side_stream(self._refresh_gfwd)
+      self._refresh_gfwd()          # the forward filter spectra of the frequency-domain layers for the next pass
     elif self.conv_mode == 'bf16' and hasattr(self, 'Wb'):
       self._on_side_stream(lambda: self._refresh_bf16_filters(False))   # the bf16 copies the next forward pass reads
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""
+    self._wait_uploads()
     call('st_ctc_greedy_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(merge_repeated),
          self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score), self.stream_ptr)
     lens = self.dec_lens.cpu().numpy()
@@ -974,6 +993,7 @@ class Wav2LetterEngine:
     """``greedy_decode`` without the host synchronisation: launches the decoder and the D2H copies of its
     outputs into pinned host buffers and returns a handle; ``handle.result()`` waits for that batch only.  Lets
     a caller enqueue the next batch's forward before it reads this batch's transcripts (inference.transcribe)."""
+    self._wait_uploads()
     call('st_ctc_greedy_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(merge_repeated),
          self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score), self.stream_ptr)
     B, n = self.dec_lens.numel(), self.dec_ids.numel()
@@ -1002,6 +1022,7 @@ class Wav2LetterEngine:
     B = self.dec_lens.numel()
     need = lib.st_ctc_beam_ws(B, self.t_out, int(beam_width))
     ws = self._storage.view('beam_ws', need // 4 + 16, torch.int32)[0]
+    self._wait_uploads()
     call('st_ctc_beam_search_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(beam_width),
          self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score),
          self._ptr(ws), ws.numel() * 4, self.stream_ptr)

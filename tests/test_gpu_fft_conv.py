@@ -95,6 +95,12 @@ def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
   call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cpi, P(dFd), None)
   dF = dFd.view(W, cin, cout).cpu().numpy()
   assert np.max(np.abs(dF - dF_ref)) < 2e-5 * np.max(np.abs(dF_ref))
+  # bias gradient read off bin 0 of the same spectra (pads written as zeros)
+  db = torch.full((npad.value,), 7.0, device=dev)
+  call('st_conv1d_fft_bias_grad_f32', dzt.ref, W, P(zf), P(db), None)
+  db_ref = dz.reshape(-1, cout).sum(axis=0)
+  assert np.max(np.abs(db[:cout].cpu().numpy() - db_ref)) < 2e-5 * np.max(np.abs(db_ref))
+  assert float(db[cout:].abs().max()) == 0.0
   # padding of the packed gradient is exactly zero (it is part of the flat gradient's global norm)
   G = dpacked.view(kp.value, npad.value)
   assert float(G[:, cout:].abs().max()) == 0.0

@@ -271,3 +271,33 @@ def test_torch_ref_equals_oracle():
   for (gF, gb), (rF, rb) in zip(got['grads'], ref['grads']):
     np.testing.assert_allclose(gF, rF, rtol=0, atol=1e-11 * np.max(np.abs(rF)) + 1e-300)
     np.testing.assert_allclose(gb, rb, rtol=0, atol=1e-11 * np.max(np.abs(rb)) + 1e-300)
+
+
+@pytest.mark.parametrize('T,W,cin,cout', [(37, 48, 5, 4), (40, 48, 3, 6), (21, 6, 4, 3), (22, 7, 2, 5)])
+def test_stride2_conv_is_a_stride1_conv_on_frame_pairs(T, W, cin, cout):
+  """The identity behind the engine's polyphase first layer (engine._polyphase): a stride-2 'SAME'
+  convolution equals a stride-1 convolution over frame pairs with pl2 = ceil(pl / 2), shift = 2 pl2 - pl,
+  W2 = ceil((W + shift) / 2) taps F2[j][p] = F[2j + p - shift] (zero outside) -- checked here in float64 with the
+  oracle's own convolution on both sides (speech_model.py:155,279)."""
+  rng = np.random.default_rng(T * W)
+  x = rng.standard_normal((2, T, cin))
+  F = rng.standard_normal((W, cin, cout))
+  bias = rng.standard_normal(cout)
+  y_ref = O.conv1d_same_fwd(x, F, bias, 2, False)
+  t_out, pl, _ = O.same_padding(T, W, 2)
+  pl2 = (pl + 1) // 2
+  shift = 2 * pl2 - pl
+  W2 = (W + shift + 1) // 2
+  F2 = np.zeros((W2, 2, cin, cout))
+  for w in range(W):
+    F2[(w + shift) // 2, (w + shift) % 2] = F[w]
+  # frame pairs as channels, with enough zero frames on both sides for the taps to reach
+  lo, hi = 2 * pl2, 2 * (W2 + 1)
+  xp = np.zeros((2, lo + 2 * t_out + hi, cin))
+  xp[:, lo:lo + T] = x
+  X2 = xp.reshape(2, -1, 2 * cin)
+  y = np.zeros_like(y_ref)
+  for t in range(t_out):
+    for j in range(W2):
+      y[:, t] += X2[:, t + j] @ F2[j].reshape(2 * cin, cout)      # X2 index t + j - pl2, shifted by the pl2 pad pairs
+  np.testing.assert_allclose(y + bias, y_ref, rtol=1e-12, atol=1e-12)

@@ -56,7 +56,7 @@ const char* st_last_error(void);
  * returns the bytes needed including the terminator.  Used by the parity tests to assert which kernels a
  * full-size step really ran.
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_prio"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 size_t st_trace_end(char* host_buf, size_t capacity);

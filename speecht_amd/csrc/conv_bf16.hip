@@ -24,8 +24,20 @@
 #include <cstdlib>
 
 #include "st_common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
+
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time value
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -220,7 +232,6 @@ struct X6Params {
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
   int tiles_m, tiles_n, chunk;
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
-  int prio_mode;                         // experiment (st_set_tuning "bf16_prio"): see the ping-pong loop
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -330,25 +341,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     }
   }
 
+  // Reduction order: tap-inner for convolutions (taps > 1: all taps of a 32-deep channel chunk, then the next chunk),
+  // plain for one-tap layers and filter gradients.  A stage is (tap t, chunk c) at reduction index k0 = t * cp + c * BK;
+  // the cursors advance without branches (the loop body must stay free of them, see `stage`).
   const bool tap_inner = p.taps > 1;
-  const int chunks = (p.cp + BK - 1) / BK;
-  const int nk_all = tap_inner ? chunks * p.taps : (p.Kvalid + BK - 1) / BK;
+  const int len = tap_inner ? p.cp : p.Kvalid;       // reduction length per tap
+  const int chunks = (len + BK - 1) / BK;
   // reduction split (filter gradients of the small layers, back-prop through L8): this workgroup owns a
-  // contiguous range of stages
-  // (tap-inner convolutions split over channel chunks, every split walks all taps)
-  const int units = tap_inner ? chunks : nk_all;
-  const int per_split = (units + p.splits - 1) / p.splits;
+  // contiguous range of chunks (tap-inner convolutions split over channel chunks, every split walks all taps)
+  const int per_split = (chunks + p.splits - 1) / p.splits;
   const int unit0 = split * per_split;
-  const int nk = max(min(per_split, units - unit0), 0) * (tap_inner ? p.taps : 1);
-  int tap = 0, chunk = unit0;            // compute cursor
-  int itap = 0, ichunk = unit0;          // DMA issue cursor (ST-1 stages ahead)
-  auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
-  auto tile_ks = [&](int t, int c) {
-    const int valid = tap_inner ? p.cp - c * BK : p.Kvalid - c * BK;
+  const int nk = max(min(per_split, chunks - unit0), 0) * p.taps;
+  const int wrap_inc = BK - (p.taps - 1) * p.cp;     // k0 step from the last tap of a chunk to the first of the next
+  struct Cursor { int t, c, k0; };
+  Cursor cc{0, unit0, unit0 * BK};                   // compute cursor
+  Cursor ic = cc;                                    // DMA issue cursor (ST-1 stages ahead)
+  auto tile_ks = [&](const Cursor& q) {
+    const int valid = len - q.c * BK;
     return valid >= BK ? KS : (valid + 15) / 16;
   };
-  auto advance = [&](int& t, int& c) {
-    if (tap_inner) { if (++t == p.taps) { t = 0; ++c; } } else { ++c; }
+  auto advance = [&](Cursor& q) {
+    const int t1 = q.t + 1;
+    const bool wrap = t1 == p.taps;
+    q.t = wrap ? 0 : t1;
+    q.c += wrap ? 1 : 0;
+    q.k0 += wrap ? wrap_inc : p.cp;
   };
   // every wave issues N_DMA pieces per stage and they retire in order, so "my stage kt+1 has landed" is
   // vmcnt <= (ST-2) * N_DMA while ST-1 stages are in flight; in the tail (nothing new issued) wait for all
@@ -360,15 +377,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
 #pragma unroll
   for (int sgi = 0; sgi < ST - 1; ++sgi) {
     if (sgi < nk) {
-      const int k0 = tile_k0(itap, ichunk);
 #pragma unroll
-      for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, k0, sgi);
-      advance(itap, ichunk);
+      for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, ic.k0, sgi);
+      advance(ic);
     }
   }
   stage_sync(nk >= ST - 1);
 
-  int cur = 0, fill = ST - 1;            // ring slots: being consumed / being filled
   auto mfma_terms = [&](bf16x8 (&af)[KS][NP][MT], bf16x8 (&bf)[KS][NP][NT], int ks) {
     constexpr int TERMS = NP == 3 ? 6 : 1;
 #pragma unroll
@@ -381,74 +396,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][TB[t]][n], af[ks][TA[t]][i], acc[i][n], 0, 0, 0);
     }
   };
-  if constexpr (PP) {
-    static_assert(ST >= 3 && NW % 2 == 0, "ping-pong needs a ring of 3 and an even number of waves");
-    const int grp = wave / (NW / 2);               // waves i and i + NW/2 share a SIMD: one of each group per SIMD
-    auto phase_barrier = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_barrier" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto wait_stage = [&](bool full_ring) {          // my pieces of the next stage have landed
-      if (full_ring) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * N_DMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // wave priorities (MI355X_MICROARCH.md "Two waves per SIMD"): VALU issue between the two waves of a SIMD goes
-    // by priority, then age.  mode 0: the MFMA phase runs at priority 1 (round 1); 1: no priorities; 2: the READ
-    // phase at priority 1; 3: static priority 1 for the younger group, no per-phase flips
-    const int prio_mode = p.prio_mode;
-    if (prio_mode == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
-    if (grp == 1) phase_barrier();                   // group 1 runs one phase behind
-    for (int kt = 0; kt < nk; ++kt) {
-      const int nks = FAST ? KS : tile_ks(tap, chunk);
-      advance(tap, chunk);
-      const bool more = kt + ST - 1 < nk;
-      const int nk0 = tile_k0(itap, ichunk);
-      if (more) advance(itap, ichunk);
-      const unsigned short* as = As + cur * NP * PL;
-      const unsigned short* bs = Bs + cur * NP * PL;
-      bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
-      // ---- read phase (the other group is in its MFMA phase)
-      if (prio_mode == 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int pl = NP - 1; pl >= 0; --pl) {
-#pragma unroll
-          for (int i = 0; i < MT; ++i) af[ks][pl][i] = *reinterpret_cast<const bf16x8*>(as + pl * PL + a_frag[ks] + i * 32 * BK);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bf[ks][pl][n] = *reinterpret_cast<const bf16x8*>(bs + pl * PL + b_frag[ks] + n * 32 * BK);
-        }
-      }
-      if (more) {                                    // slot `fill` was last read one phase ago by group 1
-#pragma unroll
-        for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, nk0, fill);
-      }
-      if (grp == 1) wait_stage(more);                // this barrier is group 0's end-of-stage barrier
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (prio_mode == 2) __builtin_amdgcn_s_setprio(0);
-      phase_barrier();
-      // ---- MFMA phase: nothing but the matrix instructions (the other group reads / issues DMA)
-      if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        if (ks < nks) mfma_terms(af, bf, ks);
-      if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
-      if (grp == 0) wait_stage(more);
-      phase_barrier();
-      cur = cur + 1 == ST ? 0 : cur + 1;
-      fill = fill + 1 == ST ? 0 : fill + 1;
-    }
-    if (grp == 0) phase_barrier();                   // every wave executes the same number of barriers
-  } else {
-  for (int kt = 0; kt < nk; ++kt) {
-    const int nks = FAST ? KS : tile_ks(tap, chunk);
-    advance(tap, chunk);
-    const bool more = kt + ST - 1 < nk;
-    const int nk0 = tile_k0(itap, ichunk);
-    if (more) advance(itap, ichunk);
-    const unsigned short* as = As + cur * NP * PL;
-    const unsigned short* bs = Bs + cur * NP * PL;
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_stage = [&](bool full_ring) {          // my pieces of the next stage have landed
+    if (full_ring) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * N_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(!PP || (ST >= 3 && NW % 2 == 0), "ping-pong needs a ring of 3 and an even number of waves");
+
+  // One stage of the reduction, instantiated per ring slot (CUR: being consumed; the one being filled is CUR - 1) so
+  // that every LDS address is a register plus an immediate, and per "a successor stage certainly exists" (MORE_CT):
+  // the steady-state loop below is then free of scalar branches -- with 32-cycle bf16 MFMAs, 16 per stage and wave,
+  // the ring arithmetic and the `more` / group tests of a run-time loop body were a visible share of every stage.
+  // PP (ping-pong): the waves form two groups (one wave of each per SIMD; GRP) that run half a stage out of phase:
+  // while one feeds the matrix pipe (at raised priority) the other reads its fragments of the next stage and issues DMA.
+  auto stage = [&](auto cur_c, auto more_c, auto grp_c, int kt) {
+    constexpr int CUR = decltype(cur_c)::value, FILL = (CUR + ST - 1) % ST, GRP = decltype(grp_c)::value;
+    constexpr bool MORE_CT = decltype(more_c)::value;
+    const int nks = FAST ? KS : tile_ks(cc);
+    if (!FAST) advance(cc);
+    const bool more = MORE_CT || kt + ST - 1 < nk;
+    const int nk0 = ic.k0;
+    if (more) advance(ic);
+    const unsigned short* as = As + CUR * NP * PL;
+    const unsigned short* bs = Bs + CUR * NP * PL;
     bf16x8 af[KS][NP][MT], bf[KS][NP][NT];
     auto read_frags = [&](int ks) {
 #pragma unroll
@@ -459,22 +433,59 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
         for (int n = 0; n < NT; ++n) bf[ks][pl][n] = *reinterpret_cast<const bf16x8*>(bs + pl * PL + b_frag[ks] + n * 32 * BK);
       }
     };
-    read_frags(0);
+    if constexpr (PP) {
+      // ---- read phase (the other group is in its MFMA phase)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (more) {
+      for (int ks = 0; ks < KS; ++ks) read_frags(ks);
+      if (more) {                                    // slot FILL was last read one phase ago by group 1
 #pragma unroll
-        for (int pc = ks * (N_DMA / KS); pc < (ks + 1) * (N_DMA / KS); ++pc) dma_piece(pc, nk0, fill);
+        for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, nk0, FILL);
       }
-      if (ks + 1 < KS) read_frags(ks + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks < nks) mfma_terms(af, bf, ks);
-      __builtin_amdgcn_sched_barrier(0);
+      if (GRP == 1) wait_stage(more);                // this barrier is group 0's end-of-stage barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      phase_barrier();
+      // ---- MFMA phase: nothing but the matrix instructions (the other group reads / issues DMA)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (FAST || ks < nks) mfma_terms(af, bf, ks);
+      __builtin_amdgcn_s_setprio(0);
+      if (GRP == 0) wait_stage(more);
+      phase_barrier();
+    } else {
+      read_frags(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (more) {
+#pragma unroll
+          for (int pc = ks * (N_DMA / KS); pc < (ks + 1) * (N_DMA / KS); ++pc) dma_piece(pc, nk0, FILL);
+        }
+        if (ks + 1 < KS) read_frags(ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FAST || ks < nks) mfma_terms(af, bf, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage_sync(more);
     }
-    stage_sync(more);
-    cur = cur + 1 == ST ? 0 : cur + 1;
-    fill = fill + 1 == ST ? 0 : fill + 1;
-  }
+  };
+  auto run = [&](auto grp_c) {
+    constexpr int GRP = decltype(grp_c)::value;
+    if (PP && GRP == 1) phase_barrier();             // group 1 runs one phase behind
+    int kt = 0;
+    for (; kt + 2 * ST - 2 < nk; kt += ST)           // every stage of the trip has a successor ST - 1 ahead
+      static_for<ST>([&](auto s_c) { stage(s_c, std::true_type{}, grp_c, kt + decltype(s_c)::value); });
+    // the last (up to 2 ST - 2) stages: ring slots go on round-robin, `more` is tested
+    static_for<2 * ST - 2>([&](auto r_c) {
+      constexpr int R = decltype(r_c)::value;
+      if (kt + R < nk) stage(std::integral_constant<int, R % ST>{}, std::false_type{}, grp_c, kt + R);
+    });
+    if (PP && GRP == 0) phase_barrier();             // every wave executes the same number of barriers
+  };
+  if constexpr (PP) {
+    if (wave / (NW / 2) == 0) run(std::integral_constant<int, 0>{});   // waves i and i + NW/2 share a SIMD
+    else run(std::integral_constant<int, 1>{});
+  } else {
+    run(std::integral_constant<int, 0>{});
   }
 
   // epilogue.  The MFMAs above were issued with the operands swapped (filter fragment first), so the
@@ -633,7 +644,6 @@ __global__ __launch_bounds__(256) void row_sum_bf16_kernel(const __bf16* __restr
 template <int NP>
 int launch_gemm(X6Params& p, hipStream_t s) {
   const int forced_tile = st::tuning(st::TUNE_BF16_TILE);
-  p.prio_mode = st::tuning(st::TUNE_BF16_PRIO);
   if (p.splits < 1) p.splits = 1;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
   const bool wide = (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192;

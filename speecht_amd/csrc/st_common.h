@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...);
 bool trace_on();
 void trace(const char* fmt, ...);
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_PRIO, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)

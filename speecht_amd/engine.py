@@ -477,6 +477,7 @@ class Wav2LetterEngine:
     ws2 = max([0] + [lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, self.layers[i].width, self.layers[i].stride,
                                                       self.geo[i][2]) for i in self._side_wgrad_bf16])
     self.wgrad_ws_b2 = self._storage.view('wgrad_ws_b2', ws2 // 4 + 64)[0] if ws2 else None
+    self.wgrad_ws_b3 = self._storage.view('wgrad_ws_b3', ws2 // 4 + 64)[0] if ws2 else None    # second side stream
     if not hasattr(self, 'Wb'):
       z = lambda n: torch.zeros(n, dtype=torch.bfloat16, device=self.device)
       self.Wb = [z(l.k_pad * l.n_pad) for l in self.layers]
@@ -519,11 +520,14 @@ class Wav2LetterEngine:
       gf, gb = self._slice(self.grads, i)
       beside = i in self._side_wgrad_bf16      # this layer's filter gradient runs beside its back-prop to the input
 
-      def filter_gradient(i=i, l=l, gf=gf, gb=gb, ws=self.wgrad_ws_b2 if beside else self.wgrad_ws_b):
+      def filter_gradient(i=i, l=l, gf=gf, gb=gb, ws=(self.wgrad_ws_b3 if (i % 2 == 1 and self.wgrad_ws_b3 is not None)
+                                                         else self.wgrad_ws_b2) if beside else self.wgrad_ws_b):
         call('st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]),
              l.width, l.stride, self.geo[i][2], self._ptr(gf), self._ptr(gb), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
       if beside:
-        self._on_side_stream(filter_gradient)
+        # two side streams take the chains in turn (each needs only its own layer's tensors): with all seven on one
+        # stream that stream, not back-prop to the input, set the length of the backward pass of the narrow layers
+        self._on_side_stream(filter_gradient, second=(i % 2 == 1 and self.wgrad_ws_b3 is not None))
         side = True
       else:
         filter_gradient()
@@ -775,30 +779,40 @@ class Wav2LetterEngine:
     self.label_ids = self._upload_i32(ids)
     self.label_offs = self._upload_i32(offs)
 
-  def _on_side_stream(self, fn):
-    """Run ``fn`` (which enqueues kernels through ``self.stream_ptr``) on the engine's side stream, ordered after
-    everything enqueued so far on the compute stream; ``_join_side_stream`` makes the compute stream wait for it.
-    Used to put small HBM-bound operand preparation next to the CTC recursion, which is a latency chain of 500
-    dependent steps on 64 wavefronts and leaves the rest of the chip idle."""
+  def _on_side_stream(self, fn, second=False):
+    """Run ``fn`` (which enqueues kernels through ``self.stream_ptr``) on the engine's side stream (``second``: on a
+    second one), ordered after everything enqueued so far on the compute stream; ``_join_side_stream`` makes the
+    compute stream wait for both.  Used to put small HBM-bound operand preparation next to the CTC recursion, which is
+    a latency chain of 500 dependent steps on 64 wavefronts and leaves the rest of the chip idle, and independent
+    chains of the backward pass next to each other."""
     main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     if getattr(self, '_side', None) is None:
       self._side = torch.cuda.Stream(self.device)
+    if second and getattr(self, '_side2', None) is None:
+      self._side2 = torch.cuda.Stream(self.device)
+    stream = self._side2 if second else self._side
     fork = torch.cuda.Event()
     fork.record(main)
-    self._side.wait_event(fork)
-    saved, self._stream = self._stream, self._side
+    stream.wait_event(fork)
+    saved, self._stream = self._stream, stream
     try:
       fn()
     finally:
       self._stream = saved
-    self._side_done = torch.cuda.Event()
-    self._side_done.record(self._side)
+    done = torch.cuda.Event()
+    done.record(stream)
+    if second:
+      self._side2_done = done
+    else:
+      self._side_done = done
 
   def _join_side_stream(self):
-    done = getattr(self, '_side_done', None)
-    if done is not None:
-      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(done)
-      self._side_done = None
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    for name in ('_side_done', '_side2_done'):
+      done = getattr(self, name, None)
+      if done is not None:
+        main.wait_event(done)
+        setattr(self, name, None)
 
   def ctc_loss_grad(self, grad_scale):
     B, T = self.X[-1].batch, self.X[-1].frames

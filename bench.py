@@ -66,7 +66,7 @@ class HostFeed:
 
 def train_step(eng, feed, reducer, lr, global_batch):
   feed.next()
-  eng.forward(training=True)
+  eng.forward()
   eng.ctc_loss_grad(1.0 / global_batch)
   eng.backward(reducer.on_layer_done if reducer else None)
   if reducer:

@@ -691,8 +691,7 @@ class Wav2LetterEngine:
       (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(ups[-1])
       del ups[:]
 
-  def forward(self, training=False):
-    """The eleven layers (``training`` is accepted for callers that distinguish the two uses; the pass is the same)."""
+  def forward(self):
     if self.conv_mode == 'bf16':
       return self._forward_bf16()
     s = self.stream_ptr
@@ -861,14 +860,6 @@ class Wav2LetterEngine:
       self._wtplanes_fresh = False
     if spectra:
       self._gbwd_fresh = True
-
-  def refresh_packed_t(self):
-    if not self._packed_t_fresh:
-      gb, self._gbwd_fresh = self._gbwd_fresh, True          # the flips only
-      try:
-        self._refresh_backward_operands()
-      finally:
-        self._gbwd_fresh = gb
 
   def _wait_bwd_operands(self, i=None):
     """The compute stream waits for the back-prop operands of layer i (None: of every layer) if they were rebuilt on the

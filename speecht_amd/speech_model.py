@@ -341,7 +341,7 @@ class SpeechModel:
     if (loss or update) and labels is None:
       raise ValueError('loss/update requested but the input loader provides no labels')
     eng.load_batch(inputs, seq_lens)
-    eng.forward(training=bool(update))
+    eng.forward()
     out = []
     avg_loss = None
     if loss or update:

@@ -216,3 +216,35 @@ def test_frequency_domain_layer_survives_shape_switching_and_weight_updates(dev)
   torch.cuda.synchronize()
   assert torch.equal(eng.X[-1].buf, fresh.X[-1].buf)
   assert torch.equal(eng.grads, fresh.grads)
+
+
+def test_training_steps_agree_between_frequency_and_w_tap_kernels(dev):
+  """Three clip + Adam steps with the frequency-domain layers (polyphase first layer, 7-tap and 32-tap layers, bias
+  gradients from bin 0, filter-gradient chains on the side stream) against the same three steps on the W-tap kernels
+  only: losses to 1e-5, every weight tensor to 2e-4 of its max -- one ReLU sign flip of a near-zero pre-activation
+  between the two formulations moves individual filter taps by about that much after three steps (the full-size
+  gradient tests take this discontinuity apart); a wrong operand, tap shift or stream order would be off by O(1)."""
+  from speecht_amd.engine import Wav2LetterEngine
+  from tests import workloads as WL
+  layers = WL.w2l_layers(80)
+  params = WL.xavier_params(layers, seed=7, dtype=np.float32)
+  x, seq, labels = WL.make_batch([601] * 8, 80, seed=11)
+  runs = {}
+  for fft in (True, False):
+    eng = Wav2LetterEngine(layers, device=dev, fft_conv=fft)
+    eng.set_weights(params)
+    losses = []
+    for _ in range(3):
+      eng.load_batch(x.astype(np.float32), seq)
+      eng.set_labels(labels)
+      eng.forward()
+      eng.ctc_loss_grad(1.0 / len(labels))
+      eng.backward()
+      eng.apply_update(1e-4)
+      losses.append(eng.fetch_losses().copy())
+    assert bool(eng.fft) == fft and (not fft or 0 in eng.fft)
+    runs[fft] = (np.array(losses), eng.get_weights())
+  np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=1e-5)
+  for (Fa, ba), (Fb, bb) in zip(runs[True][1], runs[False][1]):
+    assert np.max(np.abs(Fa - Fb)) < 2e-4 * np.max(np.abs(Fb))
+    assert np.max(np.abs(ba - bb)) < 2e-4 * max(np.max(np.abs(bb)), 1e-3)

@@ -146,6 +146,12 @@ class Wav2LetterEngine:
     # ~1e-6 of the tensor scale).  fft_conv=False / ST_FFT_CONV=0 keeps the W-tap kernels everywhere.
     self.fft_conv = (os.environ.get('ST_FFT_CONV', '1') != '0') if fft_conv is None else bool(fft_conv)
     self.fft_min_width = int(os.environ.get('ST_FFT_MIN_WIDTH', '7'))
+    # output rows (B * T') from which the path pays (measured on training steps of 1-16 x 10 s utterances): the 32-tap
+    # layer from ~1 000 rows (B = 2: 3.05 -> 2.94 ms, B = 4: 3.71 -> 3.17), the 7-tap layers and the first layer from ~3 000
+    # (B = 4, 2 004 rows: 3.17 -> 3.27 with them; B = 8, 4 008 rows: 3.86 -> 3.66); below that the W-tap kernels with their
+    # split reductions are faster (B = 1: 2.64 vs 2.88)
+    self.fft_min_rows = int(os.environ.get('ST_FFT_MIN_ROWS', '1000'))
+    self.fft_min_rows_narrow = int(os.environ.get('ST_FFT_MIN_ROWS_NARROW', '3000'))
     # the stride-2 first layer (48 taps over 80 mel channels) on its polyphase view: 25 taps over 160 channels
     self.fft_first_layer = os.environ.get('ST_FFT_FIRST_LAYER', '1') != '0'
     self.side_filter_gradient = os.environ.get('ST_WGRAD_SIDE', '1') != '0'
@@ -348,7 +354,9 @@ class Wav2LetterEngine:
 
   def _use_fft(self, i, batch, t_out):
     l = self.layers[i]
-    if not (self.fft_conv and self.conv_mode in ('fp32', 'bf16x6') and l.n_pad % 128 == 0 and batch * t_out >= 2048):
+    wide = l.stride == 1 and l.width >= 16
+    if not (self.fft_conv and self.conv_mode in ('fp32', 'bf16x6') and l.n_pad % 128 == 0 and
+            batch * t_out >= (self.fft_min_rows if wide else self.fft_min_rows_narrow)):
       return False
     if l.stride == 2:        # first layer of the model (48 taps, stride 2): 25 polyphase taps over 2 x 80 channels
       width2 = self._polyphase(i)[0]

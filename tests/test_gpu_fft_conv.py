@@ -228,7 +228,7 @@ def test_training_steps_agree_between_frequency_and_w_tap_kernels(dev):
   from tests import workloads as WL
   layers = WL.w2l_layers(80)
   params = WL.xavier_params(layers, seed=7, dtype=np.float32)
-  x, seq, labels = WL.make_batch([601] * 8, 80, seed=11)
+  x, seq, labels = WL.make_batch([601] * 12, 80, seed=11)          # 3 612 output rows: every layer class takes the path
   runs = {}
   for fft in (True, False):
     eng = Wav2LetterEngine(layers, device=dev, fft_conv=fft)

@@ -61,10 +61,16 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   v = fmaxf(v, dpp_move<0x4E>(v, v));     // quad_perm [2,3,0,1]
   v = fmaxf(v, dpp_move<0x141>(v, v));    // row_half_mirror
   v = fmaxf(v, dpp_move<0x140>(v, v));    // row_mirror: every lane of a 16-row holds the row max
-  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-  auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+  // the four rows through the scalar unit.  (v_permlane16_swap / v_permlane32_swap would stay on the vector side, but
+  // hipcc folds max(r[0], r[1]) of a swap's two results to r[0]: the "wave maximum" then was the maximum of lanes
+  // 0..15 -- uniform, so the re-centred lattice stayed consistent, but not centred: found when a linear-domain
+  // variant of the recursion, which needs the true maximum, overflowed.)
+  const int b = __builtin_bit_cast(int, v);
+  const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float m2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float m3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
 constexpr float LOG2E = 1.4426950408889634f;

@@ -88,6 +88,9 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
   del acts, ref_grads
 
   # ---- kernel by kernel on the device's stored operands ----
+  # (a stored value is the fp32 accumulation rounded to bf16, the expectation the float64 one: where the exact value sits
+  # within ~1e-7 of a rounding boundary the two may land on neighbouring bf16 values -- one spacing, which in the top
+  # binade of the tensor is up to 2 ULP of the tensor's maximum; the mean bound says it is a handful of elements)
   t0 = time.time()
   Xs = [plane(eng.X[i], eng.Xb[i]) for i in range(L)]                 # stored bf16 inputs of every layer
   dZs = [plane(eng.dZ[i], eng.dZb[i]) for i in range(L)]              # stored bf16 gradients wrt every layer's output
@@ -95,7 +98,7 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
     y = O.conv1d_same_fwd(Xs[i], O.bf16_round(F), b, s, relu)
     if i + 1 < L:
       mx, mean = scaled_err(Xs[i + 1], O.bf16_round(y))
-      assert mx <= 1.01 * ULP and mean < 0.01 * ULP, ('forward', i, mx / ULP, mean / ULP)
+      assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('forward', i, mx / ULP, mean / ULP)
     else:
       mx, _ = scaled_err(plane(eng.X[L], eng.X[L].buf), y)            # logits stay fp32
       assert mx < 1e-5, ('logits from stored X10', mx)
@@ -109,7 +112,7 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
       if layers[i - 1][4]:
         dx = dx * (Xs[i] > 0)
       mx, mean = scaled_err(dZs[i - 1], O.bf16_round(dx))
-      assert mx <= 1.01 * ULP and mean < 0.01 * ULP, ('back-prop to the input', i, mx / ULP, mean / ULP)
+      assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('back-prop to the input', i, mx / ULP, mean / ULP)
     print('kernel-level L%d ok (filters %.1e, bias %.1e of max)' % (i, mxF, mxb))
   # the bf16 copy of d loss / d logits and the fp32 CTC gradient it was rounded from
   mx, _ = scaled_err(dZs[L - 1], O.bf16_round(plane(eng.dZ[L - 1], eng.dZ[L - 1].buf)))

@@ -301,3 +301,93 @@ def test_stride2_conv_is_a_stride1_conv_on_frame_pairs(T, W, cin, cout):
     for j in range(W2):
       y[:, t] += X2[:, t + j] @ F2[j].reshape(2 * cin, cout)      # X2 index t + j - pl2, shifted by the pl2 pad pairs
   np.testing.assert_allclose(y + bias, y_ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('T,W,cin,cout', [(150, 7, 5, 6), (201, 32, 4, 3), (64, 12, 3, 4), (70, 25, 6, 2)])
+def test_block_dft_formulation_of_the_convolution_and_its_gradients(T, W, cin, cout):
+  """The mathematics csrc/conv_fft.hip implements, in float64 numpy against the oracle's convolution (speech_model.py:155,
+  173, 177, 78): blocks of V = 64 output frames, N = V + W - 1 point DFTs over real input (bins 0 .. N/2),
+    forward   Y[k] = S[k] conj(G[k]) per bin, S from x[jV - pl + n] (overlap-save), y = first V points of the inverse;
+    to input  X[k] = Z[k] G[k], Z from the V frames of dz zero-padded; frame jV + t' collects block j at m = t' + pl and
+              its two neighbours at m +- V (overlap-add);
+    filters   Q[k] = sum_rows S[k]^T conj(Z[k]),  dF[w] = inverse at lag w;   bias = sum_rows Re Z[0];
+  with the complex products written as the real [re | im] x [[Gr, -Gi], [Gi, Gr]] embedding the GEMM kernels run."""
+  V = 64
+  N = V + W - 1
+  bins = N // 2 + 1
+  rng = np.random.default_rng(T + W)
+  x = rng.standard_normal((2, T, cin))
+  F = rng.standard_normal((W, cin, cout)) / np.sqrt(W * cin)
+  bias = rng.standard_normal(cout)
+  y_ref = O.conv1d_same_fwd(x, F, bias, 1, False)
+  dz = rng.standard_normal(y_ref.shape)
+  dx_ref, dF_ref, db_ref = O.conv1d_same_bwd(x, F, y_ref, dz, 1, relu=False)
+  _, pl, _ = O.same_padding(T, W, 1)
+  blocks = -(-T // V)
+  xp = np.zeros((2, pl + blocks * V + N, cin))
+  xp[:, pl:pl + T] = x
+  dzp = np.zeros((2, blocks * V, cout))
+  dzp[:, :T] = dz
+  k = np.arange(bins)[:, None]
+  wk = np.where((k[:, 0] == 0) | (2 * k[:, 0] == N), 1.0, 2.0) / N            # hermitian halves count twice
+
+  def dft(seg):                                                                # [rows, n <= N, C] -> [bins, rows, C] complex
+    n = np.arange(seg.shape[1])[None, :]
+    return np.einsum('kn,rnc->krc', np.exp(-2j * np.pi * k * n / N), seg)
+
+  def idft_real(spec, m):                                                      # [bins, rows, C] -> points m: [rows, len(m), C]
+    ph = np.exp(2j * np.pi * k * np.asarray(m)[None, :] / N)                   # [bins, len(m)]
+    return np.einsum('k,km,krc->rmc', wk, ph, spec).real
+
+  def embed_conj(Gc):        # [re | im] x this = [re | im] of (row vector) . conj(Gc): the forward operand gfwd of the kernels
+    return np.block([[Gc.real, -Gc.imag], [Gc.imag, Gc.real]])
+
+  def embed(Gc):             # [re | im] x this = [re | im] of (row vector) . Gc: the back-prop operand gbwd (on Gc = G^T)
+    return np.block([[Gc.real, Gc.imag], [-Gc.imag, Gc.real]])
+
+  rows = [(b, j) for b in range(2) for j in range(blocks)]
+  S = dft(np.stack([xp[b, j * V:j * V + N] for b, j in rows]))                 # x[jV - pl + n]: xp is shifted by pl
+  Z = dft(np.stack([dzp[b, j * V:j * V + V] for b, j in rows]))
+  G = np.einsum('kw,wco->kco', np.exp(-2j * np.pi * k * np.arange(W)[None, :] / N), F)
+
+  # forward: per bin [Sr | Si] x [[Gr, -Gi], [Gi, Gr]] = S conj(G)
+  Y = np.empty((bins, len(rows), cout), complex)
+  for q in range(bins):
+    out = np.hstack([S[q].real, S[q].imag]) @ embed_conj(G[q])
+    Y[q] = out[:, :cout] + 1j * out[:, cout:]
+  yb = idft_real(Y, np.arange(V)) + bias
+  y = np.zeros_like(y_ref)
+  for r, (b, j) in enumerate(rows):
+    n = min(V, T - j * V)
+    y[b, j * V:j * V + n] = yb[r, :n]
+  np.testing.assert_allclose(y, y_ref, rtol=1e-10, atol=1e-10)
+
+  # back-prop to the input: per bin [Zr | Zi] x [[Gr^T, Gi^T], [-Gi^T, Gr^T]] = Z G^T, three inverse terms
+  X = np.empty((bins, len(rows), cin), complex)
+  for q in range(bins):
+    out = np.hstack([Z[q].real, Z[q].imag]) @ embed(G[q].T)
+    X[q] = out[:, :cin] + 1j * out[:, cin:]
+  tp = np.arange(V)
+  own, below, above = idft_real(X, tp + pl), idft_real(X, tp + V + pl), idft_real(X, tp - V + pl)
+  ok_below, ok_above = (tp + V + pl < N), (tp - V + pl >= 0)
+  dx = np.zeros_like(dx_ref)
+  for r, (b, j) in enumerate(rows):
+    v = own[r].copy()
+    if j > 0:
+      v[ok_below] += below[r - 1][ok_below]        # block j - 1 reaches W - 1 - pl frames into this one
+    if j + 1 < blocks:
+      v[ok_above] += above[r + 1][ok_above]        # block j + 1 reaches pl frames back into this one
+    n = min(V, T - j * V)
+    dx[b, j * V:j * V + n] = v[:n]
+  np.testing.assert_allclose(dx, dx_ref, rtol=1e-10, atol=1e-10)
+
+  # filter gradient: lag products per bin as [Sr | Si]^T [Zr | Zi] (four real blocks), then the W lags; bias from bin 0
+  dF = np.zeros_like(dF_ref)
+  for q in range(bins):
+    P = np.hstack([S[q].real, S[q].imag]).T @ np.hstack([Z[q].real, Z[q].imag])
+    re = P[:cin, :cout] + P[cin:, cout:]
+    im = P[cin:, :cout] - P[:cin, cout:]
+    ang = 2 * np.pi * q * np.arange(W) / N
+    dF += wk[q] * (re[None] * np.cos(ang)[:, None, None] - im[None] * np.sin(ang)[:, None, None])
+  np.testing.assert_allclose(dF, dF_ref, rtol=1e-10, atol=1e-10)
+  np.testing.assert_allclose(Z[0].real.sum(axis=0), db_ref, rtol=1e-10, atol=1e-10)

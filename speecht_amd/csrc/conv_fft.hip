@@ -124,14 +124,21 @@ struct RowsIn {                  // a padded NWC tensor, read frame-wise
 // ((2s, 2s + 1) of every row adjacent), so an A fragment is one ds_read_b32 at consecutive addresses across the wave.
 constexpr int CH = 12;                       // frame (bin) pairs per pipeline stage; KP / 2 = 4 * CH
 
-template <int R>
-__device__ inline void stage_matrix(float* __restrict__ dst, const float* __restrict__ src) {      // src [R][KP] row-major
-  for (int i = threadIdx.x; i < R * KP / 4; i += 256) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+template <int R, int COUNT = 1>
+__device__ inline void stage_matrix(float* __restrict__ dst, const float* __restrict__ src) {      // COUNT x src [R][KP] row-major
+  // all loads first, then the LDS writes: a load -> wait -> write loop exposes one memory latency per 4 KB
+  constexpr int IT = R * KP / 4 / 256;
+  static_assert(IT * 256 * 4 == R * KP, "the matrix must be a whole number of 256-thread passes");
+  f32x4 v[COUNT * IT];
+#pragma unroll
+  for (int it = 0; it < COUNT * IT; ++it) v[it] = reinterpret_cast<const f32x4*>(src)[threadIdx.x + 256 * it];
+#pragma unroll
+  for (int it = 0; it < COUNT * IT; ++it) {
+    const int m = it / IT, i = threadIdx.x + 256 * (it % IT);
     const int row = (i * 4) / KP, k = (i * 4) % KP;          // KP % 4 == 0: four columns of one row
-    f32x2* d = reinterpret_cast<f32x2*>(dst) + ((k >> 1) * R + row);
-    d[0] = f32x2{v[0], v[1]};
-    d[R] = f32x2{v[2], v[3]};
+    f32x2* d = reinterpret_cast<f32x2*>(dst + m * R * KP) + ((k >> 1) * R + row);
+    d[0] = f32x2{v[it][0], v[it][1]};
+    d[R] = f32x2{v[it][2], v[it][3]};
   }
 }
 
@@ -228,8 +235,7 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
   __shared__ __attribute__((aligned(16))) float wl[TERMS * V * KP];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
-#pragma unroll
-  for (int term = 0; term < TERMS; ++term) stage_matrix<V>(wl + term * V * KP, winv + term * V * KP);
+  stage_matrix<V, TERMS>(wl, winv);
   __syncthreads();
   const long plane = (long)rows_pad * 2 * half_in;
   const float* afrag = wl + 2 * l31 + h;

@@ -117,9 +117,10 @@ def test_fullsize_fp32_gradients_match_float64_reference(case):
 
 
 def test_fullsize_fp32_frequency_domain_l8_gradients_match_float64_reference(case):
-  """The default fp32 step: the 32-tap 250 -> 2000 layer runs in the frequency domain (csrc/conv_fft.hip) -- block DFTs,
-  48 per-bin GEMMs per pass on the fp32 MFMA kernel (batched launches in the trace), fused inverse + epilogue.  Same
-  three comparisons and the same tolerances as the W-tap kernels."""
+  """The default fp32 step: nine of the eleven layers run in the frequency domain (csrc/conv_fft.hip) -- block DFTs,
+  per-bin GEMMs on the fp32 MFMA kernels (batched launches in the trace: 48 bins for the 32-tap layer, 36 for the 7-tap
+  layers, 45 for the stride-2 first layer on its polyphase view), fused inverse + epilogue, filter-gradient chains of
+  the narrow layers on the side stream.  Same three comparisons and the same tolerances as the W-tap kernels."""
   eng, trace = run_step(case, 'fp32', fft_conv=True)
   text = '\n'.join(trace)
   # L8 (48 bins): forward and back-prop products on the batched convolution kernel, lag products on the batched

@@ -700,6 +700,8 @@ class Wav2LetterEngine:
       del ups[:]
 
   def forward(self):
+    """X[0] -> logits X[-1] through the eleven layers (speech_model.py:279-295): per layer the frequency-domain entry
+    point, the bf16x6 kernel or the W-tap kernel, as decided per shape by `_use_fft` / `_x6_fwd`."""
     if self.conv_mode == 'bf16':
       return self._forward_bf16()
     s = self.stream_ptr

@@ -54,11 +54,15 @@ const char* st_last_error(void);
  * kernel launch naming the variant and split policy it chose (e.g. "gemm_nn<128,128,2,2,fast> epi=1
  * splits=2 M=16032 Np=256 Kp=64512").  st_trace_end copies the text to a HOST buffer (truncating) and
  * returns the bytes needed including the terminator.  Used by the parity tests to assert which kernels a
- * full-size step really ran.
+ * full-size step really ran.  Every line of a matrix-pipe launch carries "gflop=<executed GFLOP, padding included>".
+ * st_trace_begin_timed() additionally brackets every traced launch with a pair of HIP events on the launch's own
+ * stream; st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
+ * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
  * "no_fast", "bf16_tile", "bf16_wgrad_splits"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
+int st_trace_begin_timed(void);
 size_t st_trace_end(char* host_buf, size_t capacity);
 int st_set_tuning(const char* name, int value);
 /* CRC-32C of a HOST buffer, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint bundles carry
@@ -291,6 +295,8 @@ int st_comm_unique_id_bytes(void);
 int st_comm_unique_id(void* id_out, size_t id_bytes);
 int st_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);
 int st_comm_destroy(void* comm);
+/* ranks in the communicator as RCCL itself counts them (ncclCommCount): bench.py prints it beside torch.distributed's world size */
+int st_comm_count(void* comm, int* count);
 int st_allreduce_f32(void* comm, float* buf, size_t n, void* stream);
 int st_allreduce_buckets_f32(void* comm, float* base, const size_t* starts, const size_t* counts, int n_buckets,
                              void* stream);

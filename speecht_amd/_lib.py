@@ -24,6 +24,7 @@ _SIGNATURES = {
     'st_version': (c_int, []),
     'st_last_error': (c_char_p, []),
     'st_trace_begin': (c_int, []),
+    'st_trace_begin_timed': (c_int, []),
     'st_trace_end': (c_size_t, [c_char_p, c_size_t]),
     'st_set_tuning': (c_int, [c_char_p, c_int]),
     'st_host_crc32c': (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
@@ -107,6 +108,7 @@ _SIGNATURES = {
     'st_comm_unique_id': (c_int, [c_void_p, c_size_t]),
     'st_comm_init': (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p)]),
     'st_comm_destroy': (c_int, [c_void_p]),
+    'st_comm_count': (c_int, [c_void_p, POINTER(c_int)]),
     'st_allreduce_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_allreduce_buckets_f32': (c_int, [c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_int, c_void_p]),
     'st_mfcc_ws': (c_size_t, [c_int, c_int64, c_int, c_int]),
@@ -168,10 +170,18 @@ def call(name, *args):
 
 class launch_trace:
   """``with launch_trace() as tr: ...`` -> ``tr.lines``: one line per kernel launch the library made inside
-  the block, naming the variant and split policy (st_trace_begin / st_trace_end)."""
+  the block, naming the variant and split policy (st_trace_begin / st_trace_end).  ``timed=True``: every traced
+  launch is bracketed by HIP events on its own stream and its line ends in `` ms=<duration>`` (collecting the trace
+  waits for the launches)."""
+
+  def __init__(self, timed=False):
+    self.timed = timed
 
   def __enter__(self):
-    load().st_trace_begin()
+    if self.timed:
+      load().st_trace_begin_timed()
+    else:
+      load().st_trace_begin()
     self.lines = []
     return self
 

@@ -2,6 +2,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <string.h>
 
 #include "st_common.h"
@@ -15,20 +16,48 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- launch trace: which kernel variant / split policy a call took (tests assert on it) ----
-static std::atomic<int> g_trace_on{0};
+// ---- launch trace: which kernel variant / split policy a call took (tests assert on it), and -- in timed mode
+// (st_trace_begin_timed) -- how long each traced launch took on its stream inside the real launch sequence: a pair
+// of HIP events around the launch (LaunchTimer), resolved when the trace is collected.
+static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + events
 static std::mutex g_trace_mu;
-static std::string g_trace;
+static std::vector<std::string> g_lines;
+struct TimedLaunch { int line; hipEvent_t e0, e1; };
+static std::vector<TimedLaunch> g_timed;
+static thread_local int g_last_line = -1;
 bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
 void trace(const char* fmt, ...) {
   if (!trace_on()) return;
-  char line[256];
+  char line[320];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(line, sizeof(line), fmt, ap);
   va_end(ap);
   std::lock_guard<std::mutex> lock(g_trace_mu);
-  if (g_trace.size() < (1u << 20)) { g_trace += line; g_trace += '\n'; }
+  if (g_lines.size() < (1u << 16)) {
+    g_last_line = (int)g_lines.size();
+    g_lines.emplace_back(line);
+  } else {
+    g_last_line = -1;
+  }
+}
+LaunchTimer::LaunchTimer(hipStream_t s) : stream_(s), slot_(-1) {
+  if (g_trace_on.load(std::memory_order_relaxed) != 2 || g_last_line < 0) return;
+  TimedLaunch t{g_last_line, nullptr, nullptr};
+  if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
+  hipEventRecord(t.e0, s);
+  std::lock_guard<std::mutex> lock(g_trace_mu);
+  slot_ = (int)g_timed.size();
+  g_timed.push_back(t);
+}
+LaunchTimer::~LaunchTimer() {
+  if (slot_ < 0) return;
+  hipEvent_t e1;
+  {
+    std::lock_guard<std::mutex> lock(g_trace_mu);
+    e1 = g_timed[slot_].e1;
+  }
+  hipEventRecord(e1, stream_);
 }
 
 // ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
@@ -43,21 +72,42 @@ extern "C" {
 int st_version(void) { return 200; }
 const char* st_last_error(void) { return st::g_err; }
 
-int st_trace_begin(void) {
+static int trace_begin(int mode) {
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
-  st::g_trace.clear();
-  st::g_trace_on.store(1);
+  st::g_lines.clear();
+  for (auto& t : st::g_timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+  st::g_timed.clear();
+  st::g_trace_on.store(mode);
   return ST_OK;
 }
+int st_trace_begin(void) { return trace_begin(1); }
+int st_trace_begin_timed(void) { return trace_begin(2); }
 
 size_t st_trace_end(char* host_buf, size_t capacity) {
   st::g_trace_on.store(0);
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
-  const size_t need = st::g_trace.size() + 1;
+  // timed mode: wait for each launch's closing event and append its duration to its line (first collection only)
+  for (auto& t : st::g_timed) {
+    float ms = -1.f;
+    if (hipEventSynchronize(t.e1) == hipSuccess) hipEventElapsedTime(&ms, t.e0, t.e1);
+    char tail[48];
+    snprintf(tail, sizeof(tail), " ms=%.5f", ms);
+    if (t.line >= 0 && t.line < (int)st::g_lines.size()) st::g_lines[t.line] += tail;
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
+  }
+  st::g_timed.clear();
+  size_t need = 1;
+  for (const auto& l : st::g_lines) need += l.size() + 1;
   if (host_buf && capacity > 0) {
-    const size_t n = need <= capacity ? need - 1 : capacity - 1;
-    memcpy(host_buf, st::g_trace.data(), n);
-    host_buf[n] = 0;
+    size_t at = 0;
+    for (const auto& l : st::g_lines) {
+      if (at + l.size() + 1 >= capacity) break;
+      memcpy(host_buf + at, l.data(), l.size());
+      at += l.size();
+      host_buf[at++] = '\n';
+    }
+    host_buf[at] = 0;
   }
   return need;
 }

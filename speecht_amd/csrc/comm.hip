@@ -17,6 +17,7 @@ struct RcclApi {
   ncclResult_t (*get_unique_id)(ncclUniqueId*);
   ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*comm_destroy)(ncclComm_t);
+  ncclResult_t (*comm_count)(const ncclComm_t, int*);
   ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   ncclResult_t (*group_start)();
   ncclResult_t (*group_end)();
@@ -42,7 +43,7 @@ int load_rccl() {
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   bool ok = bind(h, "ncclGetUniqueId", g_rccl.get_unique_id) & bind(h, "ncclCommInitRank", g_rccl.comm_init_rank) &
-            bind(h, "ncclCommDestroy", g_rccl.comm_destroy) & bind(h, "ncclAllReduce", g_rccl.all_reduce) &
+            bind(h, "ncclCommDestroy", g_rccl.comm_destroy) & bind(h, "ncclCommCount", g_rccl.comm_count) & bind(h, "ncclAllReduce", g_rccl.all_reduce) &
             bind(h, "ncclGroupStart", g_rccl.group_start) & bind(h, "ncclGroupEnd", g_rccl.group_end) &
             bind(h, "ncclGetErrorString", g_rccl.error_string);
   if (!ok) {
@@ -90,6 +91,12 @@ int st_comm_destroy(void* comm) {
   if (!comm) return ST_OK;
   if (int e = load_rccl()) return e;
   return rccl_check(g_rccl.comm_destroy(reinterpret_cast<ncclComm_t>(comm)), "ncclCommDestroy");
+}
+
+int st_comm_count(void* comm, int* count) {
+  ST_REQUIRE(comm && count, "st_comm_count: null argument");
+  if (int e = load_rccl()) return e;
+  return rccl_check(g_rccl.comm_count(reinterpret_cast<ncclComm_t>(comm), count), "ncclCommCount");
 }
 
 int st_allreduce_f32(void* comm, float* buf, size_t n, void* stream) {

@@ -652,7 +652,9 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   p.tiles_n = st::ceil_div(p.Np, BT);
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
-  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps);
+  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps,
+            2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
+  st::LaunchTimer timer(s);
   const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
 #define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
   do {                                                                                                         \

@@ -485,6 +485,10 @@ void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start,
                 hipStream_t s) {
   const int nchunks = st::ceil_div(half, 32);
   const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks, 4));
+  const int nst = frames_used <= 6 * CH ? 3 : 4;
+  st::trace("dft_rows<%d> rows=%d chunks=%d bins=%d gflop=%.3f", nst, pl.rows, nchunks, pl.bins,
+            4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
+  st::LaunchTimer timer(s);
   if (frames_used <= 6 * CH)                                               // the matrix has no columns past frames_used
     hipLaunchKernelGGL(dft_rows_kernel<3>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
                        half, nchunks, out);
@@ -497,6 +501,10 @@ template <int TERMS>
 void launch_idft(const float* in, const float* winv, const Plan& p, int half_in, int nchunks, const RowsOut& out, const float* bias,
                  int relu, const float* mask, long mask_batch_stride, int mask_c_pitch, hipStream_t s) {
   const dim3 grid(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4)));
+  const int hp = p.bins <= 36 ? 18 : 24;
+  st::trace("idft_rows<%d,%d> rows=%d chunks=%d bins=%d gflop=%.3f", TERMS, hp, p.rows, nchunks, p.bins,
+            4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1));
+  st::LaunchTimer timer(s);
   if (p.bins <= 36)
     hipLaunchKernelGGL((idft_rows_kernel<TERMS, 18>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
                        nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);

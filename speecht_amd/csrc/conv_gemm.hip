@@ -829,14 +829,18 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.colsum_rows = p.tiles_m * WMW;
   if (p.batches > 0) p.chunk = st::ceil_div(p.batches, 8) * p.tiles_m * p.tiles_n;
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
+  const double gflop = 2e-9 * p.tiles_m * BM * (double)p.Np * p.Kp * std::max(1, p.batches);      // executed, padding included
   if (p.batches > 0)
-    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
-              p.batches, p.M, p.Np, p.Kp);
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
+              p.batches, p.M, p.Np, p.Kp, gflop);
   else
-    st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d", BM, BN, WMW, WNW,
-              FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm);
-  if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d gflop=%.3f", BM, BN, WMW, WNW,
+              FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
+  {
+    st::LaunchTimer timer(s);
+    if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
+  }
   if (p.splits > 1) {
     const long quads = (long)p.M * (p.n_store / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 4096)), dim3(256), 0, s,
@@ -924,8 +928,11 @@ int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, 
   p.adv_b = 32 / M;
   p.adv_t = 32 % M;
   p.a_batch = a_batch; p.z_batch = z_batch; p.o_batch = o_batch;
-  st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d", batches, M, K, N);
-  hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), 0, s, p);
+  st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d gflop=%.3f", batches, M, K, N, 2e-9 * M * (double)K * N * batches);
+  {
+    st::LaunchTimer timer(s);
+    hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), 0, s, p);
+  }
   return st::check_launch("gemm_tn_batched");
 }
 
@@ -1211,20 +1218,23 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
   p.amap_batches = dz->batch;
   p.adv_b = 32 / dz->frames;
   p.adv_t = 32 % dz->frames;
-  st::trace("gemm_tn<%d> slabs=%d rows_per_slab=%d M=%d Kp=%d Np=%d", p.Np % 128 == 0 ? 128 : p.Np, used,
-            p.rows_per_split, p.M, p.Kp, p.Np);
-  if (p.Np % 128 == 0) {
-    p.tiles_n = p.Np / 128;
-    hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);
-  } else if (p.Np == 64) {
-    p.tiles_n = 1;
-    hipLaunchKernelGGL((gemm_tn_kernel<64, 2, 2>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
-  } else if (p.Np == 32) {
-    p.tiles_n = 1;
-    hipLaunchKernelGGL((gemm_tn_kernel<32, 4, 1>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
-  } else {
-    st::set_error("conv bwd_filter: unsupported n_pad=%d", p.Np);
-    return ST_EINVAL;
+  st::trace("gemm_tn<%d> slabs=%d rows_per_slab=%d M=%d Kp=%d Np=%d gflop=%.3f", p.Np % 128 == 0 ? 128 : p.Np, used,
+            p.rows_per_split, p.M, p.Kp, p.Np, 2e-9 * st::round_up(p.M, 32) * (double)(p.tiles_k * 128) * p.Np);
+  {
+    st::LaunchTimer timer(s);                // the product kernel alone (what rocprofv3 lists under this symbol)
+    if (p.Np % 128 == 0) {
+      p.tiles_n = p.Np / 128;
+      hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);
+    } else if (p.Np == 64) {
+      p.tiles_n = 1;
+      hipLaunchKernelGGL((gemm_tn_kernel<64, 2, 2>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
+    } else if (p.Np == 32) {
+      p.tiles_n = 1;
+      hipLaunchKernelGGL((gemm_tn_kernel<32, 4, 1>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
+    } else {
+      st::set_error("conv bwd_filter: unsupported n_pad=%d", p.Np);
+      return ST_EINVAL;
+    }
   }
   if (int e = st::check_launch("gemm_tn")) return e;
   if (used > 1) {

@@ -13,6 +13,19 @@ void set_error(const char* fmt, ...);
 // launch trace (st_trace_begin / st_trace_end) and tuning overrides (st_set_tuning); api.hip
 bool trace_on();
 void trace(const char* fmt, ...);
+// In timed mode (st_trace_begin_timed) a pair of HIP events around the launch that follows a trace() line: the
+// line gets " ms=..." when the trace is collected.  No-op otherwise.
+class LaunchTimer {
+ public:
+  explicit LaunchTimer(hipStream_t s);
+  ~LaunchTimer();
+  LaunchTimer(const LaunchTimer&) = delete;
+  LaunchTimer& operator=(const LaunchTimer&) = delete;
+
+ private:
+  hipStream_t stream_;
+  int slot_;
+};
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
        TUNE_BF16_WGRAD_SPLITS, TUNE_COUNT };
 int tuning(int key);

@@ -100,6 +100,12 @@ class RcclCommunicator:
       stream.wait_event(self._joined)
       self._joined = None
 
+  def count(self):
+    """Number of ranks in the RCCL communicator itself (ncclCommCount), independent of torch.distributed's view."""
+    n = ctypes.c_int(0)
+    self._lib.call('st_comm_count', self._handle, ctypes.byref(n))
+    return n.value
+
   def close(self):
     if self._handle:
       self._lib.call('st_comm_destroy', self._handle)

@@ -123,6 +123,7 @@ class _StagedHostBatch:
     self.event = torch.cuda.Event()
     self.consumed = torch.cuda.Event()
     self.consumed.record()
+    self.taken = True             # handed to load_batch (host-side state; `consumed` is the device-side one)
 
 
 class Wav2LetterEngine:
@@ -390,6 +391,11 @@ class Wav2LetterEngine:
           self._gfwd_fresh = False
       f['xref'] = ctypes.byref(f['x'])
       tables, fresh_tables = view('tables', lib.st_conv1d_fft_table_floats())
+      # the tables are functions of (taps, left padding): a new shape or another model may change either for the same
+      # layer index, so the pair is kept with them
+      if getattr(self, '_fft_table_key', {}).get(i) != (f['width'], f['pl']):
+        fresh_tables = True
+      self.__dict__.setdefault('_fft_table_key', {})[i] = (f['width'], f['pl'])
       gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(f['width'], f['cin_pitch'], f['cin'], l.cout, 0))
       gbwd, fresh_b = (view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1)) if i > 0
                        else (None, False))
@@ -634,6 +640,7 @@ class Wav2LetterEngine:
     self._ensure_shape(B, T)
     self.X[0].interior().copy_(x.to(torch.float32), non_blocking=True)
     if staged is not None and hasattr(staged, 'consumed'):
+      staged.taken = True
       staged.consumed.record(self._stream if self._stream is not None else torch.cuda.current_stream(self.device))
     self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
     # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
@@ -652,11 +659,15 @@ class Wav2LetterEngine:
     if x.dtype != torch.float32:
       x = x.to(torch.float32)
     slot = h['slots'][h['turn']]
+    if slot is not None and not slot.taken:
+      # two staging buffers: a third batch staged before the first was handed to load_batch would overwrite it
+      raise RuntimeError('stage_host_batch: both staging buffers hold batches that load_batch has not consumed yet')
     if slot is None or slot.tensor.shape != x.shape:
       if slot is not None:
         slot.consumed.synchronize()
       slot = _StagedHostBatch(torch.empty(x.shape, dtype=torch.float32, device=self.device))
       h['slots'][h['turn']] = slot
+    slot.taken = False
     with torch.cuda.stream(h['stream']):
       h['stream'].wait_event(slot.consumed)            # the compute stream is done reading this buffer
       slot.tensor.copy_(x, non_blocking=True)
@@ -781,10 +792,22 @@ class Wav2LetterEngine:
     ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
     # tf.nn.ctc_loss raises InvalidArgument for a label outside [0, num_classes - 1); the kernels index LDS with
     # the id, so it must never reach them (vocabulary.letter_to_id maps e.g. a digit to a negative id)
+    self._rejected_labels = []
     if ids.size > 1 and (int(ids.min()) < 0 or int(ids.max()) >= self.num_classes - 1):
       bad = [b for b, l in enumerate(label_list) if len(l) and (min(l) < 0 or max(l) >= self.num_classes - 1)]
-      raise ValueError('label ids must lie in [0, {}) (blank = {}); offending utterances: {}'.format(
-          self.num_classes - 1, self.num_classes - 1, bad))
+      if not getattr(self, 'defer_label_errors', False):
+        raise ValueError('label ids must lie in [0, {}) (blank = {}); offending utterances: {}'.format(
+            self.num_classes - 1, self.num_classes - 1, bad))
+      # Data-parallel training (set by SpeechModel.enable_data_parallel): raising here, on this rank only, would leave
+      # the other ranks waiting in the gradient all-reduce.  The offending utterances get an empty label (nothing
+      # out of range reaches a kernel) and a status word of their own after the CTC call; the status count travels
+      # with the gradients, every rank's update is gated off together and every rank raises in fetch_losses.
+      self._rejected_labels = bad
+      label_list = [[] if b in bad else l for b, l in enumerate(label_list)]
+      lens = [len(l) for l in label_list]
+      offs[1:] = np.cumsum(lens)
+      self.max_label_len = int(max(lens + [0]))
+      ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
     self.label_ids = self._upload_i32(ids)
     self.label_offs = self._upload_i32(offs)
 
@@ -842,6 +865,10 @@ class Wav2LetterEngine:
     call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
          self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
+    if getattr(self, '_rejected_labels', None):            # labels refused on the host (deferred mode): status 2
+      stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+      with torch.cuda.stream(stream):
+        self.ctc_status.index_fill_(0, torch.as_tensor(self._rejected_labels, dtype=torch.int64).to(self.device, non_blocking=True), 2)
     call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
 
   def _refresh_backward_operands(self):
@@ -1068,9 +1095,13 @@ class Wav2LetterEngine:
       # the gated Adam kernel enqueued behind this CTC evaluation was a no-op: take its step count back so that
       # the bias correction stays in step with the updates that really happened
       self.step_count -= min(skipped, 1)
+      if (st == 2).any():
+        raise ValueError('label ids must lie in [0, {}) (blank = {}); offending utterances: {}'.format(
+            self.num_classes - 1, self.num_classes - 1, np.nonzero(st == 2)[0].tolist()))
       if st.any():
         raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))
-      raise ValueError('Not enough time for target transition sequence ({:g} utterance(s) on other ranks)'.format(float(gate_h[0])))
+      raise ValueError('batch rejected: {:g} utterance(s) on other ranks had no valid CTC alignment or out-of-range label ids'
+                       .format(float(gate_h[0])))
     return loss_h[:B].numpy().copy()
 
   def check_ctc_status(self):

@@ -105,12 +105,25 @@ class Evaluation(execution.DatasetExecutor):
     else:
       label_rows = self.extract_decoded_ids(label)
       path_iters = [self.extract_decoded_ids(path) for path in decoded]
+      # the quirk, said out loud: every utterance that decoded to the empty string (routine for early checkpoints)
+      # shifts the pairs behind it, and the walk ends early when the decodings run out
+      empty = sum(1 for path in decoded for row in self.rows_by_batch(path) if not row)
+      if empty:
+        print('warning: {} decoding(s) of this batch are empty; the reference pairing (evaluation.py:144-151) skips them, '
+              'so later expected/decoded pairs are shifted -- pass --pair-by-row to pair by utterance'.format(empty))
     for label_ids in label_rows:
       expected = vocabulary.ids_to_sentence(label_ids)
       if verbose:
         print('expected: {}'.format(expected))
       for path in path_iters:
-        hypothesis = vocabulary.ids_to_sentence(next(path))
+        try:
+          ids = next(path)
+        except StopIteration:
+          # the reference dies here with a bare StopIteration out of run_step; same outcome, with the reason
+          raise RuntimeError('ran out of decodings before labels: an utterance of this batch decoded to the empty string and '
+                             'the reference\'s lock-step pairing (evaluation.py:144-151) cannot continue; '
+                             'use --pair-by-row') from None
+        hypothesis = vocabulary.ids_to_sentence(ids)
         stats.track_decoding(hypothesis, expected)
         if verbose:
           print('decoded: {}'.format(hypothesis))

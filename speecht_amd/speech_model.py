@@ -123,8 +123,11 @@ class _Saver:
 
   # ---- the reference's own format: TensorFlow V2 bundles (tf.train.Saver, speech_model.py:122) --------------------
   def save_tf(self, sess, save_path, global_step=None):
-    """``<save_path>-<step>.index`` / ``.data-00000-of-00001`` + TF's text ``checkpoint`` file, with the reference's
-    variable names, so that the reference (or anything that reads TF checkpoints) can restore this model."""
+    """``<save_path>-<step>.index`` / ``.data-00000-of-00001`` + TF's text ``checkpoint`` file under the variable names
+    the reference graph's Saver looks up (``tf_checkpoint.reference_variable_names``: Adam's beta powers live under the
+    ``training/`` name scope, everything else is unscoped), so that anything that reads TF checkpoints can load this
+    model.  Restoring into the reference itself is the intent and follows from TF 1.x naming rules, but has not been
+    tried against a TensorFlow installation (none is available here)."""
     from . import tf_checkpoint as tfc
     step = global_step.eval() if hasattr(global_step, 'eval') else global_step
     path = '{}-{}'.format(save_path, step) if step is not None else save_path
@@ -137,11 +140,14 @@ class _Saver:
     tensors = {'Variable': np.array(self.model.global_step.eval(), dtype=np.int32),
                'learning_rate': np.array(self.model.learning_rate.eval() if hasattr(self.model, 'learning_rate') else 0.0,
                                          dtype=np.float32),
-               'beta1_power': np.array(0.9 ** (t + 1), dtype=np.float32), 'beta2_power': np.array(0.999 ** (t + 1), dtype=np.float32)}
+               # Adam's non-slot accumulators are tf.Variables made inside tf.name_scope('training') (speech_model.py:72-82)
+               'training/beta1_power': np.array(0.9 ** (t + 1), dtype=np.float32),
+               'training/beta2_power': np.array(0.999 ** (t + 1), dtype=np.float32)}
     for i, ((F, b), (mF, mb), (vF, vb)) in enumerate(zip(weights, m, v)):
       scope = 'convolution_layer_{}'.format(i)
       tensors.update({scope + '/filters': F, scope + '/bias': b, scope + '/filters/Adam': mF, scope + '/bias/Adam': mb,
                       scope + '/filters/Adam_1': vF, scope + '/bias/Adam_1': vb})
+    assert set(tensors) == tfc.reference_variable_names(len(weights)), sorted(set(tensors) ^ tfc.reference_variable_names(len(weights)))
     tfc.write_bundle(path, tensors)
     directory = os.path.dirname(path) or '.'
     state = tfc.read_checkpoint_state(directory)
@@ -315,6 +321,9 @@ class SpeechModel:
     eng = self.engine
     self._rank = dist.get_rank(group) if dist.is_initialized() else 0
     self._reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, group) if self._world > 1 else None
+    # a label the host refuses must not raise on one rank while the others wait in the all-reduce: it becomes a status
+    # word that travels with the gradients, and every rank raises together after the step (engine.set_labels)
+    eng.defer_label_errors = self._world > 1
     if self._world > 1:
       # Only gradients are exchanged afterwards, so the replicas must START identical: rank 0's weights, Adam
       # moments, step counters and learning rate go to everyone (init_session draws an unseeded Xavier sample

@@ -346,6 +346,22 @@ def write_checkpoint_state(directory, latest, all_paths):
 _LAYER_VAR = re.compile(r'^(?:.*/)?convolution_layer_(\d+)/(filters|bias)(?:/(Adam|Adam_1))?$')
 
 
+def reference_variable_names(n_layers):
+  """The names ``tf.train.Saver(tf.global_variables())`` of the reference graph expects (speech_model.py:41,65,72-82,
+  122,148-152), as TF 1.x naming rules give them: ``get_variable`` variables and the Adam slots derived from their
+  names ignore ``tf.name_scope``; ``tf.Variable``-created ones honour it -- the unnamed ``Variable`` (global_step,
+  built outside any scope), ``learning_rate`` (outside), and Adam's non-slot accumulators, which
+  ``apply_gradients`` creates inside ``tf.name_scope('training')``: ``training/beta1_power`` / ``training/beta2_power``.
+  NOT checked against a TensorFlow installation (none exists here): restated from TF 1.1's optimizer /
+  slot_creator naming; ``Saver.restore`` raises NotFound for a missing key, so this set is what ``save_tf`` writes."""
+  names = {'Variable', 'learning_rate', 'training/beta1_power', 'training/beta2_power'}
+  for i in range(n_layers):
+    for var in ('filters', 'bias'):
+      base = 'convolution_layer_{}/{}'.format(i, var)
+      names.update({base, base + '/Adam', base + '/Adam_1'})
+  return names
+
+
 def split_variables(tensors):
   """Sort a speechT checkpoint's variables: ({layer: {('filters'|'bias', None|'Adam'|'Adam_1'): array}}, scalars).
   Names (speech_model.py): ``convolution_layer_<i>/filters`` [W, Cin, Cout] and ``.../bias`` [Cout] (:148-152), their

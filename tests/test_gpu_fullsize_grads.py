@@ -8,7 +8,8 @@ which agrees with the numpy oracle to 1e-13, tests/test_oracle_conv_ctc.py::test
 The launch trace of the library is asserted so that the test cannot silently take the small-problem kernels.
 
 Tolerances: logits <= 1e-4 absolute, loss <= 1e-4 relative, d loss / d logits and every
-gradient tensor <= 2e-4 of its own max (see ``compare`` for how the ReLU discontinuity is handled)."""
+gradient tensor <= 2e-4 of its own max -- kernel by kernel on the device's operands AND end to end against an
+independent float64 evaluation with the ReLU pattern pinned to the device's (``compare``)."""
 import time
 
 import numpy as np
@@ -64,12 +65,14 @@ def compare(eng, ref, case, grad_tol=2e-4):
   2. the BACKWARD KERNELS at full size: all 22 gradient tensors against float64 back-prop evaluated on the
      device's own stored activations and its own dlogits (tests/torch_ref.backward_from_acts) -- the exact linear
      map the kernels must reproduce, tolerance 2e-4 of each tensor's max;
-  3. end to end against the fully independent reference gradients.  The step has one discontinuity: a ReLU input
-     within rounding of zero lands on different sides in fp32 and float64 (about one element in 10^7-10^8; the
-     flipped unit's whole gradient appears or vanishes).  Such a flip at the output of layer k perturbs the filter
-     gradients of layers <= k far above rounding level (L0 is the worst conditioned: its gradient is a sum over
-     16 032 frames that cancels to ~1/100 of its terms), so layers above the highest flip keep the 2e-4 bound and
-     layers at or below it get a loose sanity bound; with no flip every layer keeps 2e-4."""
+  3. END TO END, all 22 tensors at the same 2e-4: against a second float64 evaluation of the whole step (its own
+     forward activations from the inputs, its own CTC, autograd) whose ReLU pattern is pinned to the one the device
+     took (tests/torch_ref.loss_and_grads(relu_masks=...)).  The step has one discontinuity -- a ReLU input within
+     fp32 rounding of zero lands on the other side in float64 (1-10 of 4-32 million elements per layer; the flipped
+     unit's whole gradient appears or vanishes and the ill-conditioned lower layers amplify it) -- and pinning the
+     pattern removes exactly that and nothing else: the pinned pre-activations differ from the free ones by < 1e-6
+     at the flipped elements (asserted through the logits), every other number is independent of the device.
+     The un-pinned end-to-end figures are printed for the record."""
   logits = eng.logits_time_major().cpu().numpy()
   assert logits.shape == ref['logits'].shape == (501, 32, 29)
   # frames beyond an utterance's own length are computed too (nothing is masked, SURVEY F7): compare all
@@ -81,23 +84,35 @@ def compare(eng, ref, case, grad_tol=2e-4):
   assert dl_err < 2e-4, dl_err
   acts = [eng.X[i].interior().cpu().numpy() for i in range(len(eng.layers) + 1)]
   flips = [int(np.sum((acts[i] > 0) != (ref['acts'][i] > 0))) for i in range(1, len(eng.layers))]   # ReLU outputs
-  top_flip = max([i for i, n in enumerate(flips) if n] + [-1])       # index of the highest layer whose output flipped
   got = eng.get_grads()
   exact, _ = TR.backward_from_acts(acts, case['params'], case['layers'], dl)
-  kernel_report, e2e_report, failed = [], [], []
-  for i, ((gF, gb), (xF, xb), (rF, rb)) in enumerate(zip(got, exact, ref['grads'])):
-    for name, g, x, r in (('filters', gF, xF, rF), ('bias', gb, xb, rb)):
-      assert g.shape == x.shape == r.shape
-      k, e = rel_err(g, x), rel_err(g, r)
+  t0 = time.time()
+  pinned = TR.loss_and_grads(case['x'], case['seq'], case['labels'], case['params'], case['layers'], dtype=torch.float64,
+                             relu_masks=TR.relu_masks_of(acts, case['layers']))
+  pin_secs = time.time() - t0
+  # the pinned evaluation is the same function as the free one except at the flipped units, whose pre-activations are
+  # within rounding of zero: logits and losses agree far below the parity tolerance
+  pin_shift = float(np.max(np.abs(pinned['logits'] - ref['logits'])))
+  assert pin_shift < 1e-5, pin_shift
+  assert float(np.max(np.abs(logits - pinned['logits']))) < 1e-4
+  np.testing.assert_allclose(eng.loss.cpu().numpy(), pinned['loss'], rtol=1e-4)
+  kernel_report, e2e_report, free_report, failed = [], [], [], []
+  for i, ((gF, gb), (xF, xb), (pF, pb), (rF, rb)) in enumerate(zip(got, exact, pinned['grads'], ref['grads'])):
+    for name, g, x, p, r in (('filters', gF, xF, pF, rF), ('bias', gb, xb, pb, rb)):
+      assert g.shape == x.shape == p.shape == r.shape
+      k, e, f = rel_err(g, x), rel_err(g, p), rel_err(g, r)
       kernel_report.append('L%d %s %.1e' % (i, name, k))
       e2e_report.append('L%d %s %.1e' % (i, name, e))
+      free_report.append('L%d %s %.1e' % (i, name, f))
       if not k < grad_tol:
         failed.append('kernel L%d %s %.2e' % (i, name, k))
-      if not e < (grad_tol if i > top_flip else 5e-2):
-        failed.append('end-to-end L%d %s %.2e' % (i, name, e))
+      if not e < grad_tol:
+        failed.append('end-to-end (ReLU pattern pinned) L%d %s %.2e' % (i, name, e))
   print('dlogits error %.2e of max; ReLU sign flips vs float64 per layer output: %s' % (dl_err, flips))
   print('backward kernels vs float64 back-prop on the device activations: ' + '; '.join(kernel_report))
-  print('end to end vs float64 autograd: ' + '; '.join(e2e_report))
+  print('end to end vs float64 autograd with the device\'s ReLU pattern (%.1f s, logits moved %.1e by the pinning): '
+        % (pin_secs, pin_shift) + '; '.join(e2e_report))
+  print('for the record, end to end vs the free float64 autograd (flipped units included): ' + '; '.join(free_report))
   assert not failed, failed
   return err, dl_err
 

@@ -95,8 +95,9 @@ def test_editdistance_and_eval_statistics():
 
 def test_run_step_pairs_like_the_reference_by_default():
   """evaluation.py:144-151: labels and decodings are walked with extract_decoded_ids in lock-step, so an utterance
-  that decodes to the empty string shifts the later pairings and the walk ends in StopIteration when the decodings
-  run out first; flags.pair_by_row (extension, --pair-by-row) pairs by batch row."""
+  that decodes to the empty string shifts the later pairings and the walk ends when the decodings run out first (the
+  reference: a bare StopIteration out of run_step; here the same abort as a RuntimeError that says why, after a
+  warning that names the empty decodings); flags.pair_by_row (extension, --pair-by-row) pairs by batch row."""
   import types
   from speecht_amd.evaluation import Evaluation, EvalStatistics
   from speecht_amd.speech_input import SparseTensorValue
@@ -113,7 +114,7 @@ def test_run_step_pairs_like_the_reference_by_default():
   ev = Evaluation.__new__(Evaluation)
   ev.flags = types.SimpleNamespace(pair_by_row=False)
   stats = EvalStatistics()
-  with pytest.raises(StopIteration):                   # label 'ef' finds no third decoding
+  with pytest.raises(RuntimeError, match='ran out of decodings'):      # label 'ef' finds no third decoding
     ev.run_step(model, None, stats, save=False, verbose=False)
   assert stats.decodings_counter == 2 and stats.sum_letter_edit_distance == 0 + 2     # 'ab'~'ab', 'cd'~'ef'
   ev.flags.pair_by_row = True

@@ -273,6 +273,32 @@ def test_torch_ref_equals_oracle():
     np.testing.assert_allclose(gb, rb, rtol=0, atol=1e-11 * np.max(np.abs(rb)) + 1e-300)
 
 
+def test_torch_ref_with_pinned_relu_pattern():
+  """``loss_and_grads(relu_masks=...)`` (the end-to-end reference of tests/test_gpu_fullsize_grads.py): with the masks of
+  its own forward pass it IS the free evaluation; with one unit's mask flipped it is the same network with that unit
+  forced -- the gradient of a forced-off unit's incoming filter column vanishes, everything stays finite."""
+  from tests import torch_ref as TR
+  from tests import workloads as WL
+  layers = WL.w2l_layers(16, width=24, fc=40)
+  params = WL.xavier_params(layers, seed=5)
+  x, seq, labels = WL.make_batch([75, 61, 40], 16, seed=4)
+  free = TR.loss_and_grads(x, seq, labels, params, layers, dtype=torch.float64)
+  masks = TR.relu_masks_of(free['acts'], layers)
+  assert masks[-1] is None and all(m is not None and m.dtype == bool for m in masks[:-1])
+  pinned = TR.loss_and_grads(x, seq, labels, params, layers, dtype=torch.float64, relu_masks=masks)
+  np.testing.assert_allclose(pinned['logits'], free['logits'], rtol=0, atol=1e-13)
+  np.testing.assert_allclose(pinned['loss'], free['loss'], rtol=1e-13)
+  for (gF, gb), (rF, rb) in zip(pinned['grads'], free['grads']):
+    np.testing.assert_allclose(gF, rF, rtol=0, atol=1e-12 * np.max(np.abs(rF)) + 1e-300)
+    np.testing.assert_allclose(gb, rb, rtol=0, atol=1e-12 * np.max(np.abs(rb)) + 1e-300)
+  # channel 3 of layer 2 forced off everywhere: no gradient reaches its filter column or its bias
+  forced = [None if m is None else m.copy() for m in masks]
+  forced[2][:, :, 3] = False
+  off = TR.loss_and_grads(x, seq, labels, params, layers, dtype=torch.float64, relu_masks=forced)
+  assert np.all(off['grads'][2][0][:, :, 3] == 0.0) and off['grads'][2][1][3] == 0.0
+  assert np.max(np.abs(off['grads'][2][0][:, :, 4])) > 0.0 and np.isfinite(off['avg_loss'])
+
+
 @pytest.mark.parametrize('T,W,cin,cout', [(37, 48, 5, 4), (40, 48, 3, 6), (21, 6, 4, 3), (22, 7, 2, 5)])
 def test_stride2_conv_is_a_stride1_conv_on_frame_pairs(T, W, cin, cout):
   """The identity behind the engine's polyphase first layer (engine._polyphase): a stride-2 'SAME'

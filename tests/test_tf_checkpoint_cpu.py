@@ -94,6 +94,24 @@ def test_bundle_round_trip_and_reference_variable_names(tmp_path):
     tfc.read_bundle(prefix)
 
 
+def test_reference_graph_variable_names():
+  """The key set ``save_tf`` writes (speecht_amd/speech_model.py asserts it equals this): one line per variable of the
+  reference graph.  get_variable names and their Adam slots carry no name scope (speech_model.py:148-152), the
+  tf.Variable-built ones do -- global_step and learning_rate are built outside any scope (:41,:65), Adam's
+  beta powers inside tf.name_scope('training') (:72-82)."""
+  names = tfc.reference_variable_names(11)
+  assert len(names) == 4 + 11 * 6
+  assert {'Variable', 'learning_rate', 'training/beta1_power', 'training/beta2_power'} <= names
+  assert 'beta1_power' not in names and 'training/learning_rate' not in names
+  assert {'convolution_layer_0/filters', 'convolution_layer_10/bias', 'convolution_layer_8/filters/Adam',
+          'convolution_layer_8/bias/Adam_1'} <= names
+  assert not any(n.startswith('training/convolution_layer') for n in names)
+  # and the reader sorts exactly these back into layers + scalars
+  layers, scalars = tfc.split_variables({n: np.zeros(1, np.float32) for n in names})
+  assert sorted(layers) == list(range(11)) and all(len(v) == 6 for v in layers.values())
+  assert set(scalars) == {'Variable', 'learning_rate', 'beta1_power', 'beta2_power'}
+
+
 def test_checkpoint_state_file_and_latest_checkpoint(tmp_path):
   from speecht_amd.speech_model import latest_checkpoint
   d = tmp_path / 'train'

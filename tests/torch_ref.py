@@ -28,14 +28,18 @@ def make_params(params, dtype, requires_grad=True):
   return out
 
 
-def forward(x, tparams, layers, keep=None):
+def forward(x, tparams, layers, keep=None, relu_masks=None):
   """x [B,T,Cin] torch -> logits [B,T',C] (channels-last like the reference).  ``keep``: a list that receives
-  every layer's output [B,T_i,C_i] (detached numpy)."""
+  every layer's output [B,T_i,C_i] (detached numpy).  ``relu_masks``: one boolean [B,T_i,C_i] array per layer (None for
+  a layer without ReLU): the activation becomes ``h * mask`` instead of ``relu(h)`` -- the network with its ReLU
+  pattern pinned, a smooth (piecewise-linear -> linear) function of inputs and weights."""
   h = x.permute(0, 2, 1)
-  for (w, b), (W, s, cin, cout, relu) in zip(tparams, layers):
+  for i, ((w, b), (W, s, cin, cout, relu)) in enumerate(zip(tparams, layers)):
     _, pl, pr = same_padding(h.shape[2], W, s)
     h = F.conv1d(F.pad(h, (pl, pr)), w, b, stride=s)
-    if relu:
+    if relu and relu_masks is not None:
+      h = h * torch.as_tensor(np.asarray(relu_masks[i]), dtype=h.dtype).permute(0, 2, 1)
+    elif relu:
       h = torch.relu(h)
     if keep is not None:
       keep.append(h.detach().permute(0, 2, 1).numpy())
@@ -70,16 +74,21 @@ def backward_from_acts(acts, params, layers, dlogits, dtype=torch.float64):
   return grads, dzs
 
 
-def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, threads=None):
+def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, threads=None, relu_masks=None):
   """One forward + CTC + backward.  Returns dict(logits [T',B,C], loss [B], avg_loss,
   grads [(dF [W,Cin,Cout], db [Cout])], acts (input + every layer output, [B,T_i,C_i]), dlogits [B,T',C]) as
-  numpy -- gradients of avg_loss = mean_b loss_b."""
+  numpy -- gradients of avg_loss = mean_b loss_b.
+
+  ``relu_masks`` (see ``forward``) pins the ReLU pattern, e.g. to the one the device took (``relu_masks_of``): the step's
+  only discontinuity -- a pre-activation within fp32 rounding of zero that lands on the other side in float64 and
+  switches a unit's whole gradient on or off -- is then out of the comparison, and what remains is a fully independent
+  float64 evaluation (own forward activations, own CTC, autograd) of the same piecewise-linear branch."""
   if threads:
     torch.set_num_threads(threads)
   tparams = make_params(params, dtype)
   xt = torch.tensor(np.asarray(x), dtype=dtype)
   acts = []
-  logits = forward(xt, tparams, layers, keep=acts)            # [B, T', C]
+  logits = forward(xt, tparams, layers, keep=acts, relu_masks=relu_masks)            # [B, T', C]
   logits.retain_grad()
   tm = logits.permute(1, 0, 2)
   lens = torch.as_tensor(np.asarray(seq_lens) // 2, dtype=torch.long)
@@ -94,6 +103,12 @@ def loss_and_grads(x, seq_lens, labels, params, layers, dtype=torch.float64, thr
   return dict(logits=tm.detach().numpy().astype(np.float64), loss=per_utt.detach().numpy().astype(np.float64),
               avg_loss=float(avg.detach()), grads=grads, acts=[np.asarray(x)] + acts,
               dlogits=logits.grad.numpy().astype(np.float64))
+
+
+def relu_masks_of(acts, layers):
+  """The ReLU pattern of a forward pass: acts[i + 1] = stored output of layer i ([B,T_i,C_i]) -> one boolean mask per
+  layer (None where the layer has no ReLU), in the form ``forward(relu_masks=...)`` takes."""
+  return [(np.asarray(acts[i + 1]) > 0) if layers[i][4] else None for i in range(len(layers))]
 
 
 class TorchCpuTrainer:

@@ -35,16 +35,23 @@ def _plan(features, batch_size, bucket):
   return lengths, buckets
 
 
-def transcribe(engine, features, batch_size=64, bucket=True, pipeline=True):
+# Whether `transcribe` overlaps host staging / read-back with the GPU by default.  Decided by measurement
+# (scripts/bench_inference.py, profiles/r3_inference_config3_*.json: 2 048 utterances, windows >= 0.5 s, median of 5).
+DEFAULT_PIPELINE = True
+
+
+def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None):
   """features: list of [T_i, input_size] arrays.  Returns (list of id lists, list of strings) in the
   input order, decoded greedily (speech_model.py:113-115) batch by batch.
 
-  pipeline=True (default) overlaps the three stages of consecutive batches: a stager thread pads batch k+1
+  pipeline=True (default: ``DEFAULT_PIPELINE``) overlaps the three stages of consecutive batches: a stager thread pads batch k+1
   into pinned host memory and copies it to the device on its own stream while the GPU runs batch k, and the
   transcripts of batch k are read back (pinned, asynchronous) after batch k+1 has been enqueued.  Same
   launches on the same data as the serial loop, hence identical ids."""
   if not features:
     return [], []
+  if pipeline is None:
+    pipeline = DEFAULT_PIPELINE
   lengths, buckets = _plan(features, batch_size, bucket)
   ids_out = [None] * len(features)
   if not pipeline:
@@ -83,6 +90,7 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=True):
   return ids_out, [vocabulary.ids_to_sentence(s) for s in ids_out]
 
 
+_STREAMS = {}      # device -> the stagers' copy stream
 _PINNED = {}       # (device, depth) -> ring of pinned staging buffers, grow-only
 _PIPELINE_LOCK = threading.Lock()
 
@@ -97,7 +105,8 @@ class _Stager(threading.Thread):
     self.torch = torch
     self.device, self.features, self.lengths, self.buckets = device, features, lengths, buckets
     self.queue = queue.Queue(maxsize=depth)
-    self.stream = torch.cuda.Stream(device)
+    # one copy stream per device for the life of the process (creating a stream per call costs the short pools)
+    self.stream = _STREAMS.get(str(device)) or _STREAMS.setdefault(str(device), torch.cuda.Stream(device))
     # [pinned buffer, event of its last H2D]; the buffers outlive the call (pinning host memory costs
     # milliseconds and synchronises the device) and are sized for the largest batch of the plan up front
     self.ring = _PINNED.setdefault((str(device), depth), [[None, None] for _ in range(depth + 2)])

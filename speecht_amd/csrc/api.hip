@@ -19,11 +19,12 @@ void set_error(const char* fmt, ...) {
 // ---- launch trace: which kernel variant / split policy a call took (tests assert on it), and -- in timed mode
 // (st_trace_begin_timed) -- how long each traced launch took on its stream inside the real launch sequence: a pair
 // of HIP events around the launch (LaunchTimer), resolved when the trace is collected.
-static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + events
+static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + device time stamps
 static std::mutex g_trace_mu;
 static std::vector<std::string> g_lines;
-struct TimedLaunch { int line; hipEvent_t e0, e1; };
-static std::vector<TimedLaunch> g_timed;
+constexpr int kMaxTimed = 1 << 15;
+static unsigned long long* g_stamps = nullptr;     // device: begin[kMaxTimed] (all ones) | end[kMaxTimed] (zeros)
+static std::vector<int> g_timed_line;              // slot -> trace line
 static thread_local int g_last_line = -1;
 bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
 void trace(const char* fmt, ...) {
@@ -41,29 +42,19 @@ void trace(const char* fmt, ...) {
     g_last_line = -1;
   }
 }
-LaunchTimer::LaunchTimer(hipStream_t s) : stream_(s), slot_(-1) {
+LaunchTimer::LaunchTimer(hipStream_t) : stamp_{nullptr, nullptr} {
   if (g_trace_on.load(std::memory_order_relaxed) != 2 || g_last_line < 0) return;
-  TimedLaunch t{g_last_line, nullptr, nullptr};
-  if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
-  hipEventRecord(t.e0, s);
   std::lock_guard<std::mutex> lock(g_trace_mu);
-  slot_ = (int)g_timed.size();
-  g_timed.push_back(t);
-}
-LaunchTimer::~LaunchTimer() {
-  if (slot_ < 0) return;
-  hipEvent_t e1;
-  {
-    std::lock_guard<std::mutex> lock(g_trace_mu);
-    e1 = g_timed[slot_].e1;
-  }
-  hipEventRecord(e1, stream_);
+  if (!g_stamps || (int)g_timed_line.size() >= kMaxTimed) return;
+  const int slot = (int)g_timed_line.size();
+  g_timed_line.push_back(g_last_line);
+  stamp_ = Stamp{g_stamps + slot, g_stamps + kMaxTimed + slot};
 }
 
 // ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
 // the launch path reads plain ints (no environment look-ups).
 static const char* const kTuneNames[TUNE_COUNT] = {"gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm", "no_fast",
-                                                   "bf16_tile", "bf16_wgrad_splits"};
+                                                   "bf16_tile", "bf16_wgrad_splits", "bf16_sched"};
 static std::atomic<int> g_tune[TUNE_COUNT];
 int tuning(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 }  // namespace st
@@ -75,8 +66,22 @@ const char* st_last_error(void) { return st::g_err; }
 static int trace_begin(int mode) {
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
   st::g_lines.clear();
-  for (auto& t : st::g_timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
-  st::g_timed.clear();
+  st::g_timed_line.clear();
+  if (mode == 2) {
+    // the stamp slots: allocated on first use and kept (diagnostics only; no launch path allocates)
+    if (!st::g_stamps && hipMalloc(&st::g_stamps, 2 * st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess) {
+      st::g_stamps = nullptr;
+      st::set_error("st_trace_begin_timed: cannot allocate the stamp buffer");
+      return ST_ELAUNCH;
+    }
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemset(st::g_stamps, 0xFF, st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(st::g_stamps + st::kMaxTimed, 0, st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+      st::set_error("st_trace_begin_timed: cannot clear the stamp buffer");
+      return ST_ELAUNCH;
+    }
+  }
   st::g_trace_on.store(mode);
   return ST_OK;
 }
@@ -86,17 +91,26 @@ int st_trace_begin_timed(void) { return trace_begin(2); }
 size_t st_trace_end(char* host_buf, size_t capacity) {
   st::g_trace_on.store(0);
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
-  // timed mode: wait for each launch's closing event and append its duration to its line (first collection only)
-  for (auto& t : st::g_timed) {
-    float ms = -1.f;
-    if (hipEventSynchronize(t.e1) == hipSuccess) hipEventElapsedTime(&ms, t.e0, t.e1);
-    char tail[48];
-    snprintf(tail, sizeof(tail), " ms=%.5f", ms);
-    if (t.line >= 0 && t.line < (int)st::g_lines.size()) st::g_lines[t.line] += tail;
-    hipEventDestroy(t.e0);
-    hipEventDestroy(t.e1);
+  // timed mode: wait for the device, read the stamps back and append each launch's duration to its line (once)
+  if (!st::g_timed_line.empty() && st::g_stamps) {
+    const size_t n = st::g_timed_line.size();
+    std::vector<unsigned long long> b(n), e(n);
+    int rate_khz = 0, dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+    if (rate_khz <= 0) rate_khz = 100000;                                   // s_memrealtime: 100 MHz
+    const bool ok = hipDeviceSynchronize() == hipSuccess &&
+                    hipMemcpy(b.data(), st::g_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(e.data(), st::g_stamps + st::kMaxTimed, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+    for (size_t i = 0; i < n; ++i) {
+      const int line = st::g_timed_line[i];
+      const double ms = (ok && e[i] >= b[i] && b[i] != ~0ull) ? (double)(e[i] - b[i]) / rate_khz : -1.0;
+      char tail[48];
+      snprintf(tail, sizeof(tail), " ms=%.5f", ms);
+      if (line >= 0 && line < (int)st::g_lines.size()) st::g_lines[line] += tail;
+    }
+    st::g_timed_line.clear();
   }
-  st::g_timed.clear();
   size_t need = 1;
   for (const auto& l : st::g_lines) need += l.size() + 1;
   if (host_buf && capacity > 0) {

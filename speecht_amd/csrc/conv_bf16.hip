@@ -232,6 +232,7 @@ struct X6Params {
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
   int tiles_m, tiles_n, chunk;
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+  st::Stamp stamp;                       // timed launch trace: device-side begin / end of this launch (null otherwise)
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -245,7 +246,16 @@ struct X6Params {
 // matrix pipe idles for the whole burst.
 // FAST = every reduction stage is whole (channel pitch / reduction length a multiple of BK): DMA sources are a
 // per-lane pointer plus the uniform k0 (no clamps) and every stage runs all its MFMA k-steps (no tail test).
-template <int BT, int WM, int WN, int BK, int NP, int ST = 2, bool PP = false, bool FAST = false>
+// SCH = 1 (round 3; 256 x 256 tile, FOUR waves = one per SIMD, 128 x 128 per wave, NP = 1, BK = 32, FAST): the wave
+// interleaves its own fragment reads and DMA pieces between its MFMAs instead of sharing the SIMD with a partner wave.
+// Why: in ping-pong every LDS / DMA instruction of the reading wave is issued beside the partner's streaming MFMAs and
+// costs ~100+ cycles there (PMC, DESIGN 4.3: matrix pipe 44 % busy, the read phase twice the MFMA phase); one wave per
+// SIMD hides up to ~5 single-issue instructions in each 32-cycle MFMA shadow (MI355X_MICROARCH.md), and the 128 x 128
+// wave tile needs 0.5 fragment reads + 0.25 DMA pieces per MFMA instead of 0.75 + 0.25.  The stage is software
+// pipelined across the per-stage barrier: the fragments of k-step 0 of stage kt + 1 are read during the second half of
+// the MFMAs of stage kt (the barrier sits in the middle of a stage's second k-step), so no stage opens with an exposed
+// LDS round trip.
+template <int BT, int WM, int WN, int BK, int NP, int ST = 2, bool PP = false, bool FAST = false, int SCH = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) {
   constexpr int NW = WM * WN;
   constexpr int BM = BT, BN = BT;
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   long* const c_off = a_off + BM;
   long* const m_off = c_off + BM;
 
+  st::stamp_begin(p.stamp);
   const int split = blockIdx.x / (p.chunk * 8);
   const int bid = blockIdx.x - split * (p.chunk * 8);
   const int idx = (bid & 7) * p.chunk + (bid >> 3);
@@ -468,6 +479,88 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       stage_sync(more);
     }
   };
+  if constexpr (SCH == 1) {
+    static_assert(!PP && NP == 1 && KS == 2 && FAST && MT % 2 == 0, "schedule 1: one plane, two k-steps per stage, whole stages");
+    bf16x8 fa[2][MT], fb[2][NT];                       // fragments of k-step 0 / 1 (double buffer across the stage barrier)
+    auto reads = [&](auto slot_c, auto ks_c) {
+      constexpr int SL = decltype(slot_c)::value, KI = decltype(ks_c)::value;
+      const unsigned short* as = As + SL * PL;
+      const unsigned short* bs = Bs + SL * PL;
+      // in the order the MFMAs want them (LDS returns in order, so the first MFMA waits for two reads, not for all)
+      fb[KI][0] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI]);
+      fa[KI][0] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI]);
+#pragma unroll
+      for (int n = 1; n < NT; ++n) fb[KI][n] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI] + n * 32 * BK);
+#pragma unroll
+      for (int i = 1; i < MT; ++i) fa[KI][i] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI] + i * 32 * BK);
+    };
+    auto mfmas = [&](auto ks_c, int i0, int i1) {
+      constexpr int KI = decltype(ks_c)::value;
+#pragma unroll
+      for (int i = i0; i < i1; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[KI][n], fa[KI][i], acc[i][n], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    auto stage1 = [&](auto cur_c, auto more_c, int kt) {
+      constexpr int CUR = decltype(cur_c)::value, FILL = (CUR + ST - 1) % ST, NEXT = (CUR + 1) % ST;
+      constexpr bool MORE_CT = decltype(more_c)::value;
+      const bool more = MORE_CT || kt + ST - 1 < nk;   // a stage ST - 1 ahead exists: stage it into the slot freed last
+      const bool next = MORE_CT || kt + 1 < nk;        // a stage kt + 1 exists: its first fragments are read in this one
+      const int nk0 = ic.k0;
+      if (more) advance(ic);
+      // ---- k-step 0: its fragments are in registers; between its 16 MFMAs go the 8 fragment reads of k-step 1 and
+      // the 8 DMA pieces of the stage ST - 1 ahead
+      reads(std::integral_constant<int, CUR>{}, K1{});
+      if (more) {
+#pragma unroll
+        for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, nk0, FILL);
+      }
+      mfmas(K0{}, 0, MT);
+#pragma unroll
+      for (int k = 0; k < MT + NT; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... one fragment read in its shadow
+      }
+#pragma unroll
+      for (int k = 0; k < N_DMA; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // address arithmetic / M0 of the piece
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA piece
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- k-step 1, first half
+      mfmas(K1{}, 0, MT / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (next) {
+        // stage kt + 1 complete in LDS: my own pieces by the counted wait, everybody else's by the barrier -- which also
+        // says that no wave still reads the slot the next stage's DMA (issued after this point) will overwrite
+        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((ST - 2) * N_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- k-step 1, second half, with the first fragments of the next stage read underneath: two reads behind each of
+      // the first four MFMAs, so that the last read is four MFMAs (~130 cycles) old when the next stage opens
+      if (next) reads(std::integral_constant<int, NEXT>{}, K0{});
+      mfmas(K1{}, MT / 2, MT);
+#pragma unroll
+      for (int k = 0; k < (MT + NT) / 2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nk > 0) reads(std::integral_constant<int, 0>{}, K0{});
+    int kt = 0;
+    for (; kt + 2 * ST - 2 < nk; kt += ST)
+      static_for<ST>([&](auto s_c) { stage1(s_c, std::true_type{}, kt + decltype(s_c)::value); });
+    static_for<2 * ST - 2>([&](auto r_c) {
+      constexpr int R = decltype(r_c)::value;
+      if (kt + R < nk) stage1(std::integral_constant<int, R % ST>{}, std::false_type{}, kt + R);
+    });
+  }
   auto run = [&](auto grp_c) {
     constexpr int GRP = decltype(grp_c)::value;
     if (PP && GRP == 1) phase_barrier();             // group 1 runs one phase behind
@@ -481,7 +574,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     });
     if (PP && GRP == 0) phase_barrier();             // every wave executes the same number of barriers
   };
-  if constexpr (PP) {
+  if constexpr (SCH == 1) {
+    (void)run;
+  } else if constexpr (PP) {
     if (wave / (NW / 2) == 0) run(std::integral_constant<int, 0>{});   // waves i and i + NW/2 share a SIMD
     else run(std::integral_constant<int, 1>{});
   } else {
@@ -553,6 +648,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       }
     }
   }
+  st::stamp_end(p.stamp);
 }
 
 int npad_of(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)st::round_up(cout, 128)); }
@@ -652,20 +748,30 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   p.tiles_n = st::ceil_div(p.Np, BT);
   p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
   const dim3 grid(p.chunk * 8 * p.splits);
-  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps,
+  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d sched=%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps,
+            (NP == 1 && BT == 256 && st::tuning(st::TUNE_BF16_SCHED) != 1) ? 1 : 0,
             2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
   st::LaunchTimer timer(s);
+  p.stamp = timer.stamp();
   const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
 #define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
   do {                                                                                                         \
     if (whole(K)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, true>), grid, dim3(64 * W1 * W2), 0, s, p);   \
     else hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, false>), grid, dim3(64 * W1 * W2), 0, s, p);          \
   } while (0)
+  // schedule of the 256 x 256 bf16-activation kernel: 1 = one wave per SIMD, software pipelined (SCH = 1, ring of 4 or 3);
+  // 0 = eight waves in ping-pong groups (rounds 1-2).  st_set_tuning("bf16_sched", 1 | 2 | 3): force ping-pong / SCH 1 with
+  // a ring of 4 / of 3.
+  const int sched = st::tuning(st::TUNE_BF16_SCHED);
   if constexpr (NP == 3) {
     if (BT == 256) ST_LAUNCH(256, 2, 4, 16, 3, 3, true);
     else ST_LAUNCH(128, 2, 2, 32, 3, 2, false);
   } else {
-    if (BT == 256) ST_LAUNCH(256, 2, 4, 32, 1, 4, true);
+    if (BT == 256 && whole(32) && sched != 1) {
+      if (sched == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 3, false, true, 1>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 4, false, true, 1>), grid, dim3(256), 0, s, p);
+    }
+    else if (BT == 256) ST_LAUNCH(256, 2, 4, 32, 1, 4, true);
     else ST_LAUNCH(128, 2, 2, 64, 1, 4, false);
   }
 #undef ST_LAUNCH

@@ -145,8 +145,9 @@ __device__ inline void stage_matrix(float* __restrict__ dst, const float* __rest
 template <int NST>                           // stages of CH frame pairs: the matrix has no columns past 2 * NST * CH
 __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, st::Stamp stamp) {
   __shared__ __attribute__((aligned(16))) float wl[KP * KP];
+  st::stamp_begin(stamp);
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
   stage_matrix<KP>(wl, wm);
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
         }
     }
   }
+  st::stamp_end(stamp);
 }
 
 // ---- inverse DFT of spectra back to frames, with the layer epilogue ---------------------------------------------
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
                                                            int rows, int rows_pad, int bins, int half_in, int nchunks,
                                                            RowsOut y, const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ mask, long mask_batch_stride,
-                                                           int mask_c_pitch) {
+                                                           int mask_c_pitch, st::Stamp stamp) {
+  st::stamp_begin(stamp);
   constexpr int NST = 2 * HP / CH;                      // stages per term
   static_assert(2 * HP % CH == 0 && HP <= HB / 2, "pairs per term must fill whole stages");
   __shared__ __attribute__((aligned(16))) float wl[TERMS * V * KP];
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
         }
     }
   }
+  st::stamp_end(stamp);
 }
 
 // ---- filters -> their spectra in the two GEMM operand layouts -------------------------------------------------
@@ -491,10 +495,10 @@ void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start,
   st::LaunchTimer timer(s);
   if (frames_used <= 6 * CH)                                               // the matrix has no columns past frames_used
     hipLaunchKernelGGL(dft_rows_kernel<3>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                       half, nchunks, out);
+                       half, nchunks, out, timer.stamp());
   else
     hipLaunchKernelGGL(dft_rows_kernel<4>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                       half, nchunks, out);
+                       half, nchunks, out, timer.stamp());
 }
 
 template <int TERMS>
@@ -507,10 +511,10 @@ void launch_idft(const float* in, const float* winv, const Plan& p, int half_in,
   st::LaunchTimer timer(s);
   if (p.bins <= 36)
     hipLaunchKernelGGL((idft_rows_kernel<TERMS, 18>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
+                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch, timer.stamp());
   else
     hipLaunchKernelGGL((idft_rows_kernel<TERMS, 24>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
+                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch, timer.stamp());
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }

@@ -57,6 +57,7 @@ struct NNParams {
   int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
   int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
   long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
+  st::Stamp stamp;                   // timed launch trace: device-side begin / end of this launch (null otherwise)
 };
 
 // ------------------------------------------------------------------------------------
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // tile grid as gm x gn rectangles (chosen by the host to minimise  A-bytes * gn + B-bytes * gm, i.e. how
   // often each operand is fetched into some L2); inside its rectangle an XCD walks panel-major so that
   // the CUs sharing the L2 stream the same filter panel together.
+  st::stamp_begin(p.stamp);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   int tile_m, tile_n;
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
           *reinterpret_cast<bvec*>(slab + (long)m * p.Np + col0) = out;
         }
       }
+    st::stamp_end(p.stamp);
     return;
   }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     for (int n = 0; n < NT; ++n) vset<NT>(out, n, csum[n] + __shfl_xor(csum[n], 32, 64));
     if (h == 0) *reinterpret_cast<bvec*>(p.colsum + (long)(tile_m * WMW + wm) * p.Np + col0) = out;
   }
+  st::stamp_end(p.stamp);
 }
 
 // ------------------------------------------------------------------------------------
@@ -425,6 +429,7 @@ struct TNParams {
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
   long a_batch, z_batch, o_batch;   // blockIdx.z: independent products of the same shape (csrc/conv_fft.hip), float strides
+  st::Stamp stamp;                  // timed launch trace (see NNParams)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   float* const As = smem;
   float* const Zs = smem + 2 * A_SZ;
 
+  st::stamp_begin(p.stamp);
   // XCD-aware order (see gemm_nn_kernel): 8x8 super-tiles so the CUs behind one L2 share operands
   int tile_k, tile_n;
   {
@@ -614,6 +620,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
         *reinterpret_cast<zvec*>(out + (long)k * p.Np + col0) = o;
       }
     }
+  st::stamp_end(p.stamp);
 }
 
 // dst[i] = sum_s slabs[s][i]
@@ -838,6 +845,7 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
               FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
   {
     st::LaunchTimer timer(s);
+    p.stamp = timer.stamp();
     if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
   }
@@ -931,6 +939,7 @@ int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, 
   st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d gflop=%.3f", batches, M, K, N, 2e-9 * M * (double)K * N * batches);
   {
     st::LaunchTimer timer(s);
+    p.stamp = timer.stamp();
     hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), 0, s, p);
   }
   return st::check_launch("gemm_tn_batched");
@@ -1222,6 +1231,7 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
             p.rows_per_split, p.M, p.Kp, p.Np, 2e-9 * st::round_up(p.M, 32) * (double)(p.tiles_k * 128) * p.Np);
   {
     st::LaunchTimer timer(s);                // the product kernel alone (what rocprofv3 lists under this symbol)
+    p.stamp = timer.stamp();
     if (p.Np % 128 == 0) {
       p.tiles_n = p.Np / 128;
       hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);

@@ -13,21 +13,31 @@ void set_error(const char* fmt, ...);
 // launch trace (st_trace_begin / st_trace_end) and tuning overrides (st_set_tuning); api.hip
 bool trace_on();
 void trace(const char* fmt, ...);
-// In timed mode (st_trace_begin_timed) a pair of HIP events around the launch that follows a trace() line: the
-// line gets " ms=..." when the trace is collected.  No-op otherwise.
+// Timed mode (st_trace_begin_timed): the kernel that follows a trace() line stamps its own begin and end on the device --
+// every workgroup's first lane does an atomicMin / atomicMax of the constant-rate wall clock (s_memrealtime) into the
+// launch's slot -- so a launch's duration is "first workgroup started -> last workgroup finished", what a profiler's
+// kernel trace shows, and the stream is not perturbed (no event markers between launches).  The line gets " ms=..."
+// when the trace is collected.  Outside timed mode stamp() is {nullptr, nullptr} and the kernels skip the two atomics.
+struct Stamp {
+  unsigned long long* begin;
+  unsigned long long* end;
+};
 class LaunchTimer {
  public:
   explicit LaunchTimer(hipStream_t s);
-  ~LaunchTimer();
-  LaunchTimer(const LaunchTimer&) = delete;
-  LaunchTimer& operator=(const LaunchTimer&) = delete;
+  Stamp stamp() const { return stamp_; }
 
  private:
-  hipStream_t stream_;
-  int slot_;
+  Stamp stamp_;
 };
+__device__ __forceinline__ void stamp_begin(const Stamp& s) {
+  if (s.begin && threadIdx.x == 0) atomicMin(s.begin, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(const Stamp& s) {
+  if (s.end && (threadIdx.x & 63) == 0) atomicMax(s.end, (unsigned long long)wall_clock64());   // every wave: they finish apart
+}
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)

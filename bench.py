@@ -74,6 +74,11 @@ def train_step(eng, feed, reducer, lr, global_batch):
   eng.apply_update(lr)
 
 
+def _lib_handle():
+  from speecht_amd import _lib
+  return _lib.load()
+
+
 def trace_symbol(line):
   """Launch-trace line -> the kernel symbol the roofline groups by (conv GEMMs keep their epilogue flavour)."""
   tok = line.split()
@@ -129,13 +134,16 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
       cin_real = l.cin * (l.stride if f['shift'] is not None else 1)
       fl = 2.0 * rows * (2 * cin_real) * (2 * l.cout) * nb
       nbytes = 4.0 * nb * (rows * 2 * cin_real + 4 * cin_real * l.cout + rows * 2 * l.cout)
-      launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb: call(
-          'st_gemm_nn_batched_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, P(f['ws']), nf, rp * nf, rp, ka, nf, nb, s)))
+      # the layer's workspace as its own entry points lay it out: [tail area of the per-bin products | output spectra]
+      tail_bytes = _lib_handle().st_gemm_nn_batched_tail_ws()
+      tail, outp = P(f['ws']), ctypes.c_void_p(f['ws'].data_ptr() + tail_bytes)
+      launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
+          'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
       if i > 0:
-        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, nbk=nbk, nf=nf, rp=rp, nb=nb: call(
-            'st_gemm_nn_batched_f32', P(f['zf']), nf, rp * nf, P(f['gbwd']), nf * nbk, P(f['ws']), nbk, rp * nbk, rp, nf, nbk, nb, s)))
-      launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb: call(
-          'st_gemm_tn_batched_f32', P(f['sf']), ka, rp * ka, P(f['zf']), nf, rp * nf, P(f['ws']), ka * nf, rp, ka, nf, nb, s)))
+        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, nbk=nbk, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
+            'st_gemm_nn_batched_ws_f32', P(f['zf']), nf, rp * nf, P(f['gbwd']), nf * nbk, outp, nbk, rp * nbk, rp, nf, nbk, nb, tail, tail_bytes, s)))
+      launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, outp=outp: call(
+          'st_gemm_tn_batched_f32', P(f['sf']), ka, rp * ka, P(f['zf']), nf, rp * nf, outp, ka * nf, rp, ka, nf, nb, s)))
       continue
     launches.append(('L%d fwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, pf=pf, pb=pb: call(
         'st_conv1d_nwc_fwd_ws_f32', eng.X[i].ref, P(pf), P(pb), l.width, l.stride, pl, int(l.relu), eng.X[i + 1].ref, ws, wsb, s)))

@@ -40,6 +40,9 @@ _SIGNATURES = {
                                    POINTER(c_int)]),
     'st_gemm_nn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                        c_int, c_int, c_void_p]),
+    'st_gemm_nn_batched_tail_ws': (c_size_t, []),
+    'st_gemm_nn_batched_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                          c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_gemm_tn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int,
                                        c_int, c_int, c_void_p]),
     'st_conv1d_fft_table_floats': (c_size_t, []),

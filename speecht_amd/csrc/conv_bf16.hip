@@ -230,7 +230,8 @@ struct X6Params {
   RowMapB mmap;
   __bf16* Cp; size_t c_plane;            // optional: the NP planes of the output (same geometry as C)
   int M, Kvalid, Kp, Np, n_store, relu, taps, cp;
-  int tiles_m, tiles_n, chunk;
+  int tiles_m, tiles_n, chunk;           // XCD-aware tile order: the 8 XCDs as a gm x gn grid over the tile grid,
+  int gm, tm_per, tn_per;                // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per), see launch_gemm
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
   st::Stamp stamp;                       // timed launch trace: device-side begin / end of this launch (null otherwise)
 };
@@ -278,10 +279,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   st::stamp_begin(p.stamp);
   const int split = blockIdx.x / (p.chunk * 8);
   const int bid = blockIdx.x - split * (p.chunk * 8);
-  const int idx = (bid & 7) * p.chunk + (bid >> 3);
-  if ((bid >> 3) >= p.chunk || idx >= p.tiles_m * p.tiles_n) return;
-  const int tile_n = idx / p.tiles_m;
-  const int tile_m = idx - tile_n * p.tiles_m;
+  // block b runs on XCD b % 8 and every XCD has its own L2: an XCD owns a rectangle of the tile grid (chosen by the host to
+  // minimise the operand bytes the eight L2s pull in together) and walks it row tiles fastest, so that the workgroups
+  // running side by side share a filter panel
+  const int xcd = bid & 7, local = bid >> 3;
+  const int ln = local / p.tm_per, lm = local - ln * p.tm_per;
+  const int tile_m = (xcd % p.gm) * p.tm_per + lm, tile_n = (xcd / p.gm) * p.tn_per + ln;
+  if (local >= p.chunk || tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -480,59 +484,80 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     }
   };
   if constexpr (SCH == 1) {
-    static_assert(!PP && NP == 1 && KS == 2 && FAST && MT % 2 == 0, "schedule 1: one plane, two k-steps per stage, whole stages");
-    bf16x8 fa[2][MT], fb[2][NT];                       // fragments of k-step 0 / 1 (double buffer across the stage barrier)
+    static_assert(!PP && NP == 1 && (KS == 2 || KS == 4) && MT % 2 == 0, "schedule 1: one plane, two or four k-steps per stage");
+    bf16x8 fa[2][MT], fb[2][NT];                       // fragments of even / odd k-steps (double buffer, also across stages)
     auto reads = [&](auto slot_c, auto ks_c) {
-      constexpr int SL = decltype(slot_c)::value, KI = decltype(ks_c)::value;
+      constexpr int SL = decltype(slot_c)::value, KI = decltype(ks_c)::value, BUF = KI & 1;
       const unsigned short* as = As + SL * PL;
       const unsigned short* bs = Bs + SL * PL;
       // in the order the MFMAs want them (LDS returns in order, so the first MFMA waits for two reads, not for all)
-      fb[KI][0] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI]);
-      fa[KI][0] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI]);
+      fb[BUF][0] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI]);
+      fa[BUF][0] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI]);
 #pragma unroll
-      for (int n = 1; n < NT; ++n) fb[KI][n] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI] + n * 32 * BK);
+      for (int n = 1; n < NT; ++n) fb[BUF][n] = *reinterpret_cast<const bf16x8*>(bs + b_frag[KI] + n * 32 * BK);
 #pragma unroll
-      for (int i = 1; i < MT; ++i) fa[KI][i] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI] + i * 32 * BK);
+      for (int i = 1; i < MT; ++i) fa[BUF][i] = *reinterpret_cast<const bf16x8*>(as + a_frag[KI] + i * 32 * BK);
     };
     auto mfmas = [&](auto ks_c, int i0, int i1) {
-      constexpr int KI = decltype(ks_c)::value;
+      constexpr int BUF = decltype(ks_c)::value & 1;
 #pragma unroll
       for (int i = i0; i < i1; ++i)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[KI][n], fa[KI][i], acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BUF][n], fa[BUF][i], acc[i][n], 0, 0, 0);
     };
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
+    // !FAST here means: every stage is whole EXCEPT possibly the last one (one-tap layers whose reduction length is a
+    // multiple of 16 but not of BK, e.g. 2016 channels with 64-deep stages).  That stage runs `nks_last` k-steps and its DMA
+    // sources are clamped into the row (what lies behind the valid range is never multiplied).
+    const int nks_last = (FAST || unit0 + nk != chunks) ? KS : (len - (chunks - 1) * BK + 15) / 16;   // (!FAST: one tap)
+    const int kp8 = p.Kp - 8;
+    auto dma_piece1 = [&](int pc, int k0, int buf, bool clamp) {
+      const int op = pc / PPW, i = pc % PPW;
+      if (op == 0) {
+        const __bf16* g = aptr[0][i] + (clamp ? min(k0, ktail - slot8[i]) : k0);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
+      } else {
+        const __bf16* g = bptr[0][i] + (clamp ? min(k0, kp8 - slot8[i]) : k0);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * PL + (wave * RW + i * RPP) * BK), 16, 0, 0);
+      }
+    };
+    constexpr int DPK = (N_DMA + KS - 2) / (KS - 1);   // DMA pieces per k-step, spread over the first KS - 1 k-steps
     auto stage1 = [&](auto cur_c, auto more_c, int kt) {
       constexpr int CUR = decltype(cur_c)::value, FILL = (CUR + ST - 1) % ST, NEXT = (CUR + 1) % ST;
       constexpr bool MORE_CT = decltype(more_c)::value;
       const bool more = MORE_CT || kt + ST - 1 < nk;   // a stage ST - 1 ahead exists: stage it into the slot freed last
       const bool next = MORE_CT || kt + 1 < nk;        // a stage kt + 1 exists: its first fragments are read in this one
+      const int nks = (MORE_CT || FAST || kt + 1 < nk) ? KS : nks_last;
+      const bool clamp = !FAST && !MORE_CT && kt + ST == nk;    // the stage being staged is the (short) last one
       const int nk0 = ic.k0;
       if (more) advance(ic);
-      // ---- k-step 0: its fragments are in registers; between its 16 MFMAs go the 8 fragment reads of k-step 1 and
-      // the 8 DMA pieces of the stage ST - 1 ahead
-      reads(std::integral_constant<int, CUR>{}, K1{});
-      if (more) {
+      // ---- k-steps 0 .. KS - 2: the fragments of the k-step are in registers; between its 16 MFMAs go the 8 fragment
+      // reads of the next k-step and a share of the DMA pieces of the stage ST - 1 ahead
+      static_for<KS - 1>([&](auto ks_c) {
+        constexpr int KI = decltype(ks_c)::value;
+        reads(std::integral_constant<int, CUR>{}, std::integral_constant<int, KI + 1>{});
+        constexpr int P0 = KI * DPK, P1 = (KI + 1) * DPK < N_DMA ? (KI + 1) * DPK : N_DMA;
+        if (more) {
 #pragma unroll
-        for (int pc = 0; pc < N_DMA; ++pc) dma_piece(pc, nk0, FILL);
-      }
-      mfmas(K0{}, 0, MT);
+          for (int pc = P0; pc < P1; ++pc) dma_piece1(pc, nk0, FILL, clamp);
+        }
+        if (KI < nks) mfmas(ks_c, 0, MT);
 #pragma unroll
-      for (int k = 0; k < MT + NT; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... one fragment read in its shadow
-      }
+        for (int k = 0; k < MT + NT; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... one fragment read in its shadow
+        }
 #pragma unroll
-      for (int k = 0; k < N_DMA; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // address arithmetic / M0 of the piece
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA piece
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- k-step 1, first half
-      mfmas(K1{}, 0, MT / 2);
+        for (int k = 0; k < P1 - P0; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // address arithmetic / M0 of the piece
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA piece
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // ---- last k-step, first half
+      using KL = std::integral_constant<int, KS - 1>;
+      if (KS - 1 < nks) mfmas(KL{}, 0, MT / 2);
       __builtin_amdgcn_sched_barrier(0);
       if (next) {
         // stage kt + 1 complete in LDS: my own pieces by the counted wait, everybody else's by the barrier -- which also
@@ -541,10 +566,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- k-step 1, second half, with the first fragments of the next stage read underneath: two reads behind each of
+      // ---- last k-step, second half, with the first fragments of the next stage read underneath: two reads behind each of
       // the first four MFMAs, so that the last read is four MFMAs (~130 cycles) old when the next stage opens
-      if (next) reads(std::integral_constant<int, NEXT>{}, K0{});
-      mfmas(K1{}, MT / 2, MT);
+      if (next) reads(std::integral_constant<int, NEXT>{}, std::integral_constant<int, 0>{});
+      if (KS - 1 < nks) mfmas(KL{}, MT / 2, MT);
 #pragma unroll
       for (int k = 0; k < (MT + NT) / 2; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -552,7 +577,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    if (nk > 0) reads(std::integral_constant<int, 0>{}, K0{});
+    if (nk > 0) reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     int kt = 0;
     for (; kt + 2 * ST - 2 < nk; kt += ST)
       static_for<ST>([&](auto s_c) { stage1(s_c, std::true_type{}, kt + decltype(s_c)::value); });
@@ -746,10 +771,33 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   const int BT = (forced_tile != 128 && fits256 && wide) ? 256 : 128;
   p.tiles_m = st::ceil_div(p.M, BT);
   p.tiles_n = st::ceil_div(p.Np, BT);
-  p.chunk = st::ceil_div(p.tiles_m * p.tiles_n, 8);
+  {
+    // Operand bytes the eight XCD-private L2s pull in together: the activation rows of an XCD's M range once per column
+    // group, the filter panel of its N range once per row group (a convolution's taps re-read the same rows: unique bytes).
+    // L9 at config 2 (16 032 x 2 016 x 2 048, bf16): one column panel per XCD reads the 65 MB of activations eight times
+    // (PMC round 3: 345 MB per launch at 2.1 TB/s, L2 hit rate 0.89); row bands read them once and the 8 MB of filters
+    // eight times.
+    const double a_bytes = (double)p.M * (p.taps > 1 ? p.cp : p.Kvalid) * 2.0 * NP, b_bytes = (double)p.Kp * p.Np * 2.0 * NP;
+    const int forced_gm = st::tuning(st::TUNE_XCD_GM);
+    double best = 0.0;
+    p.gm = 1;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+      const int gn = 8 / gm;
+      if (gm > p.tiles_m || gn > p.tiles_n) continue;
+      const int slots = st::ceil_div(p.tiles_m, gm) * st::ceil_div(p.tiles_n, gn) * 8;
+      const double cost = (a_bytes * gn + b_bytes * gm) * ((double)slots / (p.tiles_m * p.tiles_n));   // idle slots cost time
+      if (best == 0.0 || cost < best || gm == forced_gm) { best = gm == forced_gm ? -1.0 : cost; p.gm = gm; }
+      if (gm == forced_gm) break;
+    }
+    if (8 / p.gm > p.tiles_n) p.gm = 8;                       // fewer than 8/gm column panels: stack the XCDs along M
+    if (p.gm > p.tiles_m && 8 / p.gm <= p.tiles_n) p.gm = 1;
+    p.tm_per = st::ceil_div(p.tiles_m, p.gm);
+    p.tn_per = st::ceil_div(p.tiles_n, 8 / p.gm);
+    p.chunk = p.tm_per * p.tn_per;
+  }
   const dim3 grid(p.chunk * 8 * p.splits);
-  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d sched=%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np, p.Kp, p.taps,
-            (NP == 1 && BT == 256 && st::tuning(st::TUNE_BF16_SCHED) != 1) ? 1 : 0,
+  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d sched=%d xcd=%dx%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np,
+            p.Kp, p.taps, st::tuning(st::TUNE_BF16_SCHED), p.gm, 8 / p.gm,
             2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
   st::LaunchTimer timer(s);
   p.stamp = timer.stamp();
@@ -759,15 +807,25 @@ int launch_gemm(X6Params& p, hipStream_t s) {
     if (whole(K)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, true>), grid, dim3(64 * W1 * W2), 0, s, p);   \
     else hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, false>), grid, dim3(64 * W1 * W2), 0, s, p);          \
   } while (0)
-  // schedule of the 256 x 256 bf16-activation kernel: 1 = one wave per SIMD, software pipelined (SCH = 1, ring of 4 or 3);
-  // 0 = eight waves in ping-pong groups (rounds 1-2).  st_set_tuning("bf16_sched", 1 | 2 | 3): force ping-pong / SCH 1 with
-  // a ring of 4 / of 3.
+  // Schedule of the 256 x 256 bf16-activation kernel (st_set_tuning("bf16_sched", v) selects one; 0 = the policy = 1):
+  //   1  eight waves in ping-pong groups, 32-deep stages, ring of 4 (rounds 1-2) -- still the fastest (round 3, L8 forward /
+  //      back-prop / filter gradient: 0.462 / 0.419 / 0.537 ms)
+  //   2 / 3  one wave per SIMD, software pipelined (SCH = 1), 32-deep stages, ring of 4 / 3: 0.489 / 0.419 / 0.605 ms
+  //   4  SCH = 1 with 64-deep stages in a ring of 2 (a DMA row is a full 128-byte line: a third fewer L2 requests,
+  //      PMC 78 M -> 55 M per launch): 0.464 / 0.417 / 0.572 ms; L9 (short last stage) 0.175 vs 0.138
+  // None of the three moves the launch time: the limit is not instruction issue (scripts/ubench/gemm_issue.hip: the SCH = 1
+  // stage with every operand byte coming from L2 runs at 1.93 PFLOP/s on constant data, 1.49 on random data -- the board's
+  // power limit -- and 0.86 when every byte comes from HBM); see DESIGN 4.3.
   const int sched = st::tuning(st::TUNE_BF16_SCHED);
+  const bool one_tap_tail = p.taps == 1 && p.Kvalid % 16 == 0;           // only the last stage may be short
   if constexpr (NP == 3) {
     if (BT == 256) ST_LAUNCH(256, 2, 4, 16, 3, 3, true);
     else ST_LAUNCH(128, 2, 2, 32, 3, 2, false);
   } else {
-    if (BT == 256 && whole(32) && sched != 1) {
+    if (BT == 256 && sched == 4 && (whole(64) || one_tap_tail)) {
+      if (whole(64)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, true, 1>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, false, 1>), grid, dim3(256), 0, s, p);
+    } else if (BT == 256 && (sched == 2 || sched == 3) && whole(32)) {
       if (sched == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 3, false, true, 1>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 4, false, true, 1>), grid, dim3(256), 0, s, p);
     }

@@ -58,6 +58,13 @@ struct NNParams {
   int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
   long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
   st::Stamp stamp;                   // timed launch trace: device-side begin / end of this launch (null otherwise)
+  // Batched mode, K-split tail (see launch_nn): the bins beyond the last full set of 8 -- `batches % 8` of them -- would
+  // occupy only that many XCDs for a whole extra round.  Their tiles are cut into `tail_parts` slices of the reduction,
+  // all slices of a tile on ONE XCD; a slice stores its raw partial tile, the slice that arrives last (an atomic counter
+  // per tile, self-resetting) adds the partials in slice order -- the sum does not depend on who was last -- and stores C.
+  int tail_parts, tail_first_set, tail_chunk;
+  float* tail_slab;                  // [tile][part][BM][BN]
+  int* tail_count;                   // [tile], zero before and after every launch
 };
 
 // ------------------------------------------------------------------------------------
@@ -131,13 +138,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const float* __restrict__ Abase = p.A;
   const float* __restrict__ Bbase = p.Bm;
   float* __restrict__ Cbase = p.C;
+  int tail_part = 0, tail_tile = -1;               // K-split tail: which slice of which tail tile this workgroup is
   if (p.batches > 0) {
     // Batched mode: bin = 8 * set + xcd -- all tiles of one bin run on ONE XCD, whose L2 then holds that bin's
     // operands (a bin's filter matrix is 8 MB: spread over the XCDs every L2 would stream all of them).
     // Row tiles fastest, so the workgroups sharing a filter panel sit next to each other.
     const int per_bin = p.tiles_m * p.tiles_n;
-    const int set = local / per_bin, t = local - set * per_bin;
-    const int bin = set * 8 + xcd;
+    int set = local / per_bin, t = local - set * per_bin;
+    int bin = set * 8 + xcd;
+    if (p.tail_parts > 1 && set >= p.tail_first_set) {
+      // the bins of the last, partial set: tile u of them (u = xcd + 8 j) lives on this XCD with all its slices
+      const int lt = local - p.tail_first_set * per_bin;
+      if (lt >= p.tail_chunk) return;
+      const int j = lt / p.tail_parts;
+      tail_part = lt - j * p.tail_parts;
+      tail_tile = xcd + 8 * j;
+      if (tail_tile >= (p.batches - 8 * p.tail_first_set) * per_bin) return;
+      bin = 8 * p.tail_first_set + tail_tile / per_bin;
+      t = tail_tile % per_bin;
+    }
     if (bin >= p.batches) return;
     tile_n = t / p.tiles_m;
     tile_m = t - tile_n * p.tiles_m;
@@ -244,8 +263,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const int chunks = (p.cp + BK - 1) / BK;
   const int nk_total = tap_inner ? chunks * p.taps : p.Kp / BK;
   // split-K: this workgroup reduces k-tiles [s0, s0 + nk) and writes a raw partial tile
-  const int s0 = p.splits > 1 ? blockIdx.y * p.steps_per_split : 0;
-  const int nk = p.splits > 1 ? min(p.steps_per_split, nk_total - s0) : nk_total;
+  // (a K-split tail tile of the batched mode reduces its slice, nk_total / tail_parts k-tiles)
+  const int s0 = tail_tile >= 0 ? tail_part * (nk_total / p.tail_parts) : (p.splits > 1 ? blockIdx.y * p.steps_per_split : 0);
+  const int nk = tail_tile >= 0 ? nk_total / p.tail_parts : (p.splits > 1 ? min(p.steps_per_split, nk_total - s0) : nk_total);
   int tap = tap_inner ? s0 % p.taps : 0;          // position of the tile being COMPUTED
   int chunk = tap_inner ? s0 / p.taps : s0;
   auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
@@ -356,6 +376,50 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
       }
     st::stamp_end(p.stamp);
     return;
+  }
+  if (tail_tile >= 0) {
+    // K-split tail tile: store the raw partial; the slice that arrives last sums all slices in slice order
+    float* const mine = p.tail_slab + ((long)tail_tile * p.tail_parts + tail_part) * (BM * BN);
+    const int tcol = wn * WTN + NT * l31;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        bvec out;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
+        *reinterpret_cast<bvec*>(mine + row * BN + tcol) = out;
+      }
+    __threadfence();                               // the partial is visible (same XCD: L2) before the count says so
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(a_off);                     // (the row-offset table is no longer needed)
+    if (tid == 0) {
+      const int arrived = atomicAdd(p.tail_count + tail_tile, 1);
+      flag[0] = arrived == p.tail_parts - 1;
+      if (flag[0]) p.tail_count[tail_tile] = 0;                          // everybody is in: leave the counter as found
+    }
+    __syncthreads();
+    if (!flag[0]) {
+      st::stamp_end(p.stamp);
+      return;
+    }
+    __threadfence();                               // acquire: the other slices' partials are read from L2, not a stale L1
+    const float* const base = p.tail_slab + (long)tail_tile * p.tail_parts * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        bvec sum = *reinterpret_cast<const bvec*>(base + row * BN + tcol);      // slice 0, then 1, 2, ... : a fixed order
+        for (int q = 1; q < p.tail_parts; ++q) {
+          const bvec v = *reinterpret_cast<const bvec*>(base + (long)q * (BM * BN) + row * BN + tcol);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) vset<NT>(sum, n, vget<NT>(sum, n) + vget<NT>(v, n));
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[i][n][r] = vget<NT>(sum, n);
+      }
   }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
   float csum[NT];                                // EPI 1 + p.colsum: this lane's share of the column sums
@@ -834,12 +898,35 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.chunk = p.tm_per * p.tn_per;
   }
   p.colsum_rows = p.tiles_m * WMW;
-  if (p.batches > 0) p.chunk = st::ceil_div(p.batches, 8) * p.tiles_m * p.tiles_n;
+  if (p.batches > 0) {
+    const int per_bin = p.tiles_m * p.tiles_n, full_sets = p.batches / 8, rest = p.batches % 8;
+    p.chunk = st::ceil_div(p.batches, 8) * per_bin;
+    // K-split tail (NNParams): 36 bins x 16 tiles = 576 workgroups on 256 CUs cost three rounds for 2.25 rounds of work --
+    // bins 32..35 run on four XCDs while the other four idle (measured round 2: 32 bins 46 us, 36 bins 65 us).  Their 64
+    // tiles become 256 quarter-reduction slices, one per CU.
+    p.tail_parts = 1;
+    const int nk_total = p.Kp / BK, tail_tiles = rest * per_bin;
+    float* const ws = p.tail_slab;                 // caller's tail area (may be null): [256 counters | slab]
+    p.tail_slab = nullptr;
+    if (ws && rest > 0 && p.taps == 1 && p.splits <= 1 && tail_tiles <= 128 && !st::tuning(st::TUNE_NO_TAIL_SPLIT)) {
+      int parts = 1;
+      for (int c : {8, 6, 4, 3, 2})
+        if (nk_total % c == 0 && nk_total / c >= 3 && tail_tiles * c <= 256 && (long)tail_tiles * c * BM * BN <= st::TAIL_SLAB_FLOATS) { parts = c; break; }
+      if (parts > 1) {
+        p.tail_parts = parts;
+        p.tail_first_set = full_sets;
+        p.tail_chunk = st::ceil_div(tail_tiles, 8) * parts;
+        p.tail_count = reinterpret_cast<int*>(ws);
+        p.tail_slab = ws + st::TAIL_COUNT_FLOATS;
+        p.chunk = full_sets * per_bin + p.tail_chunk;
+      }
+    }
+  }
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   const double gflop = 2e-9 * p.tiles_m * BM * (double)p.Np * p.Kp * std::max(1, p.batches);      // executed, padding included
   if (p.batches > 0)
-    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
-              p.batches, p.M, p.Np, p.Kp, gflop);
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d tail=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
+              p.batches, p.M, p.Np, p.Kp, p.tail_parts, gflop);
   else
     st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d gflop=%.3f", BM, BN, WMW, WNW,
               FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
@@ -887,7 +974,7 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
 // Plain batched C[b] = A[b] * B[b] (row-major fp32, no epilogue) on the convolution GEMM kernel: A [M][lda] with
 // K <= lda readable floats per row, B [K][N] with N a multiple of 128, C [M][ldc]; K a multiple of 32.
 int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc,
-                        long c_batch, int M, int K, int N, int batches, hipStream_t s) {
+                        long c_batch, int M, int K, int N, int batches, hipStream_t s, float* tail_ws) {
   if (!(A && B && C && M > 0 && K > 0 && K % 32 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldc % 4 == 0)) {
     st::set_error("gemm_nn_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
@@ -907,6 +994,7 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
   p.cp = K;
   p.batches = batches;
   p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
+  p.tail_slab = tail_ws;                         // (launch_nn decides whether the tail of the bin list is K-split)
   return run_nn(p, 0, s);
 }
 

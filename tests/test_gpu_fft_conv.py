@@ -248,3 +248,50 @@ def test_training_steps_agree_between_frequency_and_w_tap_kernels(dev):
   for (Fa, ba), (Fb, bb) in zip(runs[True][1], runs[False][1]):
     assert np.max(np.abs(Fa - Fb)) < 2e-4 * np.max(np.abs(Fb))
     assert np.max(np.abs(ba - bb)) < 2e-4 * max(np.max(np.abs(bb)), 1e-3)
+
+
+@pytest.mark.parametrize('bins,M,K,N', [(36, 256, 512, 512), (45, 256, 384, 512), (36, 128, 512, 512), (3, 256, 512, 512),
+                                       (48, 256, 512, 4096), (33, 256, 512, 512)])
+def test_batched_products_with_k_split_tail(dev, bins, M, K, N):
+  """st_gemm_nn_batched_ws_f32: the tiles of the bins beyond the last full set of 8 are cut into reduction slices that the
+  last-arriving slice sums in slice order (36 bins of the 7-tap layers: 4 slices; 45 bins of the first layer: 3).  Against
+  float64 matmul per bin, bit-identical across repetitions (no dependence on arrival order), counters left at zero, and
+  within fp32 rounding of the un-split launch (which sums the reduction in one chain)."""
+  from speecht_amd import _lib
+  from speecht_amd._lib import call, launch_trace
+  lib = _lib.load()
+  rng = np.random.default_rng(bins * 1000 + K)
+  A = torch.as_tensor(rng.standard_normal((bins, M, K)), dtype=torch.float32).to(dev)
+  B = torch.as_tensor(rng.standard_normal((bins, K, N)) / np.sqrt(K), dtype=torch.float32).to(dev)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  tail_bytes = lib.st_gemm_nn_batched_tail_ws()
+  tail = torch.zeros(tail_bytes // 4, dtype=torch.float32, device=dev)
+  outs = []
+  for rep in range(3):
+    C = torch.full((bins, M, N), float('nan'), dtype=torch.float32, device=dev)
+    with launch_trace() as tr:
+      call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(tail), tail_bytes, None)
+    torch.cuda.synchronize()
+    outs.append(C)
+    assert int(tail[:256].view(torch.int32).abs().sum()) == 0                      # the counters are left as found
+  line = tr.lines[0]
+  parts = int(line.split('tail=')[1].split()[0])
+  tiles128 = -(-M // 128) * (N // 128) * bins
+  if bins % 8 and tiles128 < 512:
+    assert parts > 1, line                                                        # the narrow products really split their tail
+  if bins == 36 and M == 256 and N == 512:
+    assert parts == 4 and 'gemm_nn<64,128,2,2,fast>' in line, line
+  if bins == 45:
+    assert parts == 3, line
+  if bins == 48:
+    assert parts == 1, line                                                       # six full sets: nothing to split
+  assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+  ref = torch.matmul(A.double(), B.double())
+  err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
+  assert err < 2e-6, err
+  plain = torch.empty_like(outs[0])
+  call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(plain), N, M * N, M, K, N, bins, None)
+  torch.cuda.synchronize()
+  full_sets = bins // 8 * 8
+  assert torch.equal(plain[:full_sets], outs[0][:full_sets])                        # bins of full sets: the same launch path
+  assert float((plain.double() - ref).abs().max() / ref.abs().max()) < 2e-6

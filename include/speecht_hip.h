@@ -59,7 +59,7 @@ const char* st_last_error(void);
  * stream; st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
  * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "no_tail_split"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 int st_trace_begin_timed(void);
@@ -113,15 +113,14 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  *             the filter-gradient call
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
- *   workspace st_conv1d_fft_ws bytes, scratch of one call; its first 1 024 bytes must be ZERO on first use (the counters
- *             of st_gemm_nn_batched_ws_f32's tail area; every call leaves them zero) */
+ *   workspace st_conv1d_fft_ws bytes, scratch of one call (headed by st_gemm_nn_batched_ws_f32's tail area) */
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
 /* the per-bin products themselves: `batches` independent row-major fp32 GEMMs C[i] = A[i] * B[i] (A [m][lda], B [k][n],
  * C [m][ldc]; k a multiple of 32, n of 128; strides in floats) on the convolution MFMA kernel, bin i on XCD i % 8 */
 int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                            int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream);
-/* The same with a "tail area" of st_gemm_nn_batched_tail_ws() bytes whose first 1 024 bytes are ZERO on first use (every
- * call leaves them zero): with it the launch cuts the tiles of the last, partial set of 8 bins (36 bins: bins 32..35) into
+/* The same with a "tail area" of st_gemm_nn_batched_tail_ws() bytes of scratch (arrival counters, zeroed on the stream by
+ * the call, and partial tiles): with it the launch cuts the tiles of the last, partial set of 8 bins (36 bins: bins 32..35) into
  * slices of the reduction so that they fill the chip instead of half the XCDs for a whole extra round; the slices of a tile
  * are summed in slice order by whichever arrives last (bit-reproducible, no atomics on data).  The frequency-domain entry
  * points below carry this area at the head of their workspace. */

@@ -377,8 +377,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     st::stamp_end(p.stamp);
     return;
   }
+  if constexpr (NT == 2) {
   if (tail_tile >= 0) {
-    // K-split tail tile: store the raw partial; the slice that arrives last sums all slices in slice order
+    // K-split tail tile.  The hand-off between the slices follows MI355X_MICROARCH.md's price list: the partial goes out
+    // with write-through (sc1) stores, drained by this wave's own vmcnt wait -- no release fence (an agent-scope release
+    // writes back the whole L2's dirty lines, and this kernel keeps tens of MB dirty: measured +60 us per launch) -- then one
+    // returning atomic per workgroup on the tile's arrival counter; the slice that arrives last reads the others' partials
+    // with sc1 loads (past its L1) and adds them in slice order.
+    typedef unsigned long long u64;
     float* const mine = p.tail_slab + ((long)tail_tile * p.tail_parts + tail_part) * (BM * BN);
     const int tcol = wn * WTN + NT * l31;
 #pragma unroll
@@ -386,40 +392,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        bvec out;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
-        *reinterpret_cast<bvec*>(mine + row * BN + tcol) = out;
+        const u64 bits = (u64)__float_as_uint(acc[i][0][r]) | ((u64)__float_as_uint(acc[i][1][r]) << 32);
+        __hip_atomic_store(reinterpret_cast<u64*>(mine + row * BN + tcol), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    __threadfence();                               // the partial is visible (same XCD: L2) before the count says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* const flag = reinterpret_cast<int*>(a_off);                     // (the row-offset table is no longer needed)
-    if (tid == 0) {
-      const int arrived = atomicAdd(p.tail_count + tail_tile, 1);
-      flag[0] = arrived == p.tail_parts - 1;
-      if (flag[0]) p.tail_count[tail_tile] = 0;                          // everybody is in: leave the counter as found
-    }
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tail_count + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.tail_parts - 1;
     __syncthreads();
     if (!flag[0]) {
       st::stamp_end(p.stamp);
       return;
     }
-    __threadfence();                               // acquire: the other slices' partials are read from L2, not a stale L1
     const float* const base = p.tail_slab + (long)tail_tile * p.tail_parts * (BM * BN);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        bvec sum = *reinterpret_cast<const bvec*>(base + row * BN + tcol);      // slice 0, then 1, 2, ... : a fixed order
-        for (int q = 1; q < p.tail_parts; ++q) {
-          const bvec v = *reinterpret_cast<const bvec*>(base + (long)q * (BM * BN) + row * BN + tcol);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) vset<NT>(sum, n, vget<NT>(sum, n) + vget<NT>(v, n));
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = 0; q < p.tail_parts; ++q) {                               // slice 0, 1, 2, ...: a fixed order
+          const u64 bits = __hip_atomic_load(reinterpret_cast<const u64*>(base + (long)q * (BM * BN) + row * BN + tcol),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float v0 = __uint_as_float((unsigned)bits), v1 = __uint_as_float((unsigned)(bits >> 32));
+          s0 = q == 0 ? v0 : s0 + v0;
+          s1 = q == 0 ? v1 : s1 + v1;
         }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[i][n][r] = vget<NT>(sum, n);
+        acc[i][0][r] = s0;
+        acc[i][1][r] = s1;
       }
+  }
   }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
   float csum[NT];                                // EPI 1 + p.colsum: this lane's share of the column sums
@@ -908,11 +910,18 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     const int nk_total = p.Kp / BK, tail_tiles = rest * per_bin;
     float* const ws = p.tail_slab;                 // caller's tail area (may be null): [256 counters | slab]
     p.tail_slab = nullptr;
-    if (ws && rest > 0 && p.taps == 1 && p.splits <= 1 && tail_tiles <= 128 && !st::tuning(st::TUNE_NO_TAIL_SPLIT)) {
+    // MEASURED (round 3) AND OFF BY DEFAULT: isolated forward product 65 -> 65 us, training step 7.28 -> 7.37 ms.  The 256
+    // slices start only when the full tiles leave (two workgroups per CU are resident from t = 0), each then runs alone on
+    // its CU for a quarter of a reduction plus the hand-off (write-through partial, counter, the last slice's re-read), and
+    // the per-call counter memset is one more stream operation: together as long as the idle half-round they replace.
+    // st_set_tuning("tail_split", 1) turns it on (tests/test_gpu_fft_conv.py keeps it correct).
+    if (ws && BM == 64 && BN == 128 && rest > 0 && p.taps == 1 && p.splits <= 1 && tail_tiles <= 128 &&
+        st::tuning(st::TUNE_TAIL_SPLIT) == 1) {
       int parts = 1;
       for (int c : {8, 6, 4, 3, 2})
         if (nk_total % c == 0 && nk_total / c >= 3 && tail_tiles * c <= 256 && (long)tail_tiles * c * BM * BN <= st::TAIL_SLAB_FLOATS) { parts = c; break; }
-      if (parts > 1) {
+      // the arrival counters, zeroed on the stream every call (a caller's workspace is not to be trusted with that)
+      if (parts > 1 && hipMemsetAsync(ws, 0, (size_t)tail_tiles * sizeof(int), s) == hipSuccess) {
         p.tail_parts = parts;
         p.tail_first_set = full_sets;
         p.tail_chunk = st::ceil_div(tail_tiles, 8) * parts;

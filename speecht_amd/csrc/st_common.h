@@ -37,11 +37,11 @@ __device__ __forceinline__ void stamp_end(const Stamp& s) {
   if (s.end && (threadIdx.x & 63) == 0) atomicMax(s.end, (unsigned long long)wall_clock64());   // every wave: they finish apart
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_NO_TAIL_SPLIT, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_TAIL_SPLIT, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
-// tail_ws: optional TAIL_WS_FLOATS floats whose first TAIL_COUNT_FLOATS are zero on first use (and left zero by every call):
+// tail_ws: optional TAIL_WS_FLOATS floats of scratch (arrival counters, zeroed on the stream per call, + partial tiles):
 // lets the launch cut the tiles of the last, partial set of 8 bins into reduction slices (conv_gemm.hip, NNParams)
 constexpr long TAIL_COUNT_FLOATS = 256, TAIL_SLAB_FLOATS = 256L * 64 * 128, TAIL_WS_FLOATS = TAIL_COUNT_FLOATS + TAIL_SLAB_FLOATS;
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,

@@ -34,6 +34,7 @@ def main():
   ap.add_argument('--seconds', type=float, default=30.0)
   ap.add_argument('--beam', type=int, default=16)
   ap.add_argument('--reps', type=int, default=5)
+  ap.add_argument('--samples', type=int, default=7)
   args = ap.parse_args()
   dev = torch.device('cuda:0')
   frames = 1 + int(args.seconds * 16000) // 160
@@ -47,11 +48,35 @@ def main():
   g = torch.Generator(device='cpu').manual_seed(11)
   eng.X[-1].interior().copy_(torch.randn(eng.X[-1].interior().shape, generator=g) * 3.0)
   t_greedy = timed(lambda: eng.greedy_decode(), args.reps)
-  t_beam = timed(lambda: eng.beam_search_decode(args.beam), args.reps)
-  ids, logp = eng.beam_search_decode(args.beam)
+  # the search: median of `samples` runs, the device part (events around the library call) apart from the host share
+  # (launch + D2H of ids / lengths / scores + list building in engine.beam_search_decode)
+  import ctypes
+  import time
+  from speecht_amd import _lib
+  lib = _lib.load()
+  B = eng.dec_lens.numel()
+  ws = eng._storage.view('beam_ws', lib.st_ctc_beam_ws(B, eng.t_out, args.beam) // 4 + 16, torch.int32)[0]
+
+  def device_only():
+    _lib.call('st_ctc_beam_search_decode', eng.X[-1].ref, eng._ptr(eng.ctc_lens), args.beam, eng._ptr(eng.dec_ids), eng.t_out,
+              eng._ptr(eng.dec_lens), eng._ptr(eng.dec_score), eng._ptr(ws), ws.numel() * 4, eng.stream_ptr)
+  eng._wait_uploads()
+  dev_ms, wall_ms = [], []
+  for _ in range(args.samples):
+    dev_ms.append(timed(device_only, 3))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids, logp = eng.beam_search_decode(args.beam)
+    wall_ms.append((time.perf_counter() - t0) * 1e3)
+  t_beam = float(np.median(wall_ms))
   out = {'workload': 'configs[4]: batch {} of {:g} s, T\'={}, beam {}'.format(args.batch, args.seconds, eng.t_out, args.beam),
          'forward_ms': round(t_fwd, 3), 'greedy_ms_incl_d2h': round(t_greedy, 3),
-         'beam_ms_incl_d2h': round(t_beam, 3), 'utt_per_s_forward_plus_beam': round(args.batch / (t_fwd + t_beam) * 1e3, 1),
+         'beam_ms_incl_d2h': round(t_beam, 3), 'beam_ms_device_only': round(float(np.median(dev_ms)), 3),
+         'beam_ms_host_share': round(t_beam - float(np.median(dev_ms)), 3),
+         'beam_ms_incl_d2h_all': [round(v, 3) for v in wall_ms], 'beam_ms_device_only_all': [round(v, 3) for v in dev_ms],
+         'method': 'median of {} runs; device = HIP events around st_ctc_beam_search_decode (log-softmax rows + search kernel), '
+                   'wall = engine.beam_search_decode incl. D2H and list building'.format(args.samples),
+         'utt_per_s_forward_plus_beam': round(args.batch / (t_fwd + t_beam) * 1e3, 1),
          'mean_decoded_len': float(np.mean([len(i) for i in ids]))}
   print(json.dumps(out))
 

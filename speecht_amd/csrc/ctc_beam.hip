@@ -5,10 +5,15 @@
 // candidate order of oracle/w2l_oracle.py::ctc_beam_search_decode (total desc, slot*C + c asc).
 //
 // Mapping: ONE wavefront per utterance (the recursion is sequential in time, utterances are the
-// parallel axis).  Everything that lives across frames -- the beam entries -- sits in LDS, double
-// buffered; a frame is: log-softmax of the 29 logits (wave reduce), parent matching (W^2 hash compares
-// spread over the lanes), one sortable 32-bit score per candidate (W*C of them, lane-strided, in registers),
-// and a wave-parallel selection of the W best: the W-th largest lane maximum bounds the W-th largest
+// parallel axis), so a frame is a chain of dependent steps on one wave and its length IS the decode time
+// (round 2: 13 300 cycles per frame, measured per phase with s_memtime; round 3: the chain below).
+// What does not depend on the beam is taken off the chain: the log-softmax of every frame is computed by a
+// fully parallel kernel first (same wave reductions, bit-identical values) and read one frame ahead.
+// Everything that lives across frames -- the beam entries -- sits in LDS, double buffered; a frame is:
+// parent matching (W^2 hash compares spread over the lanes, all LDS reads of the four passes issued before the
+// first compare), the stay candidates, one sortable 32-bit score per candidate (W*C of them, lane-strided, in
+// registers; branch-free, three LDS reads each), and a wave-parallel selection of the W best: the W-th largest
+// LANE maximum -- found by a 32-step radix select on ballots, not by ranking the lanes -- bounds the W-th largest
 // candidate from below, the few candidates at or above it are compacted into LDS and ranked by counting
 // (sequential maximum rounds remain for the rare case of more than 64 survivors).  Prefix identity is a
 // 64-bit mixed hash + length (the trie TF keeps in host memory would be a pointer chase per candidate);
@@ -96,21 +101,36 @@ __device__ __forceinline__ float order_value(unsigned ord) {
   return __int_as_float((int)(ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu)));
 }
 
+// log-softmax of every frame, one wavefront per frame: out[(b * T + t) * 32 + c] (0 for c >= C).  The same wave reductions
+// in the same order as the search kernel used when it did this inside its frame loop, so the values are bit-identical;
+// frames at or beyond an utterance's length are skipped.
+__global__ __launch_bounds__(256) void logsoftmax_rows_kernel(const float* __restrict__ logits, RowMap map, int T, int C,
+                                                              const int* __restrict__ seq_lens, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= min(seq_lens[b], T)) return;
+  const float x = lane < C ? logits[map.off(b, t) + lane] : -INFINITY;
+  const float m = wave_max_f32(x);
+  const float z = wave_sum_f32(lane < C ? expf(x - m) : 0.f);
+  if (lane < kMaxClasses) out[((long)b * T + t) * kMaxClasses + lane] = lane < C ? x - m - logf(z) : 0.f;
+}
+
 // CPL = candidates per lane (beam_width * C <= 64 * CPL)
 template <int CPL>
-__global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ logits, RowMap map, int T, int C,
+__global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ lp_all, int T, int C,
                                                       const int* __restrict__ seq_lens, int W,
                                                       int2* __restrict__ node_pool, long pool_stride,
                                                       int* __restrict__ ids, int max_out,
                                                       int* __restrict__ out_lens, float* __restrict__ out_logp) {
   __shared__ BeamSet sets[2];
   __shared__ float lp_s[kMaxClasses];
-  __shared__ float2 base_s[kMaxBeam];           // {total, p_blank} of the previous frame
-  __shared__ float stay_pb[kMaxBeam], stay_pl[kMaxBeam], stay_total[kMaxBeam];
+  // per beam entry, for the scoring pass: {total, p_blank of the previous frame, total of the stay candidate, last label}
+  __shared__ __attribute__((aligned(16))) float4 slot_s[kMaxBeam];
+  __shared__ float stay_pb[kMaxBeam], stay_pl[kMaxBeam];
   __shared__ int parent_of[kMaxBeam];
   __shared__ unsigned dead[kMaxBeam];
   __shared__ int sel_k[kMaxBeam];
-  __shared__ unsigned long long surv[64];         // compacted survivor keys of the fast selection
+  __shared__ unsigned long long surv[64 + 4];     // compacted survivor keys of the fast selection (+ zero pad)
   __shared__ float sel_v[kMaxBeam];
 
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -136,31 +156,46 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   }
   __syncthreads();
 
-  float x_next = (lane < C && Tb > 0) ? logits[map.off(b, 0) + lane] : -INFINITY;
+  // log-softmax rows of this utterance, written by logsoftmax_rows_kernel: [t][32]
+  const float* __restrict__ lp_rows = lp_all + (long)b * T * kMaxClasses;
+  float lp_next = (lane < kMaxClasses && Tb > 0) ? lp_rows[lane] : 0.f;
   for (int t = 0; t < Tb; ++t) {
     const BeamSet& S = sets[cur];
     BeamSet& N = sets[cur ^ 1];
-    const float x = x_next;
-    if (t + 1 < Tb && lane < C) x_next = logits[map.off(b, t + 1) + lane];     // hide the HBM latency of frame t+1
-    // (1) log-softmax of this frame
-    {
-      float m = wave_max_f32(x);
-      float z = wave_sum_f32(lane < C ? expf(x - m) : 0.f);
-      if (lane < C) lp_s[lane] = x - m - logf(z);
-      parent_of[lane] = -1;
-      dead[lane] = 0u;
-    }
+    // (1) this frame's log-probabilities into LDS; the next frame's row is already on its way
+    if (lane < kMaxClasses) lp_s[lane] = lp_next;
+    if (t + 1 < Tb && lane < kMaxClasses) lp_next = lp_rows[(long)(t + 1) * kMaxClasses + lane];
+    parent_of[lane] = -1;
+    dead[lane] = 0u;
     __syncthreads();
-    // (2) which entries have their parent prefix in the beam?  (e, p) pairs spread over the lanes
+    // (2) which entries have their parent prefix in the beam?  (e, p) pairs spread over the lanes; the LDS reads of all
+    // passes are issued before the first compare (a pass at a time each one waits a full LDS round trip)
     {
       int lg = 32 - __clz(max(nb - 1, 1));
       if (nb <= 1) lg = 0;
-      const int wp = 1 << lg;
-      for (int idx = lane; idx < (nb << lg); idx += 64) {
-        int e = idx >> lg, p = idx & (wp - 1);
-        if (p < nb && S.len[p] + 1 == S.len[e] && S.hash[p] == S.parent_hash[e]) {
-          parent_of[e] = p;
-          atomicOr(&dead[p], 1u << S.last[e]);     // child (p, last[e]) already exists: merged into e's stay
+      const int wp = 1 << lg, pairs = nb << lg;
+      constexpr int PASSES = 4;                      // 64 * 4 = 16 x 16 pairs; wider beams loop
+      for (int idx0 = 0; idx0 < pairs; idx0 += 64 * PASSES) {
+        int e_[PASSES], p_[PASSES], len_e[PASSES], len_p[PASSES], last_e[PASSES];
+        unsigned long long hp[PASSES], he[PASSES];
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+          const int idx = idx0 + lane + 64 * i;
+          const bool in = idx < pairs && (idx & (wp - 1)) < nb;
+          e_[i] = in ? idx >> lg : 0;
+          p_[i] = in ? idx & (wp - 1) : 0;
+          len_e[i] = in ? S.len[e_[i]] : -7;
+          len_p[i] = S.len[p_[i]];
+          hp[i] = S.hash[p_[i]];
+          he[i] = S.parent_hash[e_[i]];
+          last_e[i] = S.last[e_[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+          if (len_p[i] + 1 == len_e[i] && hp[i] == he[i]) {
+            parent_of[e_[i]] = p_[i];
+            atomicOr(&dead[p_[i]], 1u << last_e[i]);     // child (p, last[e]) already exists: merged into e's stay
+          }
         }
       }
     }
@@ -178,30 +213,34 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       }
       stay_pb[lane] = npb;
       stay_pl[lane] = npl;
-      stay_total[lane] = lse(npb, npl);
-      base_s[lane] = make_float2(tot, S.pb[lane]);
+      slot_s[lane] = make_float4(tot, S.pb[lane], lse(npb, npl), __int_as_float(S.last[lane]));
     }
     __syncthreads();
     // (3) one sortable 32-bit score per candidate, in registers (candidate index k = lane + 64 j is implicit)
     unsigned ord[CPL];
     unsigned best_ord = 0u;                               // 0 is below every real candidate
     int best_j = 0;
+    {
+      // all reads first (three per candidate, none behind a branch), then the arithmetic
+      float4 info[CPL];
+      unsigned dd[CPL];
+      float lpc[CPL];
 #pragma unroll
-    for (int j = CPL - 1; j >= 0; --j) {                  // descending j + ">=": the lowest j wins a tie
-      const int slot = cslot[j], c = ccls[j];
-      unsigned oj = 0u;
-      if (slot < nb) {
-        float v;
-        if (c == blank) {
-          v = stay_total[slot];
-        } else {
-          float2 base = base_s[slot];
-          v = ((dead[slot] >> c) & 1u) ? -INFINITY : ((S.last[slot] == c) ? base.y : base.x) + lp_s[c];
-        }
-        oj = order_bits(v);
+      for (int j = 0; j < CPL; ++j) {
+        const int sl = cslot[j] < nb ? cslot[j] : 0;
+        info[j] = slot_s[sl];
+        dd[j] = dead[sl];
+        lpc[j] = lp_s[ccls[j]];
       }
-      ord[j] = oj;
-      if (oj >= best_ord) { best_ord = oj; best_j = j; }
+#pragma unroll
+      for (int j = CPL - 1; j >= 0; --j) {                // descending j + ">=": the lowest j wins a tie
+        const int c = ccls[j];
+        const float child = ((dd[j] >> c) & 1u) ? -INFINITY : ((__float_as_int(info[j].w) == c) ? info[j].y : info[j].x) + lpc[j];
+        const float v = c == blank ? info[j].z : child;
+        const unsigned oj = cslot[j] < nb ? order_bits(v) : 0u;
+        ord[j] = oj;
+        if (oj >= best_ord) { best_ord = oj; best_j = j; }
+      }
     }
     // (4) selection of the W best candidates, best first.
     // Fast path (threshold + rank): the W-th largest LANE maximum is a lower bound of the W-th largest
@@ -212,15 +251,19 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     int n_new = 0;
     bool selected = false;
     if (CPL <= 16) {
-      int ahead = 0;                                      // lanes whose maximum precedes mine (ties: lower lane)
-#pragma unroll 16
-      for (int i = 0; i < 64; ++i) {
-        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)best_ord, i);
-        ahead += (o > best_ord) || (o == best_ord && i < lane);
-      }
       const int live_lanes = __builtin_popcountll(__ballot(best_ord > kOrdNegInf));
       unsigned thr = kOrdNegInf + 1u;                     // fewer than W live lanes: every live candidate survives
-      if (live_lanes >= W) thr = (unsigned)__builtin_amdgcn_readlane((int)best_ord, __builtin_ctzll(__ballot(ahead == W - 1)));
+      if (live_lanes >= W) {
+        // the W-th largest lane maximum = the largest v with at least W lane maxima >= v: a radix select, one ballot and
+        // a population count per bit (ranking the 64 lanes against each other took 3 800 of the 13 300 cycles of a frame)
+        unsigned prefix = 0u;
+#pragma unroll
+        for (int bit = 31; bit >= 0; --bit) {
+          const unsigned trial = prefix | (1u << bit);
+          if (__builtin_popcountll(__ballot(best_ord >= trial)) >= W) prefix = trial;
+        }
+        thr = prefix;
+      }
       int base = 0;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {                     // compaction in candidate order k = lane + 64 j
@@ -233,11 +276,15 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       if (base <= 64) {
         selected = true;
         n_new = min(base, W);
+        if (lane < 4) surv[min(base, 64) + lane] = 0ull;       // pad: the counting loop reads four keys at a time
         __syncthreads();
         if (lane < base) {
           const unsigned long long mine = surv[lane];
           int rank = 0;
-          for (int t2 = 0; t2 < base; ++t2) rank += surv[t2] > mine;
+          for (int t2 = 0; t2 < base; t2 += 4) {
+            const unsigned long long k0 = surv[t2], k1 = surv[t2 + 1], k2 = surv[t2 + 2], k3 = surv[t2 + 3];
+            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine);
+          }
           if (rank < W) {
             sel_k[rank] = (int)(0xFFFFFFFFu - (unsigned)mine);
             sel_v[rank] = order_value((unsigned)(mine >> 32));
@@ -317,9 +364,14 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
 
 extern "C" {
 
+static size_t beam_pool_bytes(int batch, int frames, int beam_width) {
+  return st::round_up((size_t)batch * ((size_t)frames * beam_width + 1) * sizeof(int2), 256);
+}
+
+// [node pool: (parent, label) pairs | log-softmax rows [batch][frames][32]]
 size_t st_ctc_beam_ws(int batch, int frames, int beam_width) {
   if (batch <= 0 || frames < 0 || beam_width <= 0) return 0;
-  return (size_t)batch * ((size_t)frames * beam_width + 1) * sizeof(int2);
+  return beam_pool_bytes(batch, frames, beam_width) + (size_t)batch * frames * kMaxClasses * sizeof(float);
 }
 
 int st_ctc_beam_search_decode(const st_tensor3* logits, const int32_t* seq_lens, int beam_width, int32_t* ids,
@@ -338,10 +390,13 @@ int st_ctc_beam_search_decode(const st_tensor3* logits, const int32_t* seq_lens,
   }
   if (logits->batch == 0) return ST_OK;
   RowMap map{(long)logits->t_pitch * logits->c_pitch, (long)logits->halo * logits->c_pitch, logits->c_pitch};
+  float* lp_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + beam_pool_bytes(logits->batch, logits->frames, beam_width));
+  hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(st::ceil_div(logits->frames, 4), logits->batch), dim3(256), 0, st::as_stream(stream),
+                     logits->base, map, logits->frames, logits->channels, seq_lens, lp_rows);
   const int per_lane = st::ceil_div(beam_width * logits->channels, 64);
 #define ST_LAUNCH_BEAM(CPL)                                                                                          \
-  hipLaunchKernelGGL(ctc_beam_kernel<CPL>, dim3(logits->batch), dim3(64), 0, st::as_stream(stream), logits->base,    \
-                     map, logits->frames, logits->channels, seq_lens, beam_width,                                    \
+  hipLaunchKernelGGL(ctc_beam_kernel<CPL>, dim3(logits->batch), dim3(64), 0, st::as_stream(stream), lp_rows,         \
+                     logits->frames, logits->channels, seq_lens, beam_width,                                         \
                      reinterpret_cast<int2*>(workspace), (long)logits->frames * beam_width + 1, ids, max_out,        \
                      out_lens, log_prob)
   if (per_lane <= 4) ST_LAUNCH_BEAM(4);

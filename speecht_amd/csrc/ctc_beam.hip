@@ -55,8 +55,11 @@ __device__ __forceinline__ unsigned long long child_hash(unsigned long long h, i
 }
 
 __device__ __forceinline__ float lse(float a, float b) {
+  // hardware exp2 / log2 (1 ulp): the two calls sit on the per-frame dependent chain of the search, and the libm forms
+  // (range reduction + polynomial, ~40 instructions each) were a fifth of the `stay` phase; the result differs from them
+  // by < 2e-7, far inside the 1e-4 the scores are held to
   float hi = fmaxf(a, b), lo = fminf(a, b);
-  return hi == -INFINITY ? -INFINITY : hi + log1pf(expf(lo - hi));
+  return hi == -INFINITY ? -INFINITY : hi + __logf(1.f + __expf(lo - hi));
 }
 
 // ---- wave64 reductions on the DPP network (row shifts + row broadcasts; no LDS round trips) --------
@@ -115,6 +118,12 @@ __global__ __launch_bounds__(256) void logsoftmax_rows_kernel(const float* __res
   if (lane < kMaxClasses) out[((long)b * T + t) * kMaxClasses + lane] = lane < C ? x - m - logf(z) : 0.f;
 }
 
+// The search kernel runs ONE wavefront per workgroup, and a wave's LDS operations execute in order: between its phases it
+// needs no s_barrier, only the compiler kept from moving LDS accesses across the phase boundary and the LDS queue drained.
+// __syncthreads() would also wait for vmcnt(0) -- i.e. for the next frame's log-probabilities, whose load is meant to stay
+// in flight under this frame's work.
+#define ST_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 // CPL = candidates per lane (beam_width * C <= 64 * CPL)
 template <int CPL>
 __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ lp_all, int T, int C,
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   __shared__ int parent_of[kMaxBeam];
   __shared__ unsigned dead[kMaxBeam];
   __shared__ int sel_k[kMaxBeam];
-  __shared__ unsigned long long surv[64 + 4];     // compacted survivor keys of the fast selection (+ zero pad)
+  __shared__ __attribute__((aligned(16))) unsigned long long surv[128 + 16];   // compacted survivor keys of the fast selection (+ zero pad)
   __shared__ float sel_v[kMaxBeam];
 
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     if (t + 1 < Tb && lane < kMaxClasses) lp_next = lp_rows[(long)(t + 1) * kMaxClasses + lane];
     parent_of[lane] = -1;
     dead[lane] = 0u;
-    __syncthreads();
+    ST_WAVE_SYNC();
     // (2) which entries have their parent prefix in the beam?  (e, p) pairs spread over the lanes; the LDS reads of all
     // passes are issued before the first compare (a pass at a time each one waits a full LDS round trip)
     {
@@ -175,47 +184,62 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       if (nb <= 1) lg = 0;
       const int wp = 1 << lg, pairs = nb << lg;
       constexpr int PASSES = 4;                      // 64 * 4 = 16 x 16 pairs; wider beams loop
-      for (int idx0 = 0; idx0 < pairs; idx0 += 64 * PASSES) {
-        int e_[PASSES], p_[PASSES], len_e[PASSES], len_p[PASSES], last_e[PASSES];
-        unsigned long long hp[PASSES], he[PASSES];
+      if (wp <= 64 && pairs <= 64 * PASSES) {
+        // p = lane & (wp - 1) for every pass: the candidate parent's fields are read once
+        const int p = lane & (wp - 1);
+        const bool p_in = p < nb;
+        const int len_p = S.len[p_in ? p : 0];
+        const unsigned long long hp = S.hash[p_in ? p : 0];
+        int e_[PASSES], len_e[PASSES], last_e[PASSES];
+        unsigned long long he[PASSES];
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-          const int idx = idx0 + lane + 64 * i;
-          const bool in = idx < pairs && (idx & (wp - 1)) < nb;
+          const int idx = lane + 64 * i;
+          const bool in = idx < pairs && p_in;
           e_[i] = in ? idx >> lg : 0;
-          p_[i] = in ? idx & (wp - 1) : 0;
           len_e[i] = in ? S.len[e_[i]] : -7;
-          len_p[i] = S.len[p_[i]];
-          hp[i] = S.hash[p_[i]];
           he[i] = S.parent_hash[e_[i]];
           last_e[i] = S.last[e_[i]];
         }
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-          if (len_p[i] + 1 == len_e[i] && hp[i] == he[i]) {
-            parent_of[e_[i]] = p_[i];
-            atomicOr(&dead[p_[i]], 1u << last_e[i]);     // child (p, last[e]) already exists: merged into e's stay
+          if (len_p + 1 == len_e[i] && hp == he[i]) {
+            parent_of[e_[i]] = p;
+            atomicOr(&dead[p], 1u << last_e[i]);         // child (p, last[e]) already exists: merged into e's stay
+          }
+        }
+      } else {
+        for (int idx = lane; idx < pairs; idx += 64) {
+          const int e = idx >> lg, p = idx & (wp - 1);
+          if (p < nb && S.len[p] + 1 == S.len[e] && S.hash[p] == S.parent_hash[e]) {
+            parent_of[e] = p;
+            atomicOr(&dead[p], 1u << S.last[e]);
           }
         }
       }
     }
-    __syncthreads();
+    ST_WAVE_SYNC();
     // (2b) the stay candidate of entry `lane`
     if (lane < nb) {
-      float tot = S.total[lane];
-      float npb = tot + lp_s[blank];
+      // every LDS read up front (own fields, then the parent's through a clamped index), the arithmetic behind them
+      const float tot = S.total[lane], pl0 = S.pl[lane], pb0 = S.pb[lane];
+      const int len0 = S.len[lane], last0 = S.last[lane], p = parent_of[lane];
+      const float lp_blank = lp_s[blank], lp_last = lp_s[max(last0, 0)];
+      const int pc = max(p, 0);
+      const int plen = S.len[pc], plast = S.last[pc];
+      const float ppb = S.pb[pc], ptot = S.total[pc];
+      const float npb = tot + lp_blank;
       float npl = -INFINITY;
-      if (S.len[lane] > 0) {
-        float mass = S.pl[lane];
-        int p = parent_of[lane];
-        if (p >= 0) mass = lse(mass, (S.len[p] > 0 && S.last[p] == S.last[lane]) ? S.pb[p] : S.total[p]);
-        npl = mass + lp_s[S.last[lane]];
+      if (len0 > 0) {
+        float mass = pl0;
+        if (p >= 0) mass = lse(mass, (plen > 0 && plast == last0) ? ppb : ptot);
+        npl = mass + lp_last;
       }
       stay_pb[lane] = npb;
       stay_pl[lane] = npl;
-      slot_s[lane] = make_float4(tot, S.pb[lane], lse(npb, npl), __int_as_float(S.last[lane]));
+      slot_s[lane] = make_float4(tot, pb0, lse(npb, npl), __int_as_float(last0));
     }
-    __syncthreads();
+    ST_WAVE_SYNC();
     // (3) one sortable 32-bit score per candidate, in registers (candidate index k = lane + 64 j is implicit)
     unsigned ord[CPL];
     unsigned best_ord = 0u;                               // 0 is below every real candidate
@@ -243,52 +267,83 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       }
     }
     // (4) selection of the W best candidates, best first.
-    // Fast path (threshold + rank): the W-th largest LANE maximum is a lower bound of the W-th largest
-    // candidate, so only candidates at or above it ("survivors", a few dozen at most in practice) can be
-    // selected; they are compacted into LDS in candidate order and every survivor finds its rank by counting the
-    // survivors ahead of it (keys are unique: score, then smaller candidate index).  All of it is wave-parallel;
-    // the sequential rounds below remain as the fallback for more than 64 survivors (flat posteriors, wide beams).
+    // Fast path (threshold + rank): a cheap lower bound of the W-th largest candidate; only candidates at or above it
+    // ("survivors", a few dozen) can be selected; they are compacted into LDS and every survivor finds its rank by counting
+    // the survivors ahead of it (keys are unique: score, then smaller candidate index).  All of it is wave-parallel; the
+    // sequential rounds below remain as the fallback for more than 128 survivors and for beams wider than 16.
     int n_new = 0;
     bool selected = false;
-    if (CPL <= 16) {
-      const int live_lanes = __builtin_popcountll(__ballot(best_ord > kOrdNegInf));
-      unsigned thr = kOrdNegInf + 1u;                     // fewer than W live lanes: every live candidate survives
-      if (live_lanes >= W) {
-        // the W-th largest lane maximum = the largest v with at least W lane maxima >= v: a radix select, one ballot and
-        // a population count per bit (ranking the 64 lanes against each other took 3 800 of the 13 300 cycles of a frame)
-        unsigned prefix = 0u;
+    if (CPL <= 16 && W <= 16) {
+      // A lower bound of the W-th largest candidate that costs ten instructions: the lanes form 64 / 4 = 16 quads, every quad
+      // maximum is a candidate, so at least 16 candidates are >= the SMALLEST quad maximum (wider beams than 16 take the
+      // sequential path below).  It is looser than the W-th largest lane maximum of round 2 (flat posteriors: ~48 survivors
+      // instead of ~20) but that bound cost a ranking of the 64 lanes -- 3 800 of the frame's 13 300 cycles as 64 v_readlane
+      // steps, 1 700 as a 32-step radix select on ballots, more again as 16 four-key LDS reads -- and the survivors are
+      // ranked by counting anyway.
+      unsigned thr = kOrdNegInf + 1u;                     // a quad without a live candidate: every live candidate survives
+      if (W <= 16) {
+        unsigned g = best_ord;
+        g = max(g, (unsigned)dpp_i32<0xB1, 0xf, false>((int)g, (int)g));      // quad_perm [1, 0, 3, 2]
+        g = max(g, (unsigned)dpp_i32<0x4E, 0xf, false>((int)g, (int)g));      // quad_perm [2, 3, 0, 1]
+        thr = max(wave_min_u32(g), kOrdNegInf + 1u);
+      }
+      // compaction of the survivors into LDS: a lane's survivors sit behind those of the lanes below it (one wave prefix
+      // sum instead of a ballot per candidate row; the keys carry the candidate index, so the order does not matter)
+      int mine_n = 0;
 #pragma unroll
-        for (int bit = 31; bit >= 0; --bit) {
-          const unsigned trial = prefix | (1u << bit);
-          if (__builtin_popcountll(__ballot(best_ord >= trial)) >= W) prefix = trial;
+      for (int j = 0; j < CPL; ++j) mine_n += (ord[j] >= thr && ord[j] > kOrdNegInf) ? 1 : 0;
+      int incl = mine_n;
+#define ST_STEP(CTRL, MASK) incl += dpp_i32<CTRL, MASK, true>(0, incl)
+      ST_STEP(0x111, 0xf); ST_STEP(0x112, 0xf); ST_STEP(0x114, 0xf); ST_STEP(0x118, 0xf);   // scan inside each row of 16
+      ST_STEP(0x142, 0xa); ST_STEP(0x143, 0xc);                                            // carry the rows' totals up
+#undef ST_STEP
+      const int base = __builtin_amdgcn_readlane(incl, 63);
+      if (base <= 128) {
+        int pos = incl - mine_n;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (ord[j] >= thr && ord[j] > kOrdNegInf)
+            surv[pos++] = ((unsigned long long)ord[j] << 32) | (0xFFFFFFFFu - (unsigned)(lane + 64 * j));
         }
-        thr = prefix;
-      }
-      int base = 0;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {                     // compaction in candidate order k = lane + 64 j
-        const bool keep = ord[j] >= thr && ord[j] > kOrdNegInf;
-        const unsigned long long m = __ballot(keep);
-        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (keep && pos < 64) surv[pos] = ((unsigned long long)ord[j] << 32) | (0xFFFFFFFFu - (unsigned)(lane + 64 * j));
-        base += __builtin_popcountll(m);
-      }
-      if (base <= 64) {
         selected = true;
         n_new = min(base, W);
-        if (lane < 4) surv[min(base, 64) + lane] = 0ull;       // pad: the counting loop reads four keys at a time
-        __syncthreads();
-        if (lane < base) {
-          const unsigned long long mine = surv[lane];
-          int rank = 0;
+        if (lane < 16) surv[min(base + lane, 128 + 15)] = 0ull; // pad: the counting loop reads up to sixteen keys past the end
+        ST_WAVE_SYNC();
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        // every survivor finds its rank by counting the survivors ahead of it (keys are unique); lane l ranks survivors
+        // l and l + 64
+        const bool has0 = lane < base, has1 = lane + 64 < base;
+        const unsigned long long mine0 = surv[has0 ? lane : 0], mine1 = surv[has1 ? lane + 64 : 0];
+        int rank0 = 0, rank1 = 0;
+        if (base <= 64) {                                       // (wave-uniform)
+          // eight keys per trip, the next trip's reads issued before this trip's compares (the trip count is small and
+          // every trip would otherwise wait out a full LDS round trip)
+          u64x2 q[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const u64x2*>(&surv[2 * k]);
+          for (int t2 = 0; t2 < base; t2 += 8) {
+            u64x2 n[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) n[k] = *reinterpret_cast<const u64x2*>(&surv[min(t2 + 8, 128) + 2 * k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rank0 += (q[k][0] > mine0) + (q[k][1] > mine0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = n[k];
+          }
+        } else {
           for (int t2 = 0; t2 < base; t2 += 4) {
-            const unsigned long long k0 = surv[t2], k1 = surv[t2 + 1], k2 = surv[t2 + 2], k3 = surv[t2 + 3];
-            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine);
+            const u64x2 a = *reinterpret_cast<const u64x2*>(&surv[t2]), c2 = *reinterpret_cast<const u64x2*>(&surv[t2 + 2]);
+            rank0 += (a[0] > mine0) + (a[1] > mine0) + (c2[0] > mine0) + (c2[1] > mine0);
+            rank1 += (a[0] > mine1) + (a[1] > mine1) + (c2[0] > mine1) + (c2[1] > mine1);
           }
-          if (rank < W) {
-            sel_k[rank] = (int)(0xFFFFFFFFu - (unsigned)mine);
-            sel_v[rank] = order_value((unsigned)(mine >> 32));
-          }
+        }
+        if (has0 && rank0 < W) {
+          sel_k[rank0] = (int)(0xFFFFFFFFu - (unsigned)mine0);
+          sel_v[rank0] = order_value((unsigned)(mine0 >> 32));
+        }
+        if (has1 && rank1 < W) {
+          sel_k[rank1] = (int)(0xFFFFFFFFu - (unsigned)mine1);
+          sel_v[rank1] = order_value((unsigned)(mine1 >> 32));
         }
       }
     }
@@ -317,7 +372,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
         }
       }
     }
-    __syncthreads();
+    ST_WAVE_SYNC();
     // (5) materialise the surviving entries, best first.  Scores are kept RELATIVE to the best entry (its
     // total becomes 0) with the running offset in double: after 1500 frames the absolute log-probabilities
     // are O(-3000), where fp32 resolves only 2e-4 and near-ties at the beam boundary would be decided by
@@ -325,26 +380,31 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     const float top = n_new > 0 ? sel_v[0] : 0.f;
     offset += (double)top;
     if (lane < n_new) {
-      int k = sel_k[lane];
-      int slot = k / C, c = k - slot * C;
-      if (c == blank) {
-        N.hash[lane] = S.hash[slot]; N.parent_hash[lane] = S.parent_hash[slot];
-        N.len[lane] = S.len[slot]; N.last[lane] = S.last[slot]; N.node[lane] = S.node[slot];
-        N.pb[lane] = stay_pb[slot] - top; N.pl[lane] = stay_pl[slot] - top;
-      } else {
-        int id = 1 + t * W + lane;
-        nodes[id] = make_int2(S.node[slot], c);
-        N.hash[lane] = child_hash(S.hash[slot], c); N.parent_hash[lane] = S.hash[slot];
-        N.len[lane] = S.len[slot] + 1; N.last[lane] = c; N.node[lane] = id;
-        N.pb[lane] = -INFINITY; N.pl[lane] = sel_v[lane] - top;
-      }
-      N.total[lane] = sel_v[lane] - top;
+      const int k = sel_k[lane];
+      const float v = sel_v[lane];
+      const int slot = k / C, c = k - slot * C;
+      // the parent entry's fields, read before the stay / child decision
+      const unsigned long long h0 = S.hash[slot], ph0 = S.parent_hash[slot];
+      const int len0 = S.len[slot], last0 = S.last[slot], node0 = S.node[slot];
+      const float spb = stay_pb[slot], spl = stay_pl[slot];
+      const bool stay = c == blank;
+      const int id = 1 + t * W + lane;
+      if (!stay) nodes[id] = make_int2(node0, c);
+      N.hash[lane] = stay ? h0 : child_hash(h0, c);
+      N.parent_hash[lane] = stay ? ph0 : h0;
+      N.len[lane] = stay ? len0 : len0 + 1;
+      N.last[lane] = stay ? last0 : c;
+      N.node[lane] = stay ? node0 : id;
+      N.pb[lane] = stay ? spb - top : -INFINITY;
+      N.pl[lane] = stay ? spl - top : v - top;
+      N.total[lane] = v - top;
     }
     nb = n_new;
     cur ^= 1;
-    __syncthreads();
+    ST_WAVE_SYNC();
   }
 
+  __syncthreads();
   // top path: entry 0 of the final set; walk the node chain backwards
   if (lane == 0) {
     const BeamSet& S = sets[cur];

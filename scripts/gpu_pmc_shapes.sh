@@ -26,7 +26,7 @@ for tag in ('f', 'w', 's'):
     dur = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9 for r in csv.DictReader(open(kt[0]))}
     seen = set()
     for r in csv.DictReader(open(cc[0])):
-        m = re.search(r'(gemm_\w+<[^>]*>)', r['Kernel_Name'])
+        m = re.search(os.environ.get('KERNEL_FILTER', r'(gemm_\w+<[^>]*>)'), r['Kernel_Name'])
         if not m:
             continue
         key = '%s grid=%s' % (m.group(1), r.get('Grid_Size', r.get('Grid_Size_X', '?')))

@@ -105,5 +105,5 @@ r = b['roofline']
 print('bench: %.3f ms/step (median %.3f), %s in-step frac %.4f (isolated %s), step_hw_frac %s' % (
     b['ms_per_step'], b['ms_per_step_median'], r['kernel'], r['frac'], (r.get('isolated') or {}).get('frac'), b.get('step_hw_frac')))
 PY
-rm -rf gpurun_out/round${TAG}_prof/*kernel_trace.csv $OUT/pmc_*/*/*kernel_trace.csv $OUT/pmc_*/*/*counter_collection.csv 2>/dev/null
+find gpurun_out/round${TAG}_prof $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name '*.csv' -size +5M -delete

@@ -1,4 +1,5 @@
 // libspeecht_hip.so: version, thread-local error text, launch trace and tuning overrides (diagnostics).
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -22,8 +23,8 @@ void set_error(const char* fmt, ...) {
 static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + device time stamps
 static std::mutex g_trace_mu;
 static std::vector<std::string> g_lines;
-constexpr int kMaxTimed = 1 << 15;
-static unsigned long long* g_stamps = nullptr;     // device: begin[kMaxTimed] (all ones) | end[kMaxTimed] (zeros)
+constexpr int kMaxTimed = 1 << 14, kStampWays = 8;
+static unsigned long long* g_stamps = nullptr;     // device: begin[kMaxTimed][8] (all ones) | end[kMaxTimed][8] (zeros)
 static std::vector<int> g_timed_line;              // slot -> trace line
 static thread_local int g_last_line = -1;
 bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
@@ -48,7 +49,7 @@ LaunchTimer::LaunchTimer(hipStream_t) : stamp_{nullptr, nullptr} {
   if (!g_stamps || (int)g_timed_line.size() >= kMaxTimed) return;
   const int slot = (int)g_timed_line.size();
   g_timed_line.push_back(g_last_line);
-  stamp_ = Stamp{g_stamps + slot, g_stamps + kMaxTimed + slot};
+  stamp_ = Stamp{g_stamps + (size_t)slot * kStampWays, g_stamps + (size_t)(kMaxTimed + slot) * kStampWays};
 }
 
 // ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
@@ -69,14 +70,14 @@ static int trace_begin(int mode) {
   st::g_timed_line.clear();
   if (mode == 2) {
     // the stamp slots: allocated on first use and kept (diagnostics only; no launch path allocates)
-    if (!st::g_stamps && hipMalloc(&st::g_stamps, 2 * st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess) {
+    if (!st::g_stamps && hipMalloc(&st::g_stamps, 2 * (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess) {
       st::g_stamps = nullptr;
       st::set_error("st_trace_begin_timed: cannot allocate the stamp buffer");
       return ST_ELAUNCH;
     }
     if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemset(st::g_stamps, 0xFF, st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(st::g_stamps + st::kMaxTimed, 0, st::kMaxTimed * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(st::g_stamps, 0xFF, (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(st::g_stamps + (size_t)st::kMaxTimed * st::kStampWays, 0, (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
       st::set_error("st_trace_begin_timed: cannot clear the stamp buffer");
       return ST_ELAUNCH;
@@ -93,7 +94,7 @@ size_t st_trace_end(char* host_buf, size_t capacity) {
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
   // timed mode: wait for the device, read the stamps back and append each launch's duration to its line (once)
   if (!st::g_timed_line.empty() && st::g_stamps) {
-    const size_t n = st::g_timed_line.size();
+    const size_t launches = st::g_timed_line.size(), n = launches * st::kStampWays;
     std::vector<unsigned long long> b(n), e(n);
     int rate_khz = 0, dev = 0;
     hipGetDevice(&dev);
@@ -101,10 +102,15 @@ size_t st_trace_end(char* host_buf, size_t capacity) {
     if (rate_khz <= 0) rate_khz = 100000;                                   // s_memrealtime: 100 MHz
     const bool ok = hipDeviceSynchronize() == hipSuccess &&
                     hipMemcpy(b.data(), st::g_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess &&
-                    hipMemcpy(e.data(), st::g_stamps + st::kMaxTimed, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
-    for (size_t i = 0; i < n; ++i) {
+                    hipMemcpy(e.data(), st::g_stamps + (size_t)st::kMaxTimed * st::kStampWays, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+    for (size_t i = 0; i < launches; ++i) {
       const int line = st::g_timed_line[i];
-      const double ms = (ok && e[i] >= b[i] && b[i] != ~0ull) ? (double)(e[i] - b[i]) / rate_khz : -1.0;
+      unsigned long long lo = ~0ull, hi = 0ull;                               // first begin, last end over the 8 ways
+      for (int w = 0; w < st::kStampWays; ++w) {
+        lo = std::min(lo, b[i * st::kStampWays + w]);
+        hi = std::max(hi, e[i * st::kStampWays + w]);
+      }
+      const double ms = (ok && hi >= lo && lo != ~0ull) ? (double)(hi - lo) / rate_khz : -1.0;
       char tail[48];
       snprintf(tail, sizeof(tail), " ms=%.5f", ms);
       if (line >= 0 && line < (int)st::g_lines.size()) st::g_lines[line] += tail;

@@ -55,8 +55,9 @@ const char* st_last_error(void);
  * splits=2 M=16032 Np=256 Kp=64512").  st_trace_end copies the text to a HOST buffer (truncating) and
  * returns the bytes needed including the terminator.  Used by the parity tests to assert which kernels a
  * full-size step really ran.  Every line of a matrix-pipe launch carries "gflop=<executed GFLOP, padding included>".
- * st_trace_begin_timed() additionally brackets every traced launch with a pair of HIP events on the launch's own
- * stream; st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
+ * st_trace_begin_timed() additionally launches every traced kernel through hipExtLaunchKernel with a start and a stop
+ * event (the dispatch's own begin / end time stamps, as a profiler's kernel trace shows them; no marker between
+ * launches); st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
  * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
  * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split"); value 0 restores the library's own policy.

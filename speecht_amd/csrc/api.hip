@@ -19,13 +19,13 @@ void set_error(const char* fmt, ...) {
 
 // ---- launch trace: which kernel variant / split policy a call took (tests assert on it), and -- in timed mode
 // (st_trace_begin_timed) -- how long each traced launch took on its stream inside the real launch sequence: a pair
-// of HIP events around the launch (LaunchTimer), resolved when the trace is collected.
-static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + device time stamps
+// of start / stop events handed to hipExtLaunchKernel (LaunchTimer, st_common.h), resolved when the trace is collected.
+static std::atomic<int> g_trace_on{0};      // 0 off, 1 names, 2 names + per-launch start / stop events
 static std::mutex g_trace_mu;
 static std::vector<std::string> g_lines;
-constexpr int kMaxTimed = 1 << 14, kStampWays = 8;
-static unsigned long long* g_stamps = nullptr;     // device: begin[kMaxTimed][8] (all ones) | end[kMaxTimed][8] (zeros)
-static std::vector<int> g_timed_line;              // slot -> trace line
+constexpr int kMaxTimed = 1 << 14;
+struct TimedLaunch { int line; hipEvent_t e0, e1; };
+static std::vector<TimedLaunch> g_timed;
 static thread_local int g_last_line = -1;
 bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
 void trace(const char* fmt, ...) {
@@ -43,13 +43,16 @@ void trace(const char* fmt, ...) {
     g_last_line = -1;
   }
 }
-LaunchTimer::LaunchTimer(hipStream_t) : stamp_{nullptr, nullptr} {
+LaunchTimer::LaunchTimer(hipStream_t) : start_(nullptr), stop_(nullptr) {
   if (g_trace_on.load(std::memory_order_relaxed) != 2 || g_last_line < 0) return;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess) return;
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
   std::lock_guard<std::mutex> lock(g_trace_mu);
-  if (!g_stamps || (int)g_timed_line.size() >= kMaxTimed) return;
-  const int slot = (int)g_timed_line.size();
-  g_timed_line.push_back(g_last_line);
-  stamp_ = Stamp{g_stamps + (size_t)slot * kStampWays, g_stamps + (size_t)(kMaxTimed + slot) * kStampWays};
+  if ((int)g_timed.size() >= kMaxTimed) { hipEventDestroy(e0); hipEventDestroy(e1); return; }
+  g_timed.push_back(TimedLaunch{g_last_line, e0, e1});
+  start_ = e0;
+  stop_ = e1;
 }
 
 // ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
@@ -67,22 +70,8 @@ const char* st_last_error(void) { return st::g_err; }
 static int trace_begin(int mode) {
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
   st::g_lines.clear();
-  st::g_timed_line.clear();
-  if (mode == 2) {
-    // the stamp slots: allocated on first use and kept (diagnostics only; no launch path allocates)
-    if (!st::g_stamps && hipMalloc(&st::g_stamps, 2 * (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess) {
-      st::g_stamps = nullptr;
-      st::set_error("st_trace_begin_timed: cannot allocate the stamp buffer");
-      return ST_ELAUNCH;
-    }
-    if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemset(st::g_stamps, 0xFF, (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(st::g_stamps + (size_t)st::kMaxTimed * st::kStampWays, 0, (size_t)st::kMaxTimed * st::kStampWays * sizeof(unsigned long long)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
-      st::set_error("st_trace_begin_timed: cannot clear the stamp buffer");
-      return ST_ELAUNCH;
-    }
-  }
+  for (auto& t : st::g_timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+  st::g_timed.clear();
   st::g_trace_on.store(mode);
   return ST_OK;
 }
@@ -92,31 +81,17 @@ int st_trace_begin_timed(void) { return trace_begin(2); }
 size_t st_trace_end(char* host_buf, size_t capacity) {
   st::g_trace_on.store(0);
   std::lock_guard<std::mutex> lock(st::g_trace_mu);
-  // timed mode: wait for the device, read the stamps back and append each launch's duration to its line (once)
-  if (!st::g_timed_line.empty() && st::g_stamps) {
-    const size_t launches = st::g_timed_line.size(), n = launches * st::kStampWays;
-    std::vector<unsigned long long> b(n), e(n);
-    int rate_khz = 0, dev = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
-    if (rate_khz <= 0) rate_khz = 100000;                                   // s_memrealtime: 100 MHz
-    const bool ok = hipDeviceSynchronize() == hipSuccess &&
-                    hipMemcpy(b.data(), st::g_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess &&
-                    hipMemcpy(e.data(), st::g_stamps + (size_t)st::kMaxTimed * st::kStampWays, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
-    for (size_t i = 0; i < launches; ++i) {
-      const int line = st::g_timed_line[i];
-      unsigned long long lo = ~0ull, hi = 0ull;                               // first begin, last end over the 8 ways
-      for (int w = 0; w < st::kStampWays; ++w) {
-        lo = std::min(lo, b[i * st::kStampWays + w]);
-        hi = std::max(hi, e[i * st::kStampWays + w]);
-      }
-      const double ms = (ok && hi >= lo && lo != ~0ull) ? (double)(hi - lo) / rate_khz : -1.0;
-      char tail[48];
-      snprintf(tail, sizeof(tail), " ms=%.5f", ms);
-      if (line >= 0 && line < (int)st::g_lines.size()) st::g_lines[line] += tail;
-    }
-    st::g_timed_line.clear();
+  // timed mode: wait for each launch's stop event and append the kernel's duration to its line (first collection only)
+  for (auto& t : st::g_timed) {
+    float ms = -1.f;
+    if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) ms = -1.f;
+    char tail[48];
+    snprintf(tail, sizeof(tail), " ms=%.5f", ms);
+    if (t.line >= 0 && t.line < (int)st::g_lines.size()) st::g_lines[t.line] += tail;
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
   }
+  st::g_timed.clear();
   size_t need = 1;
   for (const auto& l : st::g_lines) need += l.size() + 1;
   if (host_buf && capacity > 0) {

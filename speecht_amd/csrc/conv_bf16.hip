@@ -233,7 +233,6 @@ struct X6Params {
   int tiles_m, tiles_n, chunk;           // XCD-aware tile order: the 8 XCDs as a gm x gn grid over the tile grid,
   int gm, tm_per, tn_per;                // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per), see launch_gemm
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
-  st::Stamp stamp;                       // timed launch trace: device-side begin / end of this launch (null otherwise)
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -276,7 +275,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
   long* const c_off = a_off + BM;
   long* const m_off = c_off + BM;
 
-  st::stamp_begin(p.stamp);
   const int split = blockIdx.x / (p.chunk * 8);
   const int bid = blockIdx.x - split * (p.chunk * 8);
   // block b runs on XCD b % 8 and every XCD has its own L2: an XCD owns a rectangle of the tile grid (chosen by the host to
@@ -673,7 +671,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
       }
     }
   }
-  st::stamp_end(p.stamp);
 }
 
 int npad_of(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)st::round_up(cout, 128)); }
@@ -800,12 +797,11 @@ int launch_gemm(X6Params& p, hipStream_t s) {
             p.Kp, p.taps, st::tuning(st::TUNE_BF16_SCHED), p.gm, 8 / p.gm,
             2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
   st::LaunchTimer timer(s);
-  p.stamp = timer.stamp();
   const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
 #define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
   do {                                                                                                         \
-    if (whole(K)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, true>), grid, dim3(64 * W1 * W2), 0, s, p);   \
-    else hipLaunchKernelGGL((gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, false>), grid, dim3(64 * W1 * W2), 0, s, p);          \
+    if (whole(K)) st::launch_timed(timer, gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, true>, grid, dim3(64 * W1 * W2), s, p);   \
+    else st::launch_timed(timer, gemm_nn_bf16_kernel<T, W1, W2, K, N, R, P, false>, grid, dim3(64 * W1 * W2), s, p);          \
   } while (0)
   // Schedule of the 256 x 256 bf16-activation kernel (st_set_tuning("bf16_sched", v) selects one; 0 = the policy = 1):
   //   1  eight waves in ping-pong groups, 32-deep stages, ring of 4 (rounds 1-2) -- still the fastest (round 3, L8 forward /
@@ -823,11 +819,11 @@ int launch_gemm(X6Params& p, hipStream_t s) {
     else ST_LAUNCH(128, 2, 2, 32, 3, 2, false);
   } else {
     if (BT == 256 && sched == 4 && (whole(64) || one_tap_tail)) {
-      if (whole(64)) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, true, 1>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, false, 1>), grid, dim3(256), 0, s, p);
+      if (whole(64)) st::launch_timed(timer, gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, true, 1>, grid, dim3(256), s, p);
+      else st::launch_timed(timer, gemm_nn_bf16_kernel<256, 2, 2, 64, 1, 2, false, false, 1>, grid, dim3(256), s, p);
     } else if (BT == 256 && (sched == 2 || sched == 3) && whole(32)) {
-      if (sched == 3) hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 3, false, true, 1>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 4, false, true, 1>), grid, dim3(256), 0, s, p);
+      if (sched == 3) st::launch_timed(timer, gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 3, false, true, 1>, grid, dim3(256), s, p);
+      else st::launch_timed(timer, gemm_nn_bf16_kernel<256, 2, 2, 32, 1, 4, false, true, 1>, grid, dim3(256), s, p);
     }
     else if (BT == 256) ST_LAUNCH(256, 2, 4, 32, 1, 4, true);
     else ST_LAUNCH(128, 2, 2, 64, 1, 4, false);

@@ -145,9 +145,8 @@ __device__ inline void stage_matrix(float* __restrict__ dst, const float* __rest
 template <int NST>                           // stages of CH frame pairs: the matrix has no columns past 2 * NST * CH
 __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
-                                                          float* __restrict__ out, st::Stamp stamp) {
+                                                          float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float wl[KP * KP];
-  st::stamp_begin(stamp);
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
   stage_matrix<KP>(wl, wm);
@@ -211,7 +210,6 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
         }
     }
   }
-  st::stamp_end(stamp);
 }
 
 // ---- inverse DFT of spectra back to frames, with the layer epilogue ---------------------------------------------
@@ -231,8 +229,7 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
                                                            int rows, int rows_pad, int bins, int half_in, int nchunks,
                                                            RowsOut y, const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ mask, long mask_batch_stride,
-                                                           int mask_c_pitch, st::Stamp stamp) {
-  st::stamp_begin(stamp);
+                                                           int mask_c_pitch) {
   constexpr int NST = 2 * HP / CH;                      // stages per term
   static_assert(2 * HP % CH == 0 && HP <= HB / 2, "pairs per term must fill whole stages");
   __shared__ __attribute__((aligned(16))) float wl[TERMS * V * KP];
@@ -328,7 +325,6 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
         }
     }
   }
-  st::stamp_end(stamp);
 }
 
 // ---- filters -> their spectra in the two GEMM operand layouts -------------------------------------------------
@@ -494,11 +490,11 @@ void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start,
             4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
   st::LaunchTimer timer(s);
   if (frames_used <= 6 * CH)                                               // the matrix has no columns past frames_used
-    hipLaunchKernelGGL(dft_rows_kernel<3>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                       half, nchunks, out, timer.stamp());
+    st::launch_timed(timer, dft_rows_kernel<3>, dim3(wgs), dim3(256), s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
+                     half, nchunks, out);
   else
-    hipLaunchKernelGGL(dft_rows_kernel<4>, dim3(wgs), dim3(256), 0, s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                       half, nchunks, out, timer.stamp());
+    st::launch_timed(timer, dft_rows_kernel<4>, dim3(wgs), dim3(256), s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
+                     half, nchunks, out);
 }
 
 template <int TERMS>
@@ -510,11 +506,11 @@ void launch_idft(const float* in, const float* winv, const Plan& p, int half_in,
             4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1));
   st::LaunchTimer timer(s);
   if (p.bins <= 36)
-    hipLaunchKernelGGL((idft_rows_kernel<TERMS, 18>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch, timer.stamp());
+    st::launch_timed(timer, idft_rows_kernel<TERMS, 18>, grid, dim3(256), s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
+                     nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
   else
-    hipLaunchKernelGGL((idft_rows_kernel<TERMS, 24>), grid, dim3(256), 0, s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                       nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch, timer.stamp());
+    st::launch_timed(timer, idft_rows_kernel<TERMS, 24>, grid, dim3(256), s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
+                     nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }

@@ -57,7 +57,6 @@ struct NNParams {
   int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
   int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
   long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
-  st::Stamp stamp;                   // timed launch trace: device-side begin / end of this launch (null otherwise)
   // Batched mode, K-split tail (see launch_nn): the bins beyond the last full set of 8 -- `batches % 8` of them -- would
   // occupy only that many XCDs for a whole extra round.  Their tiles are cut into `tail_parts` slices of the reduction,
   // all slices of a tile on ONE XCD; a slice stores its raw partial tile, the slice that arrives last (an atomic counter
@@ -131,7 +130,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   // tile grid as gm x gn rectangles (chosen by the host to minimise  A-bytes * gn + B-bytes * gm, i.e. how
   // often each operand is fetched into some L2); inside its rectangle an XCD walks panel-major so that
   // the CUs sharing the L2 stream the same filter panel together.
-  st::stamp_begin(p.stamp);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   int tile_m, tile_n;
@@ -374,7 +372,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
           *reinterpret_cast<bvec*>(slab + (long)m * p.Np + col0) = out;
         }
       }
-    st::stamp_end(p.stamp);
     return;
   }
   if constexpr (NT == 2) {
@@ -401,8 +398,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tail_count + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.tail_parts - 1;
     __syncthreads();
     if (!flag[0]) {
-      st::stamp_end(p.stamp);
-      return;
+        return;
     }
     const float* const base = p.tail_slab + (long)tail_tile * p.tail_parts * (BM * BN);
 #pragma unroll
@@ -474,7 +470,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     for (int n = 0; n < NT; ++n) vset<NT>(out, n, csum[n] + __shfl_xor(csum[n], 32, 64));
     if (h == 0) *reinterpret_cast<bvec*>(p.colsum + (long)(tile_m * WMW + wm) * p.Np + col0) = out;
   }
-  st::stamp_end(p.stamp);
 }
 
 // ------------------------------------------------------------------------------------
@@ -495,7 +490,6 @@ struct TNParams {
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
   long a_batch, z_batch, o_batch;   // blockIdx.z: independent products of the same shape (csrc/conv_fft.hip), float strides
-  st::Stamp stamp;                  // timed launch trace (see NNParams)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
@@ -523,7 +517,6 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   float* const As = smem;
   float* const Zs = smem + 2 * A_SZ;
 
-  st::stamp_begin(p.stamp);
   // XCD-aware order (see gemm_nn_kernel): 8x8 super-tiles so the CUs behind one L2 share operands
   int tile_k, tile_n;
   {
@@ -686,7 +679,6 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
         *reinterpret_cast<zvec*>(out + (long)k * p.Np + col0) = o;
       }
     }
-  st::stamp_end(p.stamp);
 }
 
 // dst[i] = sum_s slabs[s][i]
@@ -941,9 +933,8 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
               FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
   {
     st::LaunchTimer timer(s);
-    p.stamp = timer.stamp();
-    if (epi == 0) hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>), grid, block, 0, s, p);
+    if (epi == 0) st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>, grid, block, s, p);
+    else st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>, grid, block, s, p);
   }
   if (p.splits > 1) {
     const long quads = (long)p.M * (p.n_store / 4);
@@ -1036,8 +1027,7 @@ int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, 
   st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d gflop=%.3f", batches, M, K, N, 2e-9 * M * (double)K * N * batches);
   {
     st::LaunchTimer timer(s);
-    p.stamp = timer.stamp();
-    hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), 0, s, p);
+    st::launch_timed(timer, gemm_tn_kernel<128, 2, 2>, dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), s, p);
   }
   return st::check_launch("gemm_tn_batched");
 }
@@ -1328,16 +1318,15 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
             p.rows_per_split, p.M, p.Kp, p.Np, 2e-9 * st::round_up(p.M, 32) * (double)(p.tiles_k * 128) * p.Np);
   {
     st::LaunchTimer timer(s);                // the product kernel alone (what rocprofv3 lists under this symbol)
-    p.stamp = timer.stamp();
     if (p.Np % 128 == 0) {
       p.tiles_n = p.Np / 128;
-      hipLaunchKernelGGL((gemm_tn_kernel<128, 2, 2>), dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), 0, s, p);
+      st::launch_timed(timer, gemm_tn_kernel<128, 2, 2>, dim3(p.tiles_k * p.tiles_n, used), dim3(TN_THREADS), s, p);
     } else if (p.Np == 64) {
       p.tiles_n = 1;
-      hipLaunchKernelGGL((gemm_tn_kernel<64, 2, 2>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
+      st::launch_timed(timer, gemm_tn_kernel<64, 2, 2>, dim3(p.tiles_k, used), dim3(TN_THREADS), s, p);
     } else if (p.Np == 32) {
       p.tiles_n = 1;
-      hipLaunchKernelGGL((gemm_tn_kernel<32, 4, 1>), dim3(p.tiles_k, used), dim3(TN_THREADS), 0, s, p);
+      st::launch_timed(timer, gemm_tn_kernel<32, 4, 1>, dim3(p.tiles_k, used), dim3(TN_THREADS), s, p);
     } else {
       st::set_error("conv bwd_filter: unsupported n_pad=%d", p.Np);
       return ST_EINVAL;

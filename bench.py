@@ -97,7 +97,7 @@ def trace_field(line, name):
   return float(m.group(1)) if m else None
 
 
-def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps=5):
+def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=2, profiled_steps=3):
   """`roofline`: the hardware rate of every matrix-pipe kernel of the training step, measured INSIDE real steps.
 
   In-step (the contract number): `profiled_steps` real training steps run under the library's timed launch trace
@@ -156,16 +156,6 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
   if not launches:
     return None, None
 
-  # ---- in-step: real training steps under the timed trace ----
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  with launch_trace(timed=True) as tr:
-    for _ in range(profiled_steps):
-      step_fn()
-    torch.cuda.synchronize()
-    profiled_ms = (time.perf_counter() - t0) / profiled_steps * 1e3
-  step_lines = [l for l in tr.lines if trace_field(l, 'ms') is not None and trace_field(l, 'ms') >= 0.0]
-
   # ---- isolated: the same launches one by one; their trace lines give the (kernel, shape) -> algorithmic work map ----
   symbols, keys = [], []
   for _, _, _, fn in launches:
@@ -189,6 +179,26 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
   alg = {}                                       # trace key -> (flops, bytes) of one such launch (L1..L7 share a key: same work)
   for k, key in enumerate(keys):
     alg.setdefault(key, (launches[k][1], launches[k][2]))
+
+  # ---- in-step: real training steps under the timed trace, ONE kernel symbol timed per pass ----
+  # (a timed launch costs its stream ~7 us -- hipExtLaunchKernel with events gives up back-to-back dispatch -- so timing all
+  # ~100 launches of a step at once stretches it by 10 % and every overlapped launch with it; one symbol's <= 16 launches: ~1 %)
+  with launch_trace() as tr:
+    step_fn()
+  torch.cuda.synchronize()
+  name_lines = list(tr.lines)                                    # every traced launch of a step, with its executed GFLOP
+  tokens = sorted({l.split()[0] for l in name_lines})
+  step_lines, pass_ms = [], {}
+  for tok in tokens:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with launch_trace(timed=True, only=tok + ' ') as tr:
+      for _ in range(profiled_steps):
+        step_fn()
+      torch.cuda.synchronize()
+      pass_ms[tok] = (time.perf_counter() - t0) / profiled_steps * 1e3
+    step_lines += [l for l in tr.lines if trace_field(l, 'ms') is not None and trace_field(l, 'ms') >= 0.0]
+  profiled_ms = float(np.max(list(pass_ms.values())))
 
   def rate(fl, ms):
     return fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -227,9 +237,10 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
   dom = gemms[0]
   out = dict(bound='mfma', peak=PEAK_F32_TFLOPS, unit='TFLOP/s', traffic=None, traffic_unit='bytes/launch (PMC, see profiles/)')
   out.update({k: v for k, v in dom.items() if k != 'per_shape'})
-  out['timing'] = ('in-step: HIP events around every launch of this kernel inside %d real training steps (side streams '
-                   'running), st_trace_begin_timed; achieved = algorithmic FLOPs of those launches / their summed time'
-                   % profiled_steps)
+  out['timing'] = ('in-step: every launch of this kernel inside %d real training steps (side streams running) launched through '
+                   'hipExtLaunchKernel with start/stop events = the dispatch\'s own begin/end time stamps, what rocprofv3\'s kernel '
+                   'trace reports (st_trace_begin_timed, one kernel symbol per pass); achieved = algorithmic FLOPs of those '
+                   'launches / their summed time' % profiled_steps)
   out['per_shape'] = dom['per_shape']
   out['isolated'] = iso_group(dom['kernel']) if dom['kernel'] in symbols else None
   out['hbm_frac_of_peak'] = round(dom['algorithmic_mb_per_launch'] * 1e6 / (dom['avg_launch_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
@@ -248,12 +259,13 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
                                     achieved=round(rate(all_fl, all_ms), 2), frac=round(rate(all_fl, all_ms) / PEAK_F32_TFLOPS, 4),
                                     note='summed launch times; launches on the two streams of the backward pass overlap, so '
                                          'this can exceed their share of the step')
-  executed = sum(g['executed_gflop_per_launch'] * g['launches_per_step'] for g in in_step)
+  executed = sum(trace_field(l, 'gflop') or 0.0 for l in name_lines)
   step = dict(step_executed_gflop=round(executed, 1), step_hw_tflops=round(executed / step_ms, 2),
               step_hw_frac=round(executed / step_ms / PEAK_F32_TFLOPS, 4),
               step_hw_note='FLOPs the matrix pipe really executed in one step (every traced launch incl. the DFT / inverse-DFT '
                            'transforms and the 29-class layer, channel padding included) / ms_per_step / %.1f TFLOP/s' % PEAK_F32_TFLOPS,
-              profiled_ms_per_step=round(profiled_ms, 3))
+              profiled_ms_per_step=round(profiled_ms, 3),
+              profiled_note='slowest of the per-symbol timed passes (wall clock per step, host synchronised per pass)')
   return out, step
 
 

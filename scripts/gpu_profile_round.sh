@@ -54,20 +54,23 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             k = bench_key(r['Kernel_Name'])
             vals[k][c][0] += float(r['Counter_Value'])
             vals[k][c][1] += 1
-by, step_fetch, step_write = {}, 0.0, 0.0
+by, step_fetch, step_write, startup = {}, 0.0, 0.0, 0.0
 for k, d in vals.items():
     n = max(d['FETCH_SIZE'][1], d['WRITE_SIZE'][1], 1)
     fetch_total = d['FETCH_SIZE'][0] * 1024 * 2          # gfx950 correction (MI355X_MICROARCH.md, HBM section)
     write_total = d['WRITE_SIZE'][0] * 1024
-    step_fetch += fetch_total / steps
-    step_write += write_total / steps
+    if 'at::native' in k or n < steps:                   # torch fills / casts of buffer creation, one-off packing: not a step's
+        startup += fetch_total + write_total
+    else:
+        step_fetch += fetch_total / steps
+        step_write += write_total / steps
     by[k] = dict(launches=n, launches_per_step=round(n / steps, 2), fetch_bytes_per_launch=fetch_total / n,
                  write_bytes_per_launch=write_total / n, bytes_per_launch=(fetch_total + write_total) / n,
                  bytes_per_step=(fetch_total + write_total) / steps)
 traffic = dict(source_digest=digest, by_kernel=by, step_bytes=step_fetch + step_write, step_fetch_bytes=step_fetch,
-               step_write_bytes=step_write, steps_profiled=steps,
-               command='bench.py --steps-only --steps 6 --warmup 2 (every launch of the command belongs to one of the 8 training '
-                       'steps, plus the one-off weight packing at start-up, < 1 % of the bytes)',
+               step_write_bytes=step_write, steps_profiled=steps, startup_bytes_not_counted=startup,
+               command='bench.py --steps-only --steps 6 --warmup 2 (kernels launched at least once per step belong to the 8 training '
+                       'steps; torch fill kernels of buffer creation and the one-off weight packing are summed apart)',
                note='FETCH_SIZE x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE x 1024; separate rocprofv3 --pmc passes with '
                     '--kernel-trace only; per launch = total of the symbol / its launches, per step = total / steps')
 json.dump(traffic, open(os.path.join(out_dir, 'traffic.json'), 'w'), indent=1)

@@ -25,6 +25,7 @@ _SIGNATURES = {
     'st_last_error': (c_char_p, []),
     'st_trace_begin': (c_int, []),
     'st_trace_begin_timed': (c_int, []),
+    'st_trace_timed_filter': (c_int, [c_char_p]),
     'st_trace_end': (c_size_t, [c_char_p, c_size_t]),
     'st_set_tuning': (c_int, [c_char_p, c_int]),
     'st_host_crc32c': (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
@@ -177,11 +178,14 @@ class launch_trace:
   launch is bracketed by HIP events on its own stream and its line ends in `` ms=<duration>`` (collecting the trace
   waits for the launches)."""
 
-  def __init__(self, timed=False):
-    self.timed = timed
+  def __init__(self, timed=False, only=None):
+    """``only``: in timed mode, time just the launches whose trace line contains this text (a timed launch costs the
+    stream a few microseconds: timing one kernel's launches leaves the step undisturbed)."""
+    self.timed, self.only = timed, only
 
   def __enter__(self):
     if self.timed:
+      load().st_trace_timed_filter((self.only or '').encode())
       load().st_trace_begin_timed()
     else:
       load().st_trace_begin()

@@ -27,6 +27,7 @@ constexpr int kMaxTimed = 1 << 14;
 struct TimedLaunch { int line; hipEvent_t e0, e1; };
 static std::vector<TimedLaunch> g_timed;
 static thread_local int g_last_line = -1;
+static std::string g_timed_filter;                 // timed mode: only lines containing this text get events ("" = all)
 bool trace_on() { return g_trace_on.load(std::memory_order_relaxed) != 0; }
 void trace(const char* fmt, ...) {
   if (!trace_on()) return;
@@ -49,7 +50,12 @@ LaunchTimer::LaunchTimer(hipStream_t) : start_(nullptr), stop_(nullptr) {
   if (hipEventCreate(&e0) != hipSuccess) return;
   if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
   std::lock_guard<std::mutex> lock(g_trace_mu);
-  if ((int)g_timed.size() >= kMaxTimed) { hipEventDestroy(e0); hipEventDestroy(e1); return; }
+  if ((int)g_timed.size() >= kMaxTimed || g_last_line >= (int)g_lines.size() ||
+      (!g_timed_filter.empty() && g_lines[g_last_line].find(g_timed_filter) == std::string::npos)) {
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return;
+  }
   g_timed.push_back(TimedLaunch{g_last_line, e0, e1});
   start_ = e0;
   stop_ = e1;
@@ -77,6 +83,11 @@ static int trace_begin(int mode) {
 }
 int st_trace_begin(void) { return trace_begin(1); }
 int st_trace_begin_timed(void) { return trace_begin(2); }
+int st_trace_timed_filter(const char* text) {
+  std::lock_guard<std::mutex> lock(st::g_trace_mu);
+  st::g_timed_filter = text ? text : "";
+  return ST_OK;
+}
 
 size_t st_trace_end(char* host_buf, size_t capacity) {
   st::g_trace_on.store(0);

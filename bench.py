@@ -97,7 +97,7 @@ def trace_field(line, name):
   return float(m.group(1)) if m else None
 
 
-def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=2, profiled_steps=3):
+def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps=3):
   """`roofline`: the hardware rate of every matrix-pipe kernel of the training step, measured INSIDE real steps.
 
   In-step (the contract number): `profiled_steps` real training steps run under the library's timed launch trace

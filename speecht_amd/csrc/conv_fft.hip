@@ -479,12 +479,13 @@ RowsIn rows_in(const st_tensor3& t) {
   return r;
 }
 
-constexpr int TRANSFORM_WGS = 512;               // persistent: two workgroups per CU, every wave walks its share of the items
+constexpr int TRANSFORM_WGS_DEFAULT = 512;       // persistent: two workgroups per CU, every wave walks its share of the items
+inline int transform_wgs() { const int t = st::tuning(st::TUNE_TRANSFORM_WGS); return t > 0 ? t : TRANSFORM_WGS_DEFAULT; }
 
 void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
                 hipStream_t s) {
   const int nchunks = st::ceil_div(half, 32);
-  const int wgs = std::min(TRANSFORM_WGS, st::ceil_div(pl.rows_pad * nchunks, 4));
+  const int wgs = std::min(transform_wgs(), st::ceil_div(pl.rows_pad * nchunks, 4));
   const int nst = frames_used <= 6 * CH ? 3 : 4;
   st::trace("dft_rows<%d> rows=%d chunks=%d bins=%d gflop=%.3f", nst, pl.rows, nchunks, pl.bins,
             4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
@@ -500,7 +501,7 @@ void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start,
 template <int TERMS>
 void launch_idft(const float* in, const float* winv, const Plan& p, int half_in, int nchunks, const RowsOut& out, const float* bias,
                  int relu, const float* mask, long mask_batch_stride, int mask_c_pitch, hipStream_t s) {
-  const dim3 grid(std::min(TRANSFORM_WGS, st::ceil_div(p.rows * nchunks, 4)));
+  const dim3 grid(std::min(transform_wgs(), st::ceil_div(p.rows * nchunks, 4)));
   const int hp = p.bins <= 36 ? 18 : 24;
   st::trace("idft_rows<%d,%d> rows=%d chunks=%d bins=%d gflop=%.3f", TERMS, hp, p.rows, nchunks, p.bins,
             4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1));

@@ -192,9 +192,14 @@ from tests import workloads as WL
 from speecht_amd.data_parallel import GradientAllReducer, shard_range, all_reduce_mean_scalar
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-layers = [(7, 2, 6, 8, True), (5, 1, 8, 8, True), (1, 1, 8, 29, False)]
+if os.environ.get("ST_FULL_DEPTH"):
+  layers = WL.w2l_layers(6, width=8, fc=16)                      # eleven layers: the four-bucket schedule of the real model
+  frames = [80, 66, 56, 80, 71, 80, 49, 80]                      # global batch 8
+else:
+  layers = [(7, 2, 6, 8, True), (5, 1, 8, 8, True), (1, 1, 8, 29, False)]
+  frames = [40, 33, 28, 40]                                      # global batch 4
 params = WL.xavier_params(layers, seed=3)
-x, seq, labels = WL.make_batch([40, 33, 28, 40], 6, seed=4)      # global batch 4
+x, seq, labels = WL.make_batch(frames, 6, seed=4)
 lo, hi = shard_range(len(labels), rank, world)
 
 def flat_grads(xs, ss, ls, scale_batch):
@@ -209,6 +214,10 @@ offs = np.concatenate([[0], np.cumsum(sizes)])
 ranges = [(int(offs[i]), int(offs[i + 1])) for i in range(len(sizes))]
 flat = torch.tensor(local)
 red = GradientAllReducer(flat, ranges)
+if os.environ.get("ST_FULL_DEPTH"):
+  assert [b[0] for b in red.buckets] == [9, 8, 4, 0], red.buckets   # L9+L10 | L8 | L4..L7 | L0..L3, in back-prop order
+  assert red.buckets[0][2] == ranges[-1][1] and red.buckets[-1][1] == 0
+  assert sum(e - s for _, s, e in red.buckets) == flat.numel()      # the buckets tile the flat gradient exactly
 for i in reversed(range(len(layers))):
   red.on_layer_done(i)
 red.finish()
@@ -225,14 +234,18 @@ print("rank", rank, "ok")
 '''
 
 
-def test_data_parallel_allreduce_equals_single_rank_gloo(tmp_path):
-  """world_size 2 on CPU (gloo): bucketed SUM all-reduce of per-rank gradients scaled by
-  1/global_batch == gradient of the concatenated batch; replicas end bit-identical."""
+@pytest.mark.parametrize('world,full_depth', [(2, False), (4, True)])
+def test_data_parallel_allreduce_equals_single_rank_gloo(tmp_path, world, full_depth):
+  """world_size 2 and 4 on CPU (gloo): bucketed SUM all-reduce of per-rank gradients scaled by
+  1/global_batch == gradient of the concatenated batch; replicas end bit-identical.  The world-4 case runs the
+  eleven-layer model, i.e. the four buckets of the real schedule (L9+L10, L8, L4..L7, L0..L3)."""
   script = tmp_path / 'dp_worker.py'
   script.write_text(DP_WORKER)
-  env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', WORLD_SIZE='2')
+  env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29611 + world), WORLD_SIZE=str(world))
+  if full_depth:
+    env['ST_FULL_DEPTH'] = '1'
   procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                            stderr=subprocess.STDOUT) for r in range(2)]
+                            stderr=subprocess.STDOUT) for r in range(world)]
   outs = [p.communicate(timeout=240)[0].decode() for p in procs]
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o)

@@ -89,3 +89,22 @@ def test_engine_refuses_cpu():
   from speecht_amd.engine import Wav2LetterEngine
   with pytest.raises(_lib.SpeechtHipError):
     Wav2LetterEngine([(1, 1, 16, 29, False)], device='cpu')
+
+
+def test_bench_trace_line_parsing():
+  """bench.py's in-step roofline matches the library's launch-trace lines to the work they did: the symbol a line groups
+  under, its key (kernel + shape + policy, measurements stripped) and its fields."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  nn = 'gemm_nn<128,128,2,2,fast> epi=1 splits=2 M=16032 Np=256 Kp=64512 taps=32 xcd=8x1 gflop=1059.5 ms=0.54321'
+  bt = 'gemm_nn<64,128,2,2,fast> batched bins=36 M=256 Np=512 Kp=512 tail=1 gflop=4.832'
+  tn = 'gemm_tn<128> batched bins=36 M=256 Kp=512 Np=512 gflop=4.832 ms=0.06100'
+  assert bench.trace_symbol(nn) == 'gemm_nn<128,128,2,2,fast> epi=1'
+  assert bench.trace_symbol(bt) == 'gemm_nn<64,128,2,2,fast> epi=0'          # batched products: the plain epilogue
+  assert bench.trace_symbol(tn) == 'gemm_tn<128>' and bench.trace_symbol('dft_rows<3> rows=256 chunks=8 bins=36 gflop=0.9') == 'dft_rows<3>'
+  assert bench.trace_key(nn) == 'gemm_nn<128,128,2,2,fast> epi=1 splits=2 M=16032 Np=256 Kp=64512 taps=32 xcd=8x1'
+  assert bench.trace_key(tn) == bench.trace_key(tn.replace('ms=0.06100', 'ms=0.09'))
+  assert bench.trace_field(nn, 'ms') == pytest.approx(0.54321) and bench.trace_field(nn, 'gflop') == pytest.approx(1059.5)
+  assert bench.trace_field(bt, 'ms') is None and bench.trace_field(bt, 'bins') == 36.0

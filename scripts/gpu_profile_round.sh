@@ -13,7 +13,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT=$ROOT/gpurun_out/round$TAG
 mkdir -p $OUT
 cd $ROOT
-/usr/bin/time -f "bench.py default run: %e s wall" -o $OUT/bench_wall.txt python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench_wall.txt
+S0=$SECONDS; python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py default run: $((SECONDS - S0)) s wall" | tee $OUT/bench_wall.txt
 bash scripts/gpu_prof.sh round${TAG}_prof python bench.py --no-alt --no-cpu-baseline | head -40 > $OUT/kernel_top.txt
 python scripts/step_timeline.py $(find gpurun_out/round${TAG}_prof -name '*kernel_trace.csv' | head -1) > $OUT/step_timeline.txt 2>/dev/null
 cp $(find gpurun_out/round${TAG}_prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv

@@ -732,6 +732,10 @@ def main():
       out['cpu_baseline_numpy_oracle'] = cpu_baseline(args.mels, frames)
     print(json.dumps(out))
   if dist.is_initialized():
+    if world > 1:
+      # rank 0 measured on its own for a while (roofline passes, side measurements): the others wait for it here instead of
+      # tearing the communicator down under it
+      dist.barrier()
     dist.destroy_process_group()
 
 

@@ -60,7 +60,7 @@ const char* st_last_error(void);
  * launches); st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
  * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split", "transform_wgs"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split", "transform_wgs", "bf16_wgrad_target"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 int st_trace_begin_timed(void);

@@ -765,6 +765,9 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   if (p.splits < 1) p.splits = 1;
   const bool fits256 = NP == 1 ? p.Np >= 256 : p.Np % 256 == 0;
   const bool wide = (long)st::ceil_div(p.M, 256) * st::ceil_div(p.Np, 256) * p.splits >= 192;
+  // The 250-channel layers (252 tiles of 128 x 128, ONE 128 KB workgroup per CU, 23-26 us for 14.4 GFLOP) were tried in round 3
+  // as 64 x 64 tiles of two waves with 2-5 workgroups per CU (33-35 us) and in the one-wave-per-SIMD schedule (SCH = 1: 23 us
+  // alone, no change of the step): the 128 x 128 tile of four waves stays.
   const int BT = (forced_tile != 128 && fits256 && wide) ? 256 : 128;
   p.tiles_m = st::ceil_div(p.M, BT);
   p.tiles_n = st::ceil_div(p.Np, BT);
@@ -1015,7 +1018,12 @@ WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int s
   const long tiles = st::ceil_div((int)M, 128) * (long)st::ceil_div(w.n_pad, 128);
   const int stages = (int)((w.red + 63) / 64);
   const int forced = st::tuning(st::TUNE_BF16_WGRAD_SPLITS);
-  w.splits = forced ? forced : tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(st::ceil_div(512, (int)tiles), stages / 8));
+  // one 128 KB workgroup per CU: more than ~7/8 of the 256 CUs' worth of (tile, split) pairs starts a second round on some
+  // XCD (a split's tiles are dealt to the XCDs in rectangles, 28 tiles -> 32 slots), and every split adds a slab to sum.
+  // Round 3, filter gradient of a 250-channel layer incl. transposes and slab sum: 19 splits (the old "fill 512") 67 us,
+  // 12 -> 60, 7 -> 51, 4 -> 65; first layer 8 -> 95, 4 -> 73; last layer 32 -> 55, 12 -> 46.
+  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 224;
+  w.splits = forced ? forced : tiles >= 192 ? 1 : (int)std::max(1L, std::min<long>(target / tiles, stages / 8));
   w.slab_bytes = w.splits > 1 ? (size_t)w.splits * M * w.n_pad * 4 : 0;
   return w;
 }

@@ -36,7 +36,7 @@ inline void launch_timed(const LaunchTimer& t, F kernel, const dim3& grid, const
   else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_TAIL_SPLIT, TUNE_TRANSFORM_WGS, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_TAIL_SPLIT, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # The measured artefacts profiles/ holds for a round, all from ONE build (stamped with build.source_digest()):
+#   (order of execution: 3, 4, then 1, 2 -- the bench line quotes the PMC files of ITS build)
 #   1. the default bench line (what the driver runs)                       -> gpurun_out/round/bench.json
 #   2. rocprofv3 --kernel-trace --stats of `bench.py --no-alt --no-cpu-baseline` -> kernel_stats.csv, step_timeline.txt
 #   3. PMC passes over `bench.py --steps-only` (every launch belongs to a training step), counters + kernel-trace only,
@@ -13,11 +14,6 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT=$ROOT/gpurun_out/round$TAG
 mkdir -p $OUT
 cd $ROOT
-S0=$SECONDS; python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py default run: $((SECONDS - S0)) s wall" | tee $OUT/bench_wall.txt
-bash scripts/gpu_prof.sh round${TAG}_prof python bench.py --no-alt --no-cpu-baseline | head -40 > $OUT/kernel_top.txt
-python scripts/step_timeline.py $(find gpurun_out/round${TAG}_prof -name '*kernel_trace.csv' | head -1) > $OUT/step_timeline.txt 2>/dev/null
-cp $(find gpurun_out/round${TAG}_prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
-grep '^{' gpurun_out/round${TAG}_prof/stdout.log > $OUT/bench_under_rocprof.json
 STEPS=6; WARM=2
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -103,10 +99,22 @@ for k, d in agg.items():
                    wave_time_active=round(d['SQ_ACTIVE_INST_ANY'] / wc, 3), wave_time_issue_stall=round(d['SQ_WAIT_INST_ANY'] / wc, 3),
                    wave_time_parked=round(d['SQ_WAIT_ANY'] / wc, 3))
 json.dump(util, open(os.path.join(out_dir, 'mfma_util.json'), 'w'), indent=1)
-b = json.loads([l for l in open(os.path.join(out_dir, 'bench.json')) if l.startswith('{')][-1])
+PY
+# the bench quotes profiles/traffic.json / mfma_util.json only when their digest is the digest of the sources it runs: put the
+# files just collected where it looks (on this box's copy; scripts/copy_round_profiles.sh does the same for the repository)
+cp $OUT/traffic.json $OUT/mfma_util.json $ROOT/profiles/
+S0=$SECONDS; python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py default run: $((SECONDS - S0)) s wall" | tee $OUT/bench_wall.txt
+bash scripts/gpu_prof.sh round${TAG}_prof python bench.py --no-alt --no-cpu-baseline | head -40 > $OUT/kernel_top.txt
+python scripts/step_timeline.py $(find gpurun_out/round${TAG}_prof -name '*kernel_trace.csv' | head -1) > $OUT/step_timeline.txt 2>/dev/null
+cp $(find gpurun_out/round${TAG}_prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+grep '^{' gpurun_out/round${TAG}_prof/stdout.log > $OUT/bench_under_rocprof.json
+python - <<PY
+import json
+b = json.loads([l for l in open('$OUT/bench.json') if l.startswith('{')][-1])
 r = b['roofline']
-print('bench: %.3f ms/step (median %.3f), %s in-step frac %.4f (isolated %s), step_hw_frac %s' % (
-    b['ms_per_step'], b['ms_per_step_median'], r['kernel'], r['frac'], (r.get('isolated') or {}).get('frac'), b.get('step_hw_frac')))
+print('bench: %.3f ms/step (median %.3f), %s in-step frac %.4f (isolated %s), step_hw_frac %s, traffic %s' % (
+    b['ms_per_step'], b['ms_per_step_median'], r['kernel'], r['frac'], (r.get('isolated') or {}).get('frac'), b.get('step_hw_frac'),
+    'quoted' if r.get('traffic') else 'NOT quoted: ' + str(r.get('traffic_stale'))))
 PY
 find gpurun_out/round${TAG}_prof $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name '*.csv' -size +5M -delete

@@ -497,27 +497,59 @@ class Wav2LetterEngine:
       self.Wb = [z(l.k_pad * l.n_pad) for l in self.layers]
       self.WTb = [None] + [z(l.kt_pad * l.nt_pad) for l in self.layers[1:]]
 
-  def _refresh_bf16_filters(self, transposed):
+  def _refresh_bf16_filters(self, transposed, layers=None):
     for i, l in enumerate(self.layers):
+      if layers is not None and i not in layers:
+        continue
       if transposed and i > 0:
         call('st_filters_bwd_bf16', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
              l.cout_pitch, self._ptr(self.WTb[i]), self.stream_ptr)
       elif not transposed:
         call('st_filters_bf16', self._ptr(self._slice(self.params, i)[0]), l.k_pad, l.n_pad, self._ptr(self.Wb[i]),
              self.stream_ptr)
+    if layers is not None:
+      return
     if transposed:
       self._wtplanes_fresh = True
     else:
       self._wplanes_fresh = True
 
+  def _refresh_wb_after_update(self):
+    """After an update: the bottom layer's bf16 filter copy on the compute stream (the next forward pass needs it at
+    once), the others on the side stream, bottom layer first, an event per layer -- the forward pass waits layer by
+    layer instead of for the whole list (eleven small kernels, ~130 us end to end, during which the chip was idle)."""
+    L = len(self.layers)
+    self._wb_ready = {}
+    self._refresh_bf16_filters(False, layers=[0])
+
+    def rest():
+      for i in range(1, L):
+        self._refresh_bf16_filters(False, layers=[i])
+        ev = torch.cuda.Event()
+        ev.record(self._stream)
+        self._wb_ready[i] = ev
+    self._on_side_stream(rest)
+    self._wplanes_fresh = True
+
   def _forward_bf16(self):
     s, L = self.stream_ptr, len(self.layers)
-    self._join_side_stream()                       # the bf16 filter copies are rebuilt on the side stream after the update
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    ready = getattr(self, '_wb_ready', None) or {}
     if not self._wplanes_fresh:
+      self._join_side_stream()                     # (a rebuild still running there writes the same buffers)
+      ready.clear()
       self._refresh_bf16_filters(False)
     call('st_cast_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xb[0]), s)
     for i, l in enumerate(self.layers):
       last = i + 1 == L
+      if ready:
+        # the side stream works bottom layer first: the first layers wait for their own copy, the fourth for all that
+        # remain (by then the side stream is through; every wait costs the compute stream a few microseconds)
+        if i >= 3:
+          main.wait_event(ready[L - 1])
+          ready.clear()
+        elif i in ready:
+          main.wait_event(ready.pop(i))
       call('st_conv1d_nwc_fwd_ws_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(self.Wb[i]),
            self._ptr(self._slice(self.params, i)[1]), l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref,
            None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None,
@@ -756,6 +788,8 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16x6' and not self._wplanes_fresh:
       self._refresh_wplanes()
     self._join_side_stream()
+    if getattr(self, '_wb_ready', None):
+      self._wb_ready.clear()                       # (covered by the join above)
     if self.fft and self.fft_conv and not self._gfwd_fresh:
       self._refresh_fft_filters()
     self._wait_gfwd()                              # no waits on outside events inside a capture
@@ -1020,7 +1054,7 @@ class Wav2LetterEngine:
     if self.fft:
       self._refresh_gfwd()          # the forward filter spectra of the frequency-domain layers for the next pass
     elif self.conv_mode == 'bf16' and hasattr(self, 'Wb'):
-      self._on_side_stream(lambda: self._refresh_bf16_filters(False))   # the bf16 copies the next forward pass reads
+      self._refresh_wb_after_update()              # the bf16 copies the next forward pass reads
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

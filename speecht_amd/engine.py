@@ -325,6 +325,14 @@ class Wav2LetterEngine:
       ws = max([ws] + [lib.st_exp_conv1d_bwd_data_bf16x6_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                        for i, l in enumerate(self.layers) if i > 0])
     self.wgrad_ws, _ = self._storage.view('wgrad_ws', ws // 4 + 64)
+    # The classification layer (2000 -> 29): its filter gradient streams the activations, its back-prop to the input streams
+    # the mask and writes dZ of the layer below -- two HBM-bound launches of ~90 us each that do not depend on each other.
+    # Side by side on two streams (own scratch for the one on the side stream).
+    top = len(self.layers) - 1
+    self._side_wgrad_top = self.side_filter_gradient and os.environ.get('ST_WGRAD_SIDE_TOP', '1') != '0' and top > 0 and self.layers[top].cout <= 64 and self.layers[top].width == 1
+    if self._side_wgrad_top:
+      ws_top = lib.st_conv1d_bwd_filter_ws(self.X[top].ref, self.dZ[top].ref, self.layers[top].width)
+      self.wgrad_ws_top, _ = self._storage.view('wgrad_ws_top', ws_top // 4 + 64)
     self.loss = self._storage.view('loss', batch)[0][:batch]
     self.ctc_status = self._storage.view('ctc_status', batch, torch.int32)[0][:batch]
     self.dec_ids = self._storage.view('dec_ids', batch * self.t_out, torch.int32)[0][:batch * self.t_out]
@@ -487,6 +495,7 @@ class Wav2LetterEngine:
                      for i, l in enumerate(self.layers)])
     self.wgrad_ws_b, _ = self._storage.view('wgrad_ws_b', ws // 4 + 64)
     # the narrow layers' filter gradients run beside back-prop to the input on the side stream: their own scratch
+    # (the classification layer beside its back-prop, as in fp32: measured, no gain here -- 3.15 ms either way)
     self._side_wgrad_bf16 = [i for i, l in enumerate(self.layers) if self.side_filter_gradient and i > 0 and l.cout <= 512 and l.cin <= 512]
     ws2 = max([0] + [lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, self.layers[i].width, self.layers[i].stride,
                                                       self.geo[i][2]) for i in self._side_wgrad_bf16])
@@ -872,9 +881,9 @@ class Wav2LetterEngine:
     else:
       self._side_done = done
 
-  def _join_side_stream(self):
+  def _join_side_stream(self, second_only=False):
     main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    for name in ('_side_done', '_side2_done'):
+    for name in (('_side2_done',) if second_only else ('_side_done', '_side2_done')):
       done = getattr(self, name, None)
       if done is not None:
         main.wait_event(done)
@@ -958,6 +967,17 @@ class Wav2LetterEngine:
     # waits per layer; after the two layers on top one wait covers everything below (by then the side stream is through)
     wait_all_below = len(self.layers) - 3
     side_wgrad, deferred = False, None     # a filter gradient is in flight on the side stream; its layer's hook is due
+    top_pending = None                     # the classification layer's filter gradient is in flight on the second side stream
+    hook = on_layer_done
+    if hook is not None:
+      def on_layer_done(j):
+        nonlocal top_pending
+        if top_pending is not None and top_pending != j:
+          self._join_side_stream(second_only=True)
+          hook(top_pending)
+          top_pending = None
+        if top_pending != j:
+          hook(j)
     bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
@@ -999,6 +1019,14 @@ class Wav2LetterEngine:
           side_wgrad, deferred = True, i
         else:
           filter_gradient()
+      elif i + 1 == len(self.layers) and self._side_wgrad_top and self.conv_mode == 'fp32':
+        def top_gradient(i=i, l=l, gf=gf, gb=gb, need_bias=need_bias, ws=self.wgrad_ws_top):
+          call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
+               self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+        # on the SECOND side stream (the first is still rebuilding back-prop operands when CTC ends); its hook is due with
+        # the next layer's -- the two share a reduce bucket, and nothing waits for this launch until then
+        self._on_side_stream(top_gradient, second=True)
+        top_pending = i
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
@@ -1036,8 +1064,10 @@ class Wav2LetterEngine:
         on_layer_done(i)
       if deferred == i:
         deferred = None
-    if side_wgrad:
+    if side_wgrad or top_pending is not None:
       self._join_side_stream()
+    if top_pending is not None and hook is not None:
+      hook(top_pending)
 
   def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
     """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""

@@ -97,7 +97,7 @@ def trace_field(line, name):
   return float(m.group(1)) if m else None
 
 
-def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps=3):
+def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps=6):
   """`roofline`: the hardware rate of every matrix-pipe kernel of the training step, measured INSIDE real steps.
 
   In-step (the contract number): `profiled_steps` real training steps run under the library's timed launch trace
@@ -716,9 +716,15 @@ def main():
         for _ in range(args.warmup):
           train_step(alt, alt_feed, None, lr, global_batch)
         torch.cuda.synchronize()
+        # timed like the headline loop: at most `ahead` steps in flight (an unbounded burst after a sync runs its first
+        # steps slow -- it made this 3.1 ms step read 3.5 ms)
+        alt_marks = [torch.cuda.Event() for _ in range(args.steps)]
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(args.steps):
+          if ahead and k >= ahead:
+            alt_marks[k - ahead].synchronize()
           train_step(alt, alt_feed, None, lr, global_batch)
+          alt_marks[k].record()
         torch.cuda.synchronize()
         alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
         out[key] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),

@@ -1,11 +1,8 @@
 #!/bin/bash
-# the classification layer's filter gradient beside its back-prop to the input (ST_WGRAD_SIDE_TOP), both arithmetics
+# bf16-activation step: the three ways bench.py times it, on one box
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r3s
-mkdir -p $OUT
-for V in 1 0 1 0; do
-  echo "== ST_WGRAD_SIDE_TOP=$V"
-  ST_WGRAD_SIDE_TOP=$V timeout 200 python bench.py --steps-only --steps 40 --warmup 5 2>/dev/null | cut -c150-260
-  ST_WGRAD_SIDE_TOP=$V timeout 200 python bench.py --conv-mode bf16 --steps-only --steps 40 --warmup 5 2>/dev/null | cut -c150-260
+for i in 1 2; do
+  timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('default fp32', d['ms_per_step'], 'alt_bf16', d['alt_bf16']['ms_per_step'])"
+  timeout 200 python bench.py --conv-mode bf16 --no-cpu-baseline --no-alt 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('main loop bf16', d['ms_per_step'], d.get('ms_per_step_median'), d.get('host_enqueue_ms_per_step'))"
+  timeout 200 python bench.py --conv-mode bf16 --steps-only --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('steps-only bf16', d['ms_per_step'])"
 done
-timeout 900 python -m pytest tests/test_gpu_fullsize_grads.py tests/test_gpu_bf16.py tests/test_gpu_configs.py tests/test_gpu_api.py tests/test_gpu_dp4.py tests/test_gpu_fullsize.py -q -m gpu -x 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -5 | tee $OUT/pytest_top.log

@@ -1,8 +1,10 @@
 #!/bin/bash
-# bf16-activation step: the three ways bench.py times it, on one box
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-  timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('default fp32', d['ms_per_step'], 'alt_bf16', d['alt_bf16']['ms_per_step'])"
-  timeout 200 python bench.py --conv-mode bf16 --no-cpu-baseline --no-alt 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('main loop bf16', d['ms_per_step'], d.get('ms_per_step_median'), d.get('host_enqueue_ms_per_step'))"
-  timeout 200 python bench.py --conv-mode bf16 --steps-only --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('steps-only bf16', d['ms_per_step'])"
-done
+python scripts/bench_ctc.py 2>&1 | grep ctc_loss_grad | cut -c1-150
+python scripts/bench_ctc.py --frames 1501 --labels 400 --batch 16 2>&1 | grep ctc_loss_grad | cut -c1-150
+bash scripts/gpu_prof.sh r3_ctc_old python scripts/bench_ctc.py > /dev/null 2>&1
+python - <<'PY'
+import csv
+for r in csv.DictReader(open('gpurun_out/r3_ctc_old/r3_ctc_old_kernel_stats.csv')):
+    if 'ctc' in r['Name']: print(r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3, 1))
+PY

@@ -2,15 +2,17 @@
 //
 // Replaces tf.nn.ctc_loss (speech_model.py:74; CPU-only op in TF1) and
 // tf.nn.ctc_greedy_decoder(merge_repeated=True) (speech_model.py:113-115).
-// Semantics follow TF: blank = C-1, log-space f32, beta excludes the
-// emission at t, loss = -log p(l|x) unnormalised, gradient wrt the *logits*.
+// Semantics follow TF: blank = C-1, beta excludes the emission at t,
+// loss = -log p(l|x) unnormalised, gradient wrt the *logits*.  Arithmetic: the lattice is NOT kept in log space
+// (TF's, and rounds 1-2's here) but as mantissa * 2^exponent with an integer exponent per state ("scaled arithmetic"
+// below): same range, fewer and cheaper instructions on the sequential chain, and tighter than fp32 logs.
 //
 // Structure:
 //  1. ctc_logsoftmax: one thread per (b, t) row of <= 32 classes.
 //  2. ctc_alpha_beta<KPL>: the sequential part.  One WAVE per (utterance, direction): the
 //     2L+1 lattice states are dealt KPL-contiguous per lane, so a whole time step is register
-//     arithmetic plus two cross-lane shifts -- no LDS round trip, no barrier on the 500-1500
-//     step critical path.  Emissions are staged through LDS in 64-frame chunks, prefetched
+//     arithmetic plus four cross-lane shifts (DPP) -- no LDS round trip, no barrier on the 500-1500
+//     step critical path.  Emission factors are staged through LDS in 64-frame chunks, prefetched
 //     one chunk ahead.  alpha and beta run concurrently on different CUs.
 //  3. ctc_grad: fully parallel over (b, t): occupancy per class from alpha+beta with a fixed
 //     summation order (per-class position lists), so results are run-to-run deterministic.
@@ -21,6 +23,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CP = 32;        // class pitch of the log-softmax scratch
 constexpr int TC = 64;        // frames per LDS emission chunk
 #define NEG_INF (-__builtin_inff())
@@ -34,52 +37,45 @@ struct RowMap2 {   // (b, t) -> float offset
   }
 };
 
-// ---- base-2 log-domain helpers: v_exp_f32 / v_log_f32 are 2^x / log2(x) natively -------------
+// ---- scaled arithmetic --------------------------------------------------------------------------
+// A lattice value is m * 2^e: m a float in [0.5, 1) (0: no path reaches the state), e an int of its own PER STATE.
+// The recursion then is three v_ldexp_f32 (align to the largest exponent), two adds, one multiply by the emission and
+// v_frexp_mant / v_frexp_exp -- no v_exp_f32 / v_log_f32 (quarter rate: 20 of the 130 instructions of a frame of the
+// log-domain recursion of rounds 1-2, and its 820 cycles) on the 500-1500 step chain, no re-centring of columns, no
+// double-precision offsets.  It is also the more accurate form: every step rounds a 24-bit mantissa (relative 6e-8), where
+// a log2 value of magnitude 1000 has an ulp of 6e-5; and unlike a column-wide scale (tried in round 2: 3.7 nats off on a
+// 1 377-frame utterance, states 2^186 below the column maximum still carry the alignments that finish) a per-state
+// exponent cannot underflow.
+constexpr int EZ = -(1 << 28);           // exponent of a zero state: below anything a path reaches, differences stay in int range
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float lse2_b2(float a, float b) {
-  float m = fmaxf(a, b);
-  float ms = m == NEG_INF ? 0.f : m;
-  return ms + lg2(ex2(a - ms) + ex2(b - ms));
-}
-__device__ __forceinline__ float lse3_b2(float a, float b, float c) {   // branch free; all -inf -> -inf
-  float m = fmaxf(fmaxf(a, b), c);
-  float ms = m == NEG_INF ? 0.f : m;
-  return ms + lg2(ex2(a - ms) + ex2(b - ms) + ex2(c - ms));
-}
 
-// cross-lane moves on the VALU (DPP), no LDS round trip
+// cross-lane moves on the VALU (DPP), no LDS round trip; lanes without a source keep `fill`
 template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v, float fill) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
-                                                               __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+__device__ __forceinline__ int dpp_movei(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, CTRL, 0xF, 0xF, false);
 }
-__device__ __forceinline__ float from_lane_below(float v) { return dpp_move<0x138>(v, NEG_INF); }   // wave_shr:1
-__device__ __forceinline__ float from_lane_above(float v) { return dpp_move<0x130>(v, NEG_INF); }   // wave_shl:1
-__device__ __forceinline__ float wave_max_dpp(float v) {
-  v = fmaxf(v, dpp_move<0xB1>(v, v));     // quad_perm [1,0,3,2]
-  v = fmaxf(v, dpp_move<0x4E>(v, v));     // quad_perm [2,3,0,1]
-  v = fmaxf(v, dpp_move<0x141>(v, v));    // row_half_mirror
-  v = fmaxf(v, dpp_move<0x140>(v, v));    // row_mirror: every lane of a 16-row holds the row max
-  // the four rows through the scalar unit.  (v_permlane16_swap / v_permlane32_swap would stay on the vector side, but
-  // hipcc folds max(r[0], r[1]) of a swap's two results to r[0]: the "wave maximum" then was the maximum of lanes
-  // 0..15 -- uniform, so the re-centred lattice stayed consistent, but not centred: found when a linear-domain
-  // variant of the recursion, which needs the true maximum, overflowed.)
-  const int b = __builtin_bit_cast(int, v);
-  const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
-  const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-  const float m2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
-  const float m3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+template <int CTRL>
+__device__ __forceinline__ float dpp_movef(float v, float fill) {
+  return __builtin_bit_cast(float, dpp_movei<CTRL>(__builtin_bit_cast(int, v), __builtin_bit_cast(int, fill)));
+}
+// (by value: __builtin_bit_cast applied directly to a vector ELEMENT reads element 0 -- clang takes the vector's address)
+__device__ __forceinline__ int ibits(float x) { return __builtin_bit_cast(int, x); }
+constexpr int SHR1 = 0x138, SHL1 = 0x130;   // wave_shr:1 (value of the lane below), wave_shl:1 (of the lane above)
+
+// m * 2^e of the three aligned terms; zero terms (m = 0, any e) drop out, all zero -> 0 * 2^EZ
+__device__ __forceinline__ float aligned_sum3(float m0, int e0, float m1, int e1, float m2, int e2, int& E) {
+  E = max(max(e0, e1), e2);
+  return __builtin_ldexpf(m0, e0 - E) + __builtin_ldexpf(m1, e1 - E) + __builtin_ldexpf(m2, e2 - E);
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int NORM_EVERY = 4;   // re-centre the lattice column every 4 frames (every frame measured no more accurate)
 
-// log2-softmax of every (b, t) row into the scratch [B*T][32]
+// log2-softmax of every (b, t) row into the scratch [B*T][32], and the same numbers as emission factors for the recursion:
+// emis[row][c] = (m, e) with 2^logy = m * 2^e, m in [1, 2)
 __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __restrict__ logits, RowMap2 map,
-                                                             int B, int T, int C, float* __restrict__ logy) {
+                                                             int B, int T, int C, float* __restrict__ logy,
+                                                             float* __restrict__ emis) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * T) return;
   int b = i / T, t = i - b * T;
@@ -98,30 +94,44 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __rest
   for (int c = 0; c < CP; ++c) if (c < C) s += expf(v[c] - m);
   const float lz = m + logf(s);
   float* out = logy + (long)i * CP;
+  float* eo = emis + (long)i * CP * 2;
 #pragma unroll
   for (int q = 0; q < CP / 4; ++q) {
-    f32x4 o;
+    f32x4 o, e0, e1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (4 * q + e < C) ? (v[4 * q + e] - lz) * LOG2E : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      const float l2 = (4 * q + e < C) ? (v[4 * q + e] - lz) * LOG2E : 0.f;
+      o[e] = l2;
+      const float fl = floorf(l2);
+      // a class 2^-30000 below the frame's best cannot be emitted (a logit of -inf, in practice): factor 0.  (The bound also
+      // keeps every exponent sum of a 12 000-frame utterance inside int range.)
+      const bool dead = !(l2 > -30000.f);
+      const float mant = dead ? 0.f : ex2(l2 - fl);
+      const int ex = dead ? 0 : (int)fl;
+      if (e < 2) { e0[2 * e] = mant; e0[2 * e + 1] = __builtin_bit_cast(float, ex); }
+      else { e1[2 * (e - 2)] = mant; e1[2 * (e - 2) + 1] = __builtin_bit_cast(float, ex); }
+    }
     *reinterpret_cast<f32x4*>(out + 4 * q) = o;
+    *reinterpret_cast<f32x4*>(eo + 8 * q) = e0;
+    *reinterpret_cast<f32x4*>(eo + 8 * q + 4) = e1;
   }
 }
 
 // One wave per (utterance, direction).  blockIdx.y: 0 = alpha, 1 = beta.
-// Lattice columns are kept RE-CENTRED: stored value = log2 alpha_t(u) - off[t], where off (double,
-// one per frame) accumulates the wave maximum subtracted every NORM_EVERY frames.  The f32 state
-// therefore stays O(10) instead of O(-1000) and keeps ~1e-6 absolute precision over 500+ frames.
-// Storage is lane-major: value of state u = lane*KPL + j at frame t sits at ((t*KPL + j)*64 + lane).
+// Storage is lane-major, one (mantissa, exponent bits) record of 8 bytes per state: state u = lane*KPL + j at frame t is
+// record (t*KPL + j)*64 + lane.  A state no path reaches has mantissa 0; its exponent is then meaningless but stays far
+// below every live one (it starts at EZ and moves by one emission exponent per frame), so it never wins the alignment.
+// States u >= U: beta's stay 0 by themselves (they only receive from states above them), alpha's hold numbers nobody reads.
 template <int KPL>
-__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logy, int T, int C,
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ emis, int T, int C,
                                                             const int* __restrict__ label_ids,
                                                             const int* __restrict__ label_off,
                                                             const int* __restrict__ seq_lens,
                                                             float* __restrict__ alpha, float* __restrict__ beta,
-                                                            double* __restrict__ aoff, double* __restrict__ boff,
                                                             int* __restrict__ status) {
   constexpr int UP = KPL * 64;
-  __shared__ __attribute__((aligned(16))) float E[2][TC * CP];
+  constexpr int EC = CP * 2;                // floats per emission row (mantissa, exponent bits)
+  __shared__ __attribute__((aligned(16))) float E[2][TC * EC];
   const int b = blockIdx.x;
   const bool is_beta = blockIdx.y != 0;
   const int lane = threadIdx.x;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
   if (!is_beta && lane == 0) status[b] = 0;
   if (Tb == 0) return;      // no frames and (checked above) an empty label: p = 1, nothing to recurse over
 
-  int coff[KPL];          // class column of each state (LDS float offset inside an emission row)
+  int coff[KPL];          // emission of each state's class (LDS float offset inside an emission row)
   bool valid[KPL], skip[KPL];
 #pragma unroll
   for (int j = 0; j < KPL; ++j) {
@@ -151,44 +161,62 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     valid[j] = u < U;
     const bool odd = (u & 1) && valid[j];
     const int li = (u - 1) >> 1;
-    coff[j] = odd ? lab[li] : blank;
+    coff[j] = 2 * (odd ? lab[li] : blank);
     if (!is_beta) skip[j] = odd && u >= 3 && lab[li] != lab[li - 1];          // may arrive from u-2
     else skip[j] = odd && u + 2 < U && lab[li + 1] != lab[li];                  // may leave to u+2
   }
 
-  const float* ly = logy + (long)b * T * CP;
-  float* dst = (is_beta ? beta : alpha) + (long)b * T * UP + lane;
-  double* doff = (is_beta ? boff : aoff) + (long)b * T;
+  const float* ly = emis + (long)b * T * EC;
+  f32x2* dst = reinterpret_cast<f32x2*>(is_beta ? beta : alpha) + (long)b * T * UP + lane;
+  auto put = [&](int t, const float (&m)[KPL], const int (&e)[KPL]) {
+    f32x2* o = dst + (long)t * UP;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) o[j * 64] = f32x2{m[j], __builtin_bit_cast(float, e[j])};
+  };
 
   // stage one 64-frame chunk of emissions [chunk*TC, +TC) into E[buf]; rows past T read row T-1
-  f32x4 stage[TC * CP / 4 / 64];
+  constexpr int STG = TC * EC / 4 / 64;
+  f32x4 stage[STG];
   auto chunk_load = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < TC * CP / 4 / 64; ++i) {
+    for (int i = 0; i < STG; ++i) {
       int f = lane + 64 * i;                 // float4 index inside the chunk
-      int t = min(chunk * TC + f / (CP / 4), T - 1);
-      stage[i] = *reinterpret_cast<const f32x4*>(ly + (long)t * CP + (f % (CP / 4)) * 4);
+      int t = min(chunk * TC + f / (EC / 4), T - 1);
+      stage[i] = *reinterpret_cast<const f32x4*>(ly + (long)t * EC + (f % (EC / 4)) * 4);
     }
   };
   auto chunk_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < TC * CP / 4 / 64; ++i)
+    for (int i = 0; i < STG; ++i)
       *reinterpret_cast<f32x4*>(&E[buf][(lane + 64 * i) * 4]) = stage[i];
   };
-  auto recentre = [&](float (&s)[KPL], double& off) {
-    float m = NEG_INF;
+  float sm[KPL];   // mantissa of alpha_t(u) resp. beta_t(u)
+  int se[KPL];     // its exponent
+  // One step of either recursion for the KPL states of a lane: out = (a + b + [skip] c) * emission, brought back to [0.5, 1);
+  // sum_m / sum_e (optional) receive the aligned sum before the emission.
+  // Measured (scripts/bench_ctc.py, B = 32, T' = 501, 150 labels, the three kernels alone: 155 us; this one 117): normalising
+  // only every 8th frame (the mantissa can only grow in between, by < 6x per frame) removes 15 of the 108 instructions of a
+  // frame and is SLOWER (172 us: two bodies, a branch per frame); writing the step stage by stage over the states with
+  // scheduler fences, so that no instruction depends on its predecessor (a wave alone on its SIMD issues a dependent
+  // instruction after 8.3 cycles, an independent one after 4.9: scripts/ubench/valu_rates.hip), changes nothing (157): the
+  // compiler's order already runs at 4.2 cycles per instruction.  Ablations: no lattice stores -8 us, no LDS emission reads -18.
+  auto step = [&](const float (&am)[KPL], const int (&ae)[KPL], const float (&bm_)[KPL], const int (&be_)[KPL],
+                  const float (&cm)[KPL], const int (&ce)[KPL], const f32x2 (&em)[KPL], float (&om)[KPL], int (&oe)[KPL],
+                  float* sum_m = nullptr, int* sum_e = nullptr) {
+    float nm[KPL];
+    int ne[KPL];
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) m = fmaxf(m, s[j]);
-    m = wave_max_dpp(m);
-    if (m != NEG_INF) {
-#pragma unroll
-      for (int j = 0; j < KPL; ++j) s[j] -= m;
-      off += (double)m;
+    for (int j = 0; j < KPL; ++j) {
+      int big;
+      const float sum = aligned_sum3(am[j], ae[j], bm_[j], be_[j], cm[j], skip[j] ? ce[j] : EZ, big);   // (2^(EZ - big) = 0)
+      if (sum_m) { sum_m[j] = sum; sum_e[j] = big; }
+      const float v = sum * em[j][0];
+      nm[j] = __builtin_amdgcn_frexp_mantf(v);                     // v = 0 stays (0, ...): see the kernel's header
+      ne[j] = big + ibits(em[j][1]) + __builtin_amdgcn_frexp_expf(v);
     }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) { om[j] = nm[j]; oe[j] = ne[j]; }
   };
-
-  float s[KPL];   // re-centred log2 alpha_t(u) resp. log2 beta_t(u)
-  double off = 0.0;
   if (!is_beta) {
     // ---- alpha: t ascending ------------------------------------------------------------
     chunk_load(0);
@@ -196,96 +224,106 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
       const int u = lane * KPL + j;
-      s[j] = (u < 2 && valid[j]) ? E[0][coff[j]] : NEG_INF;
+      const f32x2 q = *reinterpret_cast<const f32x2*>(&E[0][coff[j]]);
+      const bool on = u < 2 && valid[j] && q[0] > 0.f;
+      sm[j] = on ? 0.5f * q[0] : 0.f;
+      se[j] = on ? ibits(q[1]) + 1 : EZ;
     }
+    put(0, sm, se);
+    // one frame: alpha_t(u) = (alpha_{t-1}(u) + alpha_{t-1}(u-1) + [skip] alpha_{t-1}(u-2)) * y_t(u)
+    auto frame = [&](int t, const float* e) {
+      f32x2 em[KPL];
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) dst[j * 64] = s[j];
-    if (lane == 0) doff[0] = 0.0;
+      for (int j = 0; j < KPL; ++j) em[j] = *reinterpret_cast<const f32x2*>(e + coff[j]);
+      const float up1m = dpp_movef<SHR1>(sm[KPL - 1], 0.f);
+      const int up1e = dpp_movei<SHR1>(se[KPL - 1], EZ);
+      const float up2m = KPL >= 2 ? dpp_movef<SHR1>(sm[KPL >= 2 ? KPL - 2 : 0], 0.f) : dpp_movef<SHR1>(up1m, 0.f);
+      const int up2e = KPL >= 2 ? dpp_movei<SHR1>(se[KPL >= 2 ? KPL - 2 : 0], EZ) : dpp_movei<SHR1>(up1e, EZ);
+      float m1[KPL], m2[KPL];
+      int e1[KPL], e2[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        m1[j] = j >= 1 ? sm[j >= 1 ? j - 1 : 0] : up1m;
+        e1[j] = j >= 1 ? se[j >= 1 ? j - 1 : 0] : up1e;
+        m2[j] = j >= 2 ? sm[j >= 2 ? j - 2 : 0] : (j == 1 ? up1m : up2m);
+        e2[j] = j >= 2 ? se[j >= 2 ? j - 2 : 0] : (j == 1 ? up1e : up2e);
+      }
+      step(sm, se, m1, e1, m2, e2, em, sm, se);
+      put(t, sm, se);
+    };
     const int nchunks = (Tb + TC - 1) / TC;
     for (int ch = 0; ch < nchunks; ++ch) {
       const int buf = ch & 1;
       if (ch + 1 < nchunks) chunk_load(ch + 1);
       const int t_lo = max(1, ch * TC), t_hi = min(Tb, (ch + 1) * TC);
       for (int t = t_lo; t < t_hi; ++t) {
-        const float* e = &E[buf][(t - ch * TC) * CP];
-        float ev[KPL];
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) ev[j] = e[coff[j]];
-        const float up1 = from_lane_below(s[KPL - 1]);
-        const float up2 = KPL >= 2 ? from_lane_below(s[KPL >= 2 ? KPL - 2 : 0]) : from_lane_below(up1);
-        float n[KPL];
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-          const float p1 = j >= 1 ? s[j >= 1 ? j - 1 : 0] : up1;
-          const float p2 = j >= 2 ? s[j >= 2 ? j - 2 : 0] : (j == 1 ? up1 : up2);
-          const float v = ev[j] + lse3_b2(s[j], p1, skip[j] ? p2 : NEG_INF);
-          n[j] = valid[j] ? v : NEG_INF;
-        }
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) s[j] = n[j];
-        if ((t & (NORM_EVERY - 1)) == 0) recentre(s, off);
-        float* o = dst + (long)t * UP;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
-        if (lane == 0) doff[t] = off;
+        const float* e = &E[buf][(t - ch * TC) * EC];
+        frame(t, e);
       }
       if (ch + 1 < nchunks) chunk_store(buf ^ 1);
     }
   } else {
-    // ---- beta: t descending; step t consumes the emissions of frame t+1 -------------------
+    // ---- beta: t descending.  Carried: G_t(u) = beta_t(u) * y_t(u) (beta itself excludes the emission at t, and is what is
+    // stored): beta_t(u) = G_{t+1}(u) + G_{t+1}(u+1) + [skip] G_{t+1}(u+2).  The emission is then needed at the END of a
+    // step, as in alpha, and its LDS read has the whole step to arrive. ---------------------------------------------------
     const int last = (Tb - 1) / TC;
     chunk_load(last);
     chunk_store(last & 1);
-#pragma unroll
-    for (int j = 0; j < KPL; ++j) {
-      const int u = lane * KPL + j;
-      s[j] = (valid[j] && u >= U - 2) ? 0.f : NEG_INF;
-    }
     {
-      float* o = dst + (long)(Tb - 1) * UP;
+      const float* e = &E[last & 1][(Tb - 1 - last * TC) * EC];
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
-      if (lane == 0) doff[Tb - 1] = 0.0;
+      for (int j = 0; j < KPL; ++j) {
+        const int u = lane * KPL + j;
+        const bool on = valid[j] && u >= U - 2;
+        sm[j] = on ? 0.5f : 0.f;               // 1 = 0.5 * 2^1
+        se[j] = on ? 1 : EZ;
+      }
+      put(Tb - 1, sm, se);
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        const f32x2 q = *reinterpret_cast<const f32x2*>(e + coff[j]);
+        sm[j] *= 0.5f * q[0];                  // stays in [0.5, 1) (or 0)
+        se[j] += ibits(q[1]) + 1;
+      }
     }
+    auto frame = [&](int t, const float* e) {
+      f32x2 em[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) em[j] = *reinterpret_cast<const f32x2*>(e + coff[j]);
+      const float dn1m = dpp_movef<SHL1>(sm[0], 0.f);
+      const int dn1e = dpp_movei<SHL1>(se[0], EZ);
+      const float dn2m = KPL >= 2 ? dpp_movef<SHL1>(sm[KPL >= 2 ? 1 : 0], 0.f) : dpp_movef<SHL1>(dn1m, 0.f);
+      const int dn2e = KPL >= 2 ? dpp_movei<SHL1>(se[KPL >= 2 ? 1 : 0], EZ) : dpp_movei<SHL1>(dn1e, EZ);
+      float m1[KPL], m2[KPL], bm[KPL];
+      int e1[KPL], e2[KPL], be[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        m1[j] = j + 1 < KPL ? sm[j + 1 < KPL ? j + 1 : 0] : dn1m;
+        e1[j] = j + 1 < KPL ? se[j + 1 < KPL ? j + 1 : 0] : dn1e;
+        m2[j] = j + 2 < KPL ? sm[j + 2 < KPL ? j + 2 : 0] : (j + 2 == KPL ? dn1m : dn2m);
+        e2[j] = j + 2 < KPL ? se[j + 2 < KPL ? j + 2 : 0] : (j + 2 == KPL ? dn1e : dn2e);
+      }
+      step(sm, se, m1, e1, m2, e2, em, sm, se, bm, be);       // beta_t(u) itself (before the emission) is what is stored
+      put(t, bm, be);
+    };
     for (int ch = last; ch >= 0; --ch) {
       const int buf = ch & 1;
       if (ch > 0) chunk_load(ch - 1);
-      // frames f = t+1 of this chunk: f in [max(1, ch*TC), min(Tb-1, ch*TC+TC-1)]
-      const int f_hi = min(Tb - 1, ch * TC + TC - 1), f_lo = max(1, ch * TC);
-      for (int f = f_hi; f >= f_lo; --f) {
-        const float* e = &E[buf][(f - ch * TC) * CP];
-        float g[KPL];
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) g[j] = s[j] + e[coff[j]];
-        const float dn1 = from_lane_above(g[0]);
-        const float dn2 = KPL >= 2 ? from_lane_above(g[KPL >= 2 ? 1 : 0]) : from_lane_above(dn1);
-        float n[KPL];
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-          const float p1 = j + 1 < KPL ? g[j + 1 < KPL ? j + 1 : 0] : dn1;
-          const float p2 = j + 2 < KPL ? g[j + 2 < KPL ? j + 2 : 0] : (j + 2 == KPL ? dn1 : dn2);
-          const float v = lse3_b2(g[j], p1, skip[j] ? p2 : NEG_INF);
-          n[j] = valid[j] ? v : NEG_INF;
-        }
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) s[j] = n[j];
-        if ((f & (NORM_EVERY - 1)) == 0) recentre(s, off);
-        float* o = dst + (long)(f - 1) * UP;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) o[j * 64] = s[j];
-        if (lane == 0) doff[f - 1] = off;
+      const int t_hi = min(Tb - 2, ch * TC + TC - 1), t_lo = ch * TC;
+      for (int t = t_hi; t >= t_lo; --t) {
+        const float* e = &E[buf][(t - ch * TC) * EC];
+        frame(t, e);
       }
       if (ch > 0) chunk_store(buf ^ 1);
     }
   }
 }
 
-// grad[b,t,c] = scale * (y_t(c) - sum_{u: l'_u = c} exp(alpha_t(u) + beta_t(u) - log p))
+// grad[b,t,c] = scale * (y_t(c) - sum_{u: l'_u = c} alpha_t(u) beta_t(u) / p)
 constexpr int GF = 16;   // frames per block (4 waves x 4)
+template <int KPL>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logy, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta,
-                                                       const double* __restrict__ aoff,
-                                                       const double* __restrict__ boff, int T, int C, int KPL,
+                                                       const float* __restrict__ beta, int T, int C,
                                                        const int* __restrict__ label_ids,
                                                        const int* __restrict__ label_off,
                                                        const int* __restrict__ seq_lens,
@@ -296,7 +334,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   int* pos_off = smem;                 // [32]
   int* pos_list = smem + 32;           // [lmax]
   float* wbuf = reinterpret_cast<float*>(smem + 32 + lmax);   // [4][lmax]
-  const int UP = KPL * 64;
+  constexpr int UP = KPL * 64;
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int* lab = label_ids + label_off[b];
@@ -320,10 +358,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   }
   __syncthreads();
 
-  double logp2 = 0.0;   // log2 p(l|x); stays 0 (p = 1) for an utterance without frames
+  // p(l|x) = alpha_{Tb-1}(U-1) + alpha_{Tb-1}(U-2) = pm * 2^pe; stays 1 for an utterance without frames
+  int pe = 0;
+  double logp2 = 0.0;
   if (!bad && Tb > 0) {
-    const float* al = alpha + ((long)b * T + (Tb - 1)) * UP;
-    logp2 = aoff[(long)b * T + Tb - 1] + (double)lse2_b2(al[sidx(U - 1)], U > 1 ? al[sidx(U - 2)] : NEG_INF);
+    const f32x2* al = reinterpret_cast<const f32x2*>(alpha) + ((long)b * T + (Tb - 1)) * UP;
+    const f32x2 a1 = al[sidx(U - 1)], a2 = U > 1 ? al[sidx(U - 2)] : f32x2{0.f, __builtin_bit_cast(float, EZ)};
+    const float sum = aligned_sum3(a1[0], ibits(a1[1]), a2[0], ibits(a2[1]), 0.f, EZ, pe);
+    logp2 = sum > 0.f ? (double)pe + log2((double)sum) : -__builtin_inf();
   }
   if (blockIdx.x == 0 && tid == 0) loss[b] = bad ? __builtin_inff() : (float)(-logp2 * (double)LN2);
 
@@ -333,19 +375,25 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const bool live = !bad && t < Tb && t < T;
     float blank_sum = 0.f, occ_scale = 1.f;
     if (live) {
-      const float* al = alpha + ((long)b * T + t) * UP;
-      const float* be = beta + ((long)b * T + t) * UP;
-      const float shift = (float)(aoff[(long)b * T + t] + boff[(long)b * T + t] - logp2);
+      const f32x2* al = reinterpret_cast<const f32x2*>(alpha) + ((long)b * T + t) * UP;
+      const f32x2* be = reinterpret_cast<const f32x2*>(beta) + ((long)b * T + t) * UP;
       float label_sum = 0.f;
-      for (int u = lane; u < U; u += 64) {
-        const int i = sidx(u);
-        float w = ex2(al[i] + be[i] + shift);
-        if (u & 1) { wb[u >> 1] = w; label_sum += w; } else blank_sum += w;
+      // in storage order (state lane*KPL + j is record j*64 + lane: 512 contiguous bytes per j), all loads of the frame issued
+      // before the first is used
+      f32x2 av[KPL], bv[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) { av[j] = al[j * 64 + lane]; bv[j] = be[j * 64 + lane]; }
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        const int u = lane * KPL + j;
+        // alpha_t(u) beta_t(u) / 2^pe: of the order of 1 where it matters, 0 for states no path passes through
+        float w = __builtin_ldexpf(av[j][0] * bv[j][0], ibits(av[j][1]) + ibits(bv[j][1]) - pe);
+        w = u < U ? w : 0.f;                                       // (alpha's records beyond U hold numbers nobody may read)
+        if (u & 1) { if (u < U) wb[u >> 1] = w; label_sum += w; } else blank_sum += w;
       }
       blank_sum = st::wave_sum(blank_sum);
-      // sum_u alpha_t(u) beta_t(u) == p(l|x) for EVERY t; the recursions accumulate the (biased)
-      // 1-ULP error of v_exp/v_log over hundreds of dependent steps, so the per-frame sum can be off
-      // by ~1e-4 relative.  Normalising by the frame's own total removes that common factor.
+      // sum_u alpha_t(u) beta_t(u) == p(l|x) for EVERY t: normalising by the frame's own total removes the rounding the two
+      // recursions accumulated on their way to this frame (a common factor of all its states)
       const float total = blank_sum + st::wave_sum(label_sum);
       occ_scale = total > 0.f ? 1.f / total : 1.f;
       blank_sum *= occ_scale;
@@ -437,10 +485,10 @@ RowMap2 make_map2(const st_tensor3& t) {
 }
 
 template <int KPL>
-void launch_ab(int B, hipStream_t s, const float* logy, int T, int C, const int* ids, const int* off,
-               const int* lens, float* alpha, float* beta, double* aoff, double* boff, int* status) {
-  hipLaunchKernelGGL((ctc_alpha_beta_kernel<KPL>), dim3(B, 2), dim3(64), 0, s, logy, T, C, ids, off, lens,
-                     alpha, beta, aoff, boff, status);
+void launch_ab(int B, hipStream_t s, const float* emis, int T, int C, const int* ids, const int* off,
+               const int* lens, float* alpha, float* beta, int* status) {
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<KPL>), dim3(B, 2), dim3(64), 0, s, emis, T, C, ids, off, lens,
+                     alpha, beta, status);
 }
 
 }  // namespace
@@ -451,7 +499,8 @@ size_t st_ctc_ws(int batch, int frames, int max_label_len) {
   int kpl = pick_kpl(std::max(max_label_len, 0));
   if (kpl < 0 || batch <= 0 || frames <= 0) return 0;
   size_t rows = (size_t)batch * frames;
-  return rows * CP * sizeof(float) + 2 * rows * kpl * 64 * sizeof(float) + 2 * rows * sizeof(double) + 512;
+  // log2-softmax [rows][32] | emission factors [rows][32][2] | alpha, beta: (mantissa, exponent) records [rows][kpl*64][2]
+  return rows * CP * sizeof(float) * 3 + 4 * rows * kpl * 64 * sizeof(float) + 512;
 }
 
 int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, const int32_t* label_offsets,
@@ -471,23 +520,26 @@ int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, con
   const int B = logits->batch, T = logits->frames, C = logits->channels;
   const size_t rows = (size_t)B * T;
   float* logy = reinterpret_cast<float*>(workspace);
-  float* alpha = logy + rows * CP;
-  float* beta = alpha + rows * kpl * 64;
-  double* aoff = reinterpret_cast<double*>(beta + rows * kpl * 64);   // 8-byte aligned: all counts are even
-  double* boff = aoff + rows;
+  float* emis = logy + rows * CP;
+  float* alpha = emis + rows * CP * 2;             // (mantissa, exponent) records
+  float* beta = alpha + rows * kpl * 64 * 2;
   hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, logits->base,
-                     make_map2(*logits), B, T, C, logy);
+                     make_map2(*logits), B, T, C, logy, emis);
   switch (kpl) {
-#define ST_AB(K) case K: launch_ab<K>(B, s, logy, T, C, label_ids, label_offsets, seq_lens, alpha, beta, aoff, boff, status); break;
+#define ST_AB(K) case K: launch_ab<K>(B, s, emis, T, C, label_ids, label_offsets, seq_lens, alpha, beta, status); break;
     ST_AB(1) ST_AB(2) ST_AB(3) ST_AB(4) ST_AB(5) ST_AB(6) ST_AB(8) ST_AB(10) ST_AB(12) ST_AB(16)
 #undef ST_AB
   }
   if (int e = st::check_launch("ctc_alpha_beta")) return e;
   const int lmax = std::max(1, kpl * 32);
   const size_t shm = (32 + (size_t)lmax * 5) * sizeof(int);
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3(st::ceil_div(T, GF), B), dim3(256), shm, s, logy, alpha, beta, aoff, boff,
-                     T, C, kpl, label_ids, label_offsets, seq_lens, status, grad_scale, grad->base, make_map2(*grad),
-                     std::min(grad->c_pitch, CP), loss, lmax);
+  switch (kpl) {
+#define ST_GR(K) case K: hipLaunchKernelGGL(ctc_grad_kernel<K>, dim3(st::ceil_div(T, GF), B), dim3(256), shm, s, logy, alpha, beta, \
+                                            T, C, label_ids, label_offsets, seq_lens, status, grad_scale, grad->base,            \
+                                            make_map2(*grad), std::min(grad->c_pitch, CP), loss, lmax); break;
+    ST_GR(1) ST_GR(2) ST_GR(3) ST_GR(4) ST_GR(5) ST_GR(6) ST_GR(8) ST_GR(10) ST_GR(12) ST_GR(16)
+#undef ST_GR
+  }
   return st::check_launch("ctc_grad");
 }
 

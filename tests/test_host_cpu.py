@@ -80,7 +80,8 @@ def test_argument_validation_without_gpu():
   # halo too small for pad_left = 5
   assert lib.st_conv1d_nwc_fwd_f32(ctypes.byref(x), 1, None, 11, 1, 5, 1, ctypes.byref(y), None) == -1
   assert b'halo' in lib.st_last_error()
-  assert lib.st_ctc_ws(32, 501, 150) == 32 * 501 * (4 * (32 + 2 * 5 * 64) + 16) + 512
+  # log2-softmax [32] + emission factors [32][2] + alpha, beta records [5 * 64][2] floats per (utterance, frame)
+  assert lib.st_ctc_ws(32, 501, 150) == 32 * 501 * 4 * (32 * 3 + 4 * 5 * 64) + 512
   assert lib.st_ctc_ws(1, 10, 600) == 0                                    # label too long
 
 

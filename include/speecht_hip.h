@@ -190,7 +190,9 @@ int st_conv1d_nwc_bwd_filter_f32(const st_tensor3* x, const st_tensor3* dz, int 
  * [B+1], label_ids [label_offsets[B]].  seq_lens[b] = frames to use (reference passes
  * sequence_lengths // 2).  Outputs: loss[b] = -log p(l|x); grad = grad_scale * dloss/dlogits
  * (0 for t >= seq_lens[b]); status[b] != 0 when the label does not fit ("Not enough time for
- * target transition sequence") -- then loss = +inf and grad = 0. */
+ * target transition sequence") -- then loss = +inf and grad = 0.  The forward-backward lattice is kept as mantissa * 2^exponent
+ * with an integer exponent per state (not in log space): exact range, no transcendental on the sequential chain; a class more than
+ * 2^-30000 below its frame's best counts as impossible.  Workspace: st_ctc_ws bytes (log-softmax, emission factors, two lattices). */
 size_t st_ctc_ws(int batch, int frames, int max_label_len);
 int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids,
                          const int32_t* label_offsets, const int32_t* seq_lens, int max_label_len,

@@ -40,9 +40,10 @@ struct RowMap2 {   // (b, t) -> float offset
 // ---- scaled arithmetic --------------------------------------------------------------------------
 // A lattice value is m * 2^e: m a float in [0.5, 1) (0: no path reaches the state), e an int of its own PER STATE.
 // The recursion then is three v_ldexp_f32 (align to the largest exponent), two adds, one multiply by the emission and
-// v_frexp_mant / v_frexp_exp -- no v_exp_f32 / v_log_f32 (quarter rate: 20 of the 130 instructions of a frame of the
-// log-domain recursion of rounds 1-2, and its 820 cycles) on the 500-1500 step chain, no re-centring of columns, no
-// double-precision offsets.  It is also the more accurate form: every step rounds a 24-bit mantissa (relative 6e-8), where
+// v_frexp_mant / v_frexp_exp -- no v_exp_f32 / v_log_f32 (8.8 cycles of issue against 4.9 for everything else,
+// scripts/ubench/valu_rates.hip: 20 of the 130 instructions of a frame of the log-domain recursion of rounds 1-2) on the
+// 500-1500 step chain, no re-centring of columns, no double-precision offsets: 108 instructions per frame for five states
+// per lane, 160 -> 117 us for T' = 501.  It is also the more accurate form: every step rounds a 24-bit mantissa (relative 6e-8), where
 // a log2 value of magnitude 1000 has an ulp of 6e-5; and unlike a column-wide scale (tried in round 2: 3.7 nats off on a
 // 1 377-frame utterance, states 2^186 below the column maximum still carry the alignments that finish) a per-state
 // exponent cannot underflow.

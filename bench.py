@@ -134,8 +134,8 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
       cin_real = l.cin * (l.stride if f['shift'] is not None else 1)
       fl = 2.0 * rows * (2 * cin_real) * (2 * l.cout) * nb
       nbytes = 4.0 * nb * (rows * 2 * cin_real + 4 * cin_real * l.cout + rows * 2 * l.cout)
-      # the layer's workspace as its own entry points lay it out: [tail area of the per-bin products | output spectra]
-      tail_bytes = _lib_handle().st_gemm_nn_batched_tail_ws()
+      # the layer's workspace as its own entry points lay it out: [stream-K area of the per-bin products | output spectra]
+      tail_bytes = _lib_handle().st_gemm_nn_batched_ws_bytes()
       tail, outp = P(f['ws']), ctypes.c_void_p(f['ws'].data_ptr() + tail_bytes)
       launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
           'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
@@ -421,21 +421,25 @@ def parity_on_bench_inputs(eng, x, seq_lens, labels, rows=(0, -1)):
   ref = O.wav2letter_forward(np.asarray(x, np.float32)[rows].astype(np.float64), params64, layers)
   loss_ref, _ = O.ctc_loss_and_grad(ref, [labels[r] for r in rows], np.asarray(seq_lens)[rows] // 2)
   ref_dec, _ = O.ctc_greedy_decode(ref, np.asarray(seq_lens)[rows] // 2)
-  loss_dev = eng.loss.cpu().numpy()[rows].astype(np.float64)
+  loss_f32 = eng.loss.cpu().numpy()[rows].astype(np.float64)      # the fp32 value tf.nn.ctc_loss would return
+  loss_dev = eng.losses_precise()[rows]                            # (hi, lo) float pair of the kernel: -log p as it knows it
   out = dict(rows=rows, max_logit_err=float(np.max(np.abs(got - ref))),
              ctc_loss_delta=float(np.max(np.abs(loss_dev - loss_ref))),
              ctc_loss_delta_rel=float(np.max(np.abs(loss_dev - loss_ref) / np.abs(loss_ref))),
+             ctc_loss_delta_fp32_output=float(np.max(np.abs(loss_f32 - loss_ref))),
              ctc_loss_oracle=[round(float(v), 4) for v in loss_ref],
              greedy_strings_equal=bool([dec[r] for r in rows] == ref_dec),
              oracle='oracle/w2l_oracle.py float64 on utterances {} of the bench batch, initial weights'.format(rows))
-  # What is ASSERTED (bench.py exits non-zero otherwise): north_star's "within 1e-4 fp32" is read as 1e-4 ABSOLUTE for the
-  # logits (O(1) numbers) and 1e-4 RELATIVE for the per-utterance CTC loss (an unnormalised sum over ~500 frames, O(1000):
-  # one fp32 ulp of such a loss is 1.2e-4 absolute, so an absolute 1e-4 cannot be represented, let alone asserted);
-  # `ctc_loss_delta` is the absolute difference, reported for the record.
-  out['asserted'] = dict(max_logit_err='< 1e-4 absolute', ctc_loss_delta_rel='< 1e-4 relative', greedy_strings_equal=True,
-                         ctc_loss_delta='reported, not asserted (absolute; one fp32 ulp of the loss is %.1e)'
-                                        % float(np.spacing(np.float32(np.max(np.abs(loss_ref))))))
-  out['passed'] = bool(out['max_logit_err'] < 1e-4 and out['ctc_loss_delta_rel'] < 1e-4 and out['greedy_strings_equal'])
+  # What is ASSERTED (bench.py exits non-zero otherwise): north_star's "within 1e-4": 1e-4 ABSOLUTE for the logits (O(1)
+  # numbers) and 1e-4 ABSOLUTE for the per-utterance CTC loss -- an unnormalised sum over ~500 frames, O(1000), where one fp32
+  # ulp is 1.2e-4: the kernel therefore returns -log p as a (hi, lo) float pair (st_ctc_loss_grad_hilo_f32); hi alone, the fp32
+  # number TF's op returns, is reported as `ctc_loss_delta_fp32_output` and cannot meet an absolute 1e-4 at this magnitude.
+  out['asserted'] = dict(max_logit_err='< 1e-4 absolute', ctc_loss_delta='< 1e-4 absolute (hi + lo of the kernel\'s loss pair)',
+                         ctc_loss_delta_rel='< 1e-4 relative', greedy_strings_equal=True,
+                         ctc_loss_delta_fp32_output='reported, not asserted (one fp32 ulp of the loss is %.1e)'
+                                                    % float(np.spacing(np.float32(np.max(np.abs(loss_ref))))))
+  out['passed'] = bool(out['max_logit_err'] < 1e-4 and out['ctc_loss_delta'] < 1e-4 and out['ctc_loss_delta_rel'] < 1e-4 and
+                       out['greedy_strings_equal'])
   return out
 
 

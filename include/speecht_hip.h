@@ -60,7 +60,7 @@ const char* st_last_error(void);
  * launches); st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
  * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split", "transform_wgs", "bf16_wgrad_target"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "streamk", "transform_wgs", "bf16_wgrad_target"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 int st_trace_begin_timed(void);
@@ -118,21 +118,24 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  *             the filter-gradient call
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
- *   workspace st_conv1d_fft_ws bytes, scratch of one call (headed by st_gemm_nn_batched_ws_f32's tail area) */
+ *   workspace st_conv1d_fft_ws bytes, scratch of one call, headed by st_gemm_nn_batched_ws_f32's area (control words zero before the
+ *             first call: allocate it zero-filled; one workspace per stream) */
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
 /* the per-bin products themselves: `batches` independent row-major fp32 GEMMs C[i] = A[i] * B[i] (A [m][lda], B [k][n],
  * C [m][ldc]; k a multiple of 32, n of 128; strides in floats) on the convolution MFMA kernel, bin i on XCD i % 8 */
 int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                            int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream);
-/* The same with a "tail area" of st_gemm_nn_batched_tail_ws() bytes of scratch (arrival counters, zeroed on the stream by
- * the call, and partial tiles): with it the launch cuts the tiles of the last, partial set of 8 bins (36 bins: bins 32..35) into
- * slices of the reduction so that they fill the chip instead of half the XCDs for a whole extra round; the slices of a tile
- * are summed in slice order by whichever arrives last (bit-reproducible, no atomics on data).  The frequency-domain entry
- * points below carry this area at the head of their workspace. */
-size_t st_gemm_nn_batched_tail_ws(void);
+/* The same with st_gemm_nn_batched_ws_bytes() bytes of scratch: a launch whose 64 x 128 tiles would leave the last round of
+ * workgroups ragged (the 7-tap layers: 36 bins x 16 tiles = 576 workgroups on 512 slots) then runs as ONE persistent launch
+ * that deals the (bin, tile, k-tile) list in equal runs to 512 workgroups; a tile cut in two is summed head + tail by the
+ * workgroup that holds its start (bit-reproducible, no atomics on data).  The first st_gemm_nn_batched_ctrl_bytes() bytes of
+ * the scratch are control words: ZERO before the first call, left zero by every call; one scratch per stream.  The
+ * frequency-domain entry points below carry this area at the head of their workspace. */
+size_t st_gemm_nn_batched_ws_bytes(void);
+size_t st_gemm_nn_batched_ctrl_bytes(void);
 int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
-                              int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* tail_workspace,
-                              size_t tail_workspace_bytes, void* stream);
+                              int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* workspace,
+                              size_t workspace_bytes, void* stream);
 /* out[i] = A[i]^T * Z[i]: A [m][lda] (k columns), Z [m][ldz] (n columns), out [k][n]; the reduction runs over the m rows
  * (m a multiple of 32, k and n of 128) -- the lag products of the filter gradient */
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
@@ -198,6 +201,14 @@ int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids,
                          const int32_t* label_offsets, const int32_t* seq_lens, int max_label_len,
                          float grad_scale, float* loss, const st_tensor3* grad, int32_t* status,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the loss as a (hi, lo) float pair: loss[b] is the fp32 value above (what TF's fp32 op returns), loss_lo[b]
+ * (may be null) the part of -log p that fp32 cannot hold at that magnitude -- the kernel knows log p in double (the lattice
+ * rounds 6e-8 relative per step, one fp32 ulp of a loss of 1 239 is 1.2e-4); (double)loss[b] + loss_lo[b] is the loss to
+ * ~1e-6 of the float64 oracle.  speech_model.py:74-75: avg_loss = mean of these. */
+int st_ctc_loss_grad_hilo_f32(const st_tensor3* logits, const int32_t* label_ids,
+                              const int32_t* label_offsets, const int32_t* seq_lens, int max_label_len,
+                              float grad_scale, float* loss, float* loss_lo, const st_tensor3* grad, int32_t* status,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K14: tf.nn.ctc_greedy_decoder(merge_repeated) (speech_model.py:113-115) ------------
  * ids [B][max_out] int32 (max_out >= frames), out_lens [B], neg_sum_logits [B]. */

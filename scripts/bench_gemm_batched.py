@@ -17,19 +17,21 @@ for kv in args.tune:
   set_tuning(k, int(v))
 dev = torch.device('cuda:0')
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-shapes = [('fwd', args.rows, 512, 4096), ('bwd', args.rows, 4096, 512), ('wgrad', 512, args.rows, 4096)]
+from speecht_amd import _lib  # noqa: E402
+WS_BYTES = _lib.load().st_gemm_nn_batched_ws_bytes()
+WS = torch.zeros(WS_BYTES // 4, device=dev)        # stream-K scratch of the per-bin products (control words zero)
+shapes = [('fwd', args.rows, 512, 4096), ('bwd', args.rows, 4096, 512)]
 for name, M, K, N in shapes:
   A = torch.randn(args.bins * M * K, device=dev)
   B = torch.randn(args.bins * K * N, device=dev)
   C = torch.empty(args.bins * M * N, device=dev)
-  fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, args.bins, None)
+  fn = lambda: call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, args.bins, P(WS), WS_BYTES, None)
   ms = timeit(fn, 20)
   print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s' % (name, M, K, N, args.bins, ms, 2.0 * M * K * N * args.bins / ms / 1e9))
 # the 7-tap 250 -> 250 layers: 36 bins
-for name, M, K, N in [('fwd7', args.rows, 512, 512), ('wgrad7', 512, args.rows, 512)]:
-  bins = 36
+for name, M, K, N, bins in [('fwd7', args.rows, 512, 512, 36), ('fwd0', args.rows, 384, 512, 45), ('bwd0-ish', args.rows, 512, 384 + 128, 45)]:
   A = torch.randn(bins * M * K, device=dev); B = torch.randn(bins * K * N, device=dev); C = torch.empty(bins * M * N, device=dev)
-  fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, None)
+  fn = lambda: call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(WS), WS_BYTES, None)
   ms = timeit(fn, 20)
   print('%-6s M=%d K=%d N=%d x%d: %.3f ms  %.1f TF/s' % (name, M, K, N, bins, ms, 2.0 * M * K * N * bins / ms / 1e9))
 
@@ -50,6 +52,6 @@ if os.environ.get('SWEEP'):
     for K in (32, 128, 256, 512, 1024):
       M, N = args.rows, 512
       A = torch.randn(bins * M * K, device=dev); B = torch.randn(bins * K * N, device=dev); C = torch.empty(bins * M * N, device=dev)
-      fn = lambda: call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, None)
+      fn = lambda: call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(WS), WS_BYTES, None)
       ms = timeit(fn, 20)
       print('sweep  bins=%d M=%d K=%d N=%d: %.1f us  %.1f TF/s' % (bins, M, K, N, ms * 1e3, 2.0 * M * K * N * bins / ms / 1e9))

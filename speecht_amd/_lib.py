@@ -41,7 +41,8 @@ _SIGNATURES = {
                                    POINTER(c_int)]),
     'st_gemm_nn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                        c_int, c_int, c_void_p]),
-    'st_gemm_nn_batched_tail_ws': (c_size_t, []),
+    'st_gemm_nn_batched_ws_bytes': (c_size_t, []),
+    'st_gemm_nn_batched_ctrl_bytes': (c_size_t, []),
     'st_gemm_nn_batched_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_gemm_tn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int,
@@ -74,6 +75,8 @@ _SIGNATURES = {
     'st_bias_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_ctc_ws': (c_size_t, [c_int, c_int, c_int]),
     'st_ctc_loss_grad_f32': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, _T3P,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    'st_ctc_loss_grad_hilo_f32': (c_int, [_T3P, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, _T3P,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_ctc_greedy_decode': (c_int, [_T3P, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'st_ctc_beam_ws': (c_size_t, [c_int, c_int, c_int]),

@@ -45,18 +45,22 @@ void trace(const char* fmt, ...) {
   }
 }
 LaunchTimer::LaunchTimer(hipStream_t) : start_(nullptr), stop_(nullptr) {
-  if (g_trace_on.load(std::memory_order_relaxed) != 2 || g_last_line < 0) return;
+  // the line this launch belongs to is CONSUMED here: a later launch on this thread that traced nothing of its own must not
+  // attach its events to it (and trace_begin forgets it: an index into the previous collection's lines)
+  const int line = g_last_line;
+  g_last_line = -1;
+  if (g_trace_on.load(std::memory_order_relaxed) != 2 || line < 0) return;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess) return;
   if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
   std::lock_guard<std::mutex> lock(g_trace_mu);
-  if ((int)g_timed.size() >= kMaxTimed || g_last_line >= (int)g_lines.size() ||
-      (!g_timed_filter.empty() && g_lines[g_last_line].find(g_timed_filter) == std::string::npos)) {
+  if ((int)g_timed.size() >= kMaxTimed || line >= (int)g_lines.size() ||
+      (!g_timed_filter.empty() && g_lines[line].find(g_timed_filter) == std::string::npos)) {
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return;
   }
-  g_timed.push_back(TimedLaunch{g_last_line, e0, e1});
+  g_timed.push_back(TimedLaunch{line, e0, e1});
   start_ = e0;
   stop_ = e1;
 }
@@ -64,7 +68,7 @@ LaunchTimer::LaunchTimer(hipStream_t) : start_(nullptr), stop_(nullptr) {
 // ---- tuning overrides: 0 = the library's policy.  Set explicitly by perf scripts through st_set_tuning;
 // the launch path reads plain ints (no environment look-ups).
 static const char* const kTuneNames[TUNE_COUNT] = {"gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm", "no_fast",
-                                                   "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "tail_split", "transform_wgs", "bf16_wgrad_target"};
+                                                   "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "streamk", "transform_wgs", "bf16_wgrad_target"};
 static std::atomic<int> g_tune[TUNE_COUNT];
 int tuning(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 }  // namespace st
@@ -78,6 +82,7 @@ static int trace_begin(int mode) {
   st::g_lines.clear();
   for (auto& t : st::g_timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
   st::g_timed.clear();
+  st::g_last_line = -1;                 // (this thread's; other threads consume theirs at their next LaunchTimer)
   st::g_trace_on.store(mode);
   return ST_OK;
 }

@@ -525,13 +525,14 @@ int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const f
   return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream));
 }
 
-size_t st_gemm_nn_batched_tail_ws(void) { return (size_t)st::TAIL_WS_FLOATS * sizeof(float); }
+size_t st_gemm_nn_batched_ws_bytes(void) { return (size_t)st::SK_WS_FLOATS * sizeof(float); }
+size_t st_gemm_nn_batched_ctrl_bytes(void) { return (size_t)st::SK_CTRL_WORDS * sizeof(unsigned); }
 
 int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c, int64_t ldc,
-                              int64_t c_batch, int m, int k, int n, int batches, void* tail_workspace, size_t tail_workspace_bytes,
+                              int64_t c_batch, int m, int k, int n, int batches, void* workspace, size_t workspace_bytes,
                               void* stream) {
-  float* tail = (tail_workspace && tail_workspace_bytes >= st_gemm_nn_batched_tail_ws()) ? reinterpret_cast<float*>(tail_workspace) : nullptr;
-  return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream), tail);
+  float* sk = (workspace && workspace_bytes >= st_gemm_nn_batched_ws_bytes()) ? reinterpret_cast<float*>(workspace) : nullptr;
+  return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream), sk);
 }
 
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch, float* out,
@@ -616,8 +617,8 @@ size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
   const Plan p = make_plan(width, y->frames, y->batch);
   const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)half_of(x->c_pitch), nb = 2 * (size_t)npad_of(x->channels);
   const size_t yf = (size_t)p.bins * p.rows_pad * nf, xf = (size_t)p.bins * p.rows_pad * nb, qf = (size_t)p.bins * ka * nf;
-  // [tail area of the per-bin products (counters + partial tiles, st_common.h) | spectra of the call's output]
-  return (st::TAIL_WS_FLOATS + std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
+  // [stream-K area of the per-bin products (control words + partial tiles, st_common.h) | spectra of the call's output]
+  return (st::SK_WS_FLOATS + std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
 }
 
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
@@ -629,11 +630,11 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, y->frames, y->batch);
   const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
-  float* const tail = reinterpret_cast<float*>(workspace);
-  float* yf = tail + st::TAIL_WS_FLOATS;
+  float* const sk = reinterpret_cast<float*>(workspace);
+  float* yf = sk + st::SK_WS_FLOATS;
   launch_dft(*x, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), sf, s);
   if (int e = st::gemm_nn_batched(sf, ka, (long)p.rows_pad * ka, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka,
-                                  nf, p.bins, s, tail))
+                                  nf, p.bins, s, sk))
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
@@ -669,10 +670,10 @@ int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const 
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
   const int kz = 2 * npad_of(dz->channels), npi = npad_of(dx->channels), nb = 2 * npi;
-  float* const tail = reinterpret_cast<float*>(workspace);
-  float* xf = tail + st::TAIL_WS_FLOATS;
+  float* const sk = reinterpret_cast<float*>(workspace);
+  float* xf = sk + st::SK_WS_FLOATS;
   if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gbwd, (long)kz * nb, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
-                                  nb, p.bins, s, tail))
+                                  nb, p.bins, s, sk))
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
@@ -690,7 +691,7 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   const Plan p = make_plan(width, dz->frames, dz->batch);
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
-  float* qf = reinterpret_cast<float*>(workspace) + st::TAIL_WS_FLOATS;
+  float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
   // Q[bin] = Sf[bin]^T (2 half x rows_pad) * Zf[bin] (rows_pad x 2 npo): the reduction-major kernel of the W-tap filter
   // gradient takes both spectra as they are
   if (int e = st::gemm_tn_batched(sf, ka, (long)p.rows_pad * ka, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf,

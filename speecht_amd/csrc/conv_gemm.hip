@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "st_common.h"
+#include "streamk_map.h"
 
 namespace {
 
@@ -57,13 +58,6 @@ struct NNParams {
   int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
   int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
   long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
-  // Batched mode, K-split tail (see launch_nn): the bins beyond the last full set of 8 -- `batches % 8` of them -- would
-  // occupy only that many XCDs for a whole extra round.  Their tiles are cut into `tail_parts` slices of the reduction,
-  // all slices of a tile on ONE XCD; a slice stores its raw partial tile, the slice that arrives last (an atomic counter
-  // per tile, self-resetting) adds the partials in slice order -- the sum does not depend on who was last -- and stores C.
-  int tail_parts, tail_first_set, tail_chunk;
-  float* tail_slab;                  // [tile][part][BM][BN]
-  int* tail_count;                   // [tile], zero before and after every launch
 };
 
 // ------------------------------------------------------------------------------------
@@ -136,25 +130,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const float* __restrict__ Abase = p.A;
   const float* __restrict__ Bbase = p.Bm;
   float* __restrict__ Cbase = p.C;
-  int tail_part = 0, tail_tile = -1;               // K-split tail: which slice of which tail tile this workgroup is
   if (p.batches > 0) {
     // Batched mode: bin = 8 * set + xcd -- all tiles of one bin run on ONE XCD, whose L2 then holds that bin's
     // operands (a bin's filter matrix is 8 MB: spread over the XCDs every L2 would stream all of them).
     // Row tiles fastest, so the workgroups sharing a filter panel sit next to each other.
     const int per_bin = p.tiles_m * p.tiles_n;
-    int set = local / per_bin, t = local - set * per_bin;
-    int bin = set * 8 + xcd;
-    if (p.tail_parts > 1 && set >= p.tail_first_set) {
-      // the bins of the last, partial set: tile u of them (u = xcd + 8 j) lives on this XCD with all its slices
-      const int lt = local - p.tail_first_set * per_bin;
-      if (lt >= p.tail_chunk) return;
-      const int j = lt / p.tail_parts;
-      tail_part = lt - j * p.tail_parts;
-      tail_tile = xcd + 8 * j;
-      if (tail_tile >= (p.batches - 8 * p.tail_first_set) * per_bin) return;
-      bin = 8 * p.tail_first_set + tail_tile / per_bin;
-      t = tail_tile % per_bin;
-    }
+    const int set = local / per_bin, t = local - set * per_bin;
+    const int bin = set * 8 + xcd;
     if (bin >= p.batches) return;
     tile_n = t / p.tiles_m;
     tile_m = t - tile_n * p.tiles_m;
@@ -261,9 +243,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   const int chunks = (p.cp + BK - 1) / BK;
   const int nk_total = tap_inner ? chunks * p.taps : p.Kp / BK;
   // split-K: this workgroup reduces k-tiles [s0, s0 + nk) and writes a raw partial tile
-  // (a K-split tail tile of the batched mode reduces its slice, nk_total / tail_parts k-tiles)
-  const int s0 = tail_tile >= 0 ? tail_part * (nk_total / p.tail_parts) : (p.splits > 1 ? blockIdx.y * p.steps_per_split : 0);
-  const int nk = tail_tile >= 0 ? nk_total / p.tail_parts : (p.splits > 1 ? min(p.steps_per_split, nk_total - s0) : nk_total);
+  const int s0 = p.splits > 1 ? blockIdx.y * p.steps_per_split : 0;
+  const int nk = p.splits > 1 ? min(p.steps_per_split, nk_total - s0) : nk_total;
   int tap = tap_inner ? s0 % p.taps : 0;          // position of the tile being COMPUTED
   int chunk = tap_inner ? s0 / p.taps : s0;
   auto tile_k0 = [&](int t, int c) { return tap_inner ? t * p.cp + c * BK : c * BK; };
@@ -374,51 +355,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
       }
     return;
   }
-  if constexpr (NT == 2) {
-  if (tail_tile >= 0) {
-    // K-split tail tile.  The hand-off between the slices follows MI355X_MICROARCH.md's price list: the partial goes out
-    // with write-through (sc1) stores, drained by this wave's own vmcnt wait -- no release fence (an agent-scope release
-    // writes back the whole L2's dirty lines, and this kernel keeps tens of MB dirty: measured +60 us per launch) -- then one
-    // returning atomic per workgroup on the tile's arrival counter; the slice that arrives last reads the others' partials
-    // with sc1 loads (past its L1) and adds them in slice order.
-    typedef unsigned long long u64;
-    float* const mine = p.tail_slab + ((long)tail_tile * p.tail_parts + tail_part) * (BM * BN);
-    const int tcol = wn * WTN + NT * l31;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const u64 bits = (u64)__float_as_uint(acc[i][0][r]) | ((u64)__float_as_uint(acc[i][1][r]) << 32);
-        __hip_atomic_store(reinterpret_cast<u64*>(mine + row * BN + tcol), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* const flag = reinterpret_cast<int*>(a_off);                     // (the row-offset table is no longer needed)
-    if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tail_count + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.tail_parts - 1;
-    __syncthreads();
-    if (!flag[0]) {
-        return;
-    }
-    const float* const base = p.tail_slab + (long)tail_tile * p.tail_parts * (BM * BN);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float s0 = 0.f, s1 = 0.f;
-        for (int q = 0; q < p.tail_parts; ++q) {                               // slice 0, 1, 2, ...: a fixed order
-          const u64 bits = __hip_atomic_load(reinterpret_cast<const u64*>(base + (long)q * (BM * BN) + row * BN + tcol),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const float v0 = __uint_as_float((unsigned)bits), v1 = __uint_as_float((unsigned)(bits >> 32));
-          s0 = q == 0 ? v0 : s0 + v0;
-          s1 = q == 0 ? v1 : s1 + v1;
-        }
-        acc[i][0][r] = s0;
-        acc[i][1][r] = s1;
-      }
-  }
-  }
   const bool col_ok = col0 < p.n_store;          // n_store is a multiple of 16: all NT columns in or out
   float csum[NT];                                // EPI 1 + p.colsum: this lane's share of the column sums
 #pragma unroll
@@ -469,6 +405,254 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) vset<NT>(out, n, csum[n] + __shfl_xor(csum[n], 32, 64));
     if (h == 0) *reinterpret_cast<bvec*>(p.colsum + (long)(tile_m * WMW + wm) * p.Np + col0) = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-bin products of the frequency-domain layers as ONE persistent launch ("stream-K"): `bins` independent GEMMs
+// C[b] = A[b] * B[b] of a shape whose tile count does not fill whole rounds of the chip -- the seven 7-tap layers:
+// 36 bins x 16 tiles of 64 x 128 = 576 workgroups on 512 slots, the fullest CU runs three tiles for 2.25 tiles of work
+// (measured rounds 2-3: 32 bins 46 us, 36 bins 65 us; a K-split of the last bins only, round 3, bought nothing because its
+// slices started when the full tiles left).  Here the (bin, tile, k-tile) unit list is dealt from t = 0 in equal contiguous
+// runs to 8 x 64 workgroups (csrc/streamk_map.h): every workgroup walks 18 k-tiles -- the end of one tile, whole tiles, the
+// start of the next.  A tile cut in two is finished by the workgroup that holds its START (its last piece, computed late):
+// the workgroup holding the END computed it first thing and published it long before.  Hand-off per MI355X_MICROARCH.md
+// (R1: write-through `sc1` payload, every storing wave drains `vmcnt`, one relaxed agent-scope flag; the reader polls that one
+// word and reads the payload with `sc1` loads) -- placement-independent; the sum is head + tail, a fixed order.
+// Which run a workgroup takes is decided by a dequeue on its label's head word (blockIdx.x % 8), not by blockIdx: the run a
+// workgroup waits for then belongs to a workgroup that has started or will start as soon as ANY slot frees up, whatever
+// order the dispatcher uses (with a static map an out-of-order dispatch could park every resident workgroup on an unstarted
+// one).  Control words are self-resetting: zero before the first call, zero after every call (st_gemm_nn_batched_ws_f32).
+// Inner loop: the FAST stage of gemm_nn_kernel (whole k-tiles, LDS-DMA with source-side XOR swizzle, DMA slices between
+// MFMA quads); no row-offset tables (rows are plain multiples of lda).
+// ------------------------------------------------------------------------------------
+struct BinsParams {
+  const float* A; const float* B; float* C;
+  long lda, ldb, ldc, a_batch, b_batch, c_batch;
+  int tiles_m, tiles_n;               // per bin
+  st::SkPlan plan;
+  unsigned* ctrl;                     // st::SK_CTRL_WORDS control words (heads, flags, timeout count)
+  float* partial;                     // [8 * wgs_per_xcd][BM * BN]
+};
+
+template <int BM, int BN, int WMW, int WNW>
+__global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_DMA = BM / 32, B_DMA = BN / 32, B_LPR = BN / 4;
+  constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
+  constexpr int N_DMA = A_DMA + B_DMA;
+  static_assert(WMW * WNW == 4 && MT >= 1 && NT == 2 && A_DMA >= 1 && B_DMA >= 1, "tile config");
+  typedef typename FVec<NT>::type bvec;
+  typedef unsigned long long u64;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ + 4];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_SZ;
+  int* const bcast = reinterpret_cast<int*>(smem + 2 * A_SZ + 2 * B_SZ);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  // which run: a dequeue on this label's head word; the last puller of the launch puts the word back to zero
+  const int xcd = blockIdx.x & 7;
+  if (tid == 0) {
+    unsigned* head = p.ctrl + xcd * st::SK_HEAD_STRIDE;
+    const unsigned got = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)got == p.plan.wgs_per_xcd - 1) __hip_atomic_store(head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bcast[0] = (int)got;
+  }
+  __syncthreads();
+  const int local = __builtin_amdgcn_readfirstlane(bcast[0]);
+  const int slot = local * 8 + xcd;                          // this workgroup's partial tile and flag
+  st::SkCursor cur;
+  if (local >= p.plan.wgs_per_xcd || !st::sk_begin(p.plan, xcd, local, cur)) return;
+  const int per_bin = p.tiles_m * p.tiles_n;
+
+  // lane-constant parts of the DMA sources (see gemm_nn_kernel): A instruction i of this wave covers rows
+  // (wave * A_DMA + i) * 8 .. +8, lane -> (row, swizzled 16-byte slot); B instruction i covers 64 / B_LPR rows of k
+  long a_lane[A_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) {
+    const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
+    a_lane[i] = (long)row * p.lda + (((lane & 7) ^ ((row >> 1) & 7))) * 4;
+  }
+  long b_lane[B_DMA];
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i)
+    b_lane[i] = (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.ldb + (lane % B_LPR) * 4;
+  int a_frag[4];
+  {
+    const int row = wm * WTM + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
+  const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
+  const int tcol = wn * WTN + NT * l31;                      // this lane's first column inside the tile
+
+  while (cur.u < cur.u_end) {
+    const st::SkPiece pc = st::sk_piece(p.plan, cur);
+    cur.u += pc.kt1 - pc.kt0;
+    const int bin = pc.tile / per_bin, t = pc.tile - bin * per_bin;
+    const int tile_n = t / p.tiles_m, tile_m = t - tile_n * p.tiles_m;   // row tiles fastest: neighbours share a filter panel
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* __restrict__ Ab = p.A + (long)bin * p.a_batch + (long)m0 * p.lda;
+    const float* __restrict__ Bb = p.B + (long)bin * p.b_batch + n0;
+    const float* aptr[A_DMA];
+    const float* bptr[B_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) aptr[i] = Ab + a_lane[i];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) bptr[i] = Bb + b_lane[i];
+    auto dma_piece = [&](int pcx, int k0, int buf) {
+      if (pcx < A_DMA) {
+        const int i = pcx < A_DMA ? pcx : 0;
+        __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + k0), (lptr_t)(As + buf * A_SZ + (wave * A_DMA + i) * 256), 16, 0, 0);
+      } else {
+        const int i = pcx - A_DMA < B_DMA ? pcx - A_DMA : 0;
+        __builtin_amdgcn_global_load_lds((gptr_t)(bptr[i] + (long)k0 * p.ldb), (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
+      }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int k0 = pc.kt0 * BK;                                    // reduction index of the tile being COMPUTED
+#pragma unroll
+    for (int pcx = 0; pcx < N_DMA; ++pcx) dma_piece(pcx, k0, 0);
+    __syncthreads();                                         // (drains the DMA; the previous piece's stores too)
+
+    auto stage = [&](auto cur_c, auto more_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      constexpr bool MORE = decltype(more_c)::value;
+      const int nk0 = k0 + BK;
+      k0 = nk0;
+      const float* as = As + CUR * A_SZ;
+      const float* bs = Bs + CUR * B_SZ + b_frag;
+      f32x4 af[4][MT];
+      bvec bf[4][4];
+      auto read_frags = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + a_frag[q] + i * 32 * BK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+      };
+      read_frags(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (MORE) {
+#pragma unroll
+          for (int pcx = q; pcx < N_DMA; pcx += 4) dma_piece(pcx, nk0, CUR ^ 1);
+        }
+        if (q < 3) read_frags(q + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    using std::integral_constant;
+    using std::true_type;
+    using std::false_type;
+    const int nk = pc.kt1 - pc.kt0;
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+      stage(integral_constant<int, 0>{}, true_type{});
+      stage(integral_constant<int, 1>{}, true_type{});
+    }
+    if (kt + 2 == nk) {
+      stage(integral_constant<int, 0>{}, true_type{});
+      stage(integral_constant<int, 1>{}, false_type{});
+    } else if (kt + 1 == nk) {
+      stage(integral_constant<int, 0>{}, false_type{});
+    }
+
+    if (pc.kt0 > 0) {
+      // TAIL piece [kt0, nk): publish the partial tile (write-through stores, drained by every storing wave), then the flag
+      float* const mine = p.partial + (long)slot * (BM * BN);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const u64 bits = (u64)__float_as_uint(acc[i][0][r]) | ((u64)__float_as_uint(acc[i][1][r]) << 32);
+          __hip_atomic_store(reinterpret_cast<u64*>(mine + row * BN + tcol), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.ctrl + st::SK_FLAGS + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (pc.kt1 < p.plan.nk) {
+      // HEAD piece [0, kt1): the rest of the tile is the first piece of the next run of this label (slot + 8), computed at
+      // the start of the launch.  One lane polls (bounded: a lost producer must not hang the GPU), takes the flag back.
+      if (tid == 0) {
+        unsigned* flag = p.ctrl + st::SK_FLAGS + slot + 8;
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 21)) {
+            __hip_atomic_fetch_add(p.ctrl + st::SK_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const float* const theirs = p.partial + (long)(slot + 8) * (BM * BN);
+      u64 part[MT][16];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          part[i][r] = __hip_atomic_load(reinterpret_cast<const u64*>(theirs + row * BN + tcol), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][0][r] += __uint_as_float((unsigned)part[i][r]);
+          acc[i][1][r] += __uint_as_float((unsigned)(part[i][r] >> 32));
+        }
+    }
+    float* __restrict__ Cb = p.C + (long)bin * p.c_batch + (long)m0 * p.ldc + n0 + tcol;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        bvec out;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
+        *reinterpret_cast<bvec*>(Cb + (long)row * p.ldc) = out;
+      }
   }
 }
 
@@ -892,42 +1076,12 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
     p.chunk = p.tm_per * p.tn_per;
   }
   p.colsum_rows = p.tiles_m * WMW;
-  if (p.batches > 0) {
-    const int per_bin = p.tiles_m * p.tiles_n, full_sets = p.batches / 8, rest = p.batches % 8;
-    p.chunk = st::ceil_div(p.batches, 8) * per_bin;
-    // K-split tail (NNParams): 36 bins x 16 tiles = 576 workgroups on 256 CUs cost three rounds for 2.25 rounds of work --
-    // bins 32..35 run on four XCDs while the other four idle (measured round 2: 32 bins 46 us, 36 bins 65 us).  Their 64
-    // tiles become 256 quarter-reduction slices, one per CU.
-    p.tail_parts = 1;
-    const int nk_total = p.Kp / BK, tail_tiles = rest * per_bin;
-    float* const ws = p.tail_slab;                 // caller's tail area (may be null): [256 counters | slab]
-    p.tail_slab = nullptr;
-    // MEASURED (round 3) AND OFF BY DEFAULT: isolated forward product 65 -> 65 us, training step 7.28 -> 7.37 ms.  The 256
-    // slices start only when the full tiles leave (two workgroups per CU are resident from t = 0), each then runs alone on
-    // its CU for a quarter of a reduction plus the hand-off (write-through partial, counter, the last slice's re-read), and
-    // the per-call counter memset is one more stream operation: together as long as the idle half-round they replace.
-    // st_set_tuning("tail_split", 1) turns it on (tests/test_gpu_fft_conv.py keeps it correct).
-    if (ws && BM == 64 && BN == 128 && rest > 0 && p.taps == 1 && p.splits <= 1 && tail_tiles <= 128 &&
-        st::tuning(st::TUNE_TAIL_SPLIT) == 1) {
-      int parts = 1;
-      for (int c : {8, 6, 4, 3, 2})
-        if (nk_total % c == 0 && nk_total / c >= 3 && tail_tiles * c <= 256 && (long)tail_tiles * c * BM * BN <= st::TAIL_SLAB_FLOATS) { parts = c; break; }
-      // the arrival counters, zeroed on the stream every call (a caller's workspace is not to be trusted with that)
-      if (parts > 1 && hipMemsetAsync(ws, 0, (size_t)tail_tiles * sizeof(int), s) == hipSuccess) {
-        p.tail_parts = parts;
-        p.tail_first_set = full_sets;
-        p.tail_chunk = st::ceil_div(tail_tiles, 8) * parts;
-        p.tail_count = reinterpret_cast<int*>(ws);
-        p.tail_slab = ws + st::TAIL_COUNT_FLOATS;
-        p.chunk = full_sets * per_bin + p.tail_chunk;
-      }
-    }
-  }
+  if (p.batches > 0) p.chunk = st::ceil_div(p.batches, 8) * p.tiles_m * p.tiles_n;
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   const double gflop = 2e-9 * p.tiles_m * BM * (double)p.Np * p.Kp * std::max(1, p.batches);      // executed, padding included
   if (p.batches > 0)
-    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d tail=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
-              p.batches, p.M, p.Np, p.Kp, p.tail_parts, gflop);
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
+              p.batches, p.M, p.Np, p.Kp, gflop);
   else
     st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d gflop=%.3f", BM, BN, WMW, WNW,
               FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
@@ -973,11 +1127,41 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
 
 // Plain batched C[b] = A[b] * B[b] (row-major fp32, no epilogue) on the convolution GEMM kernel: A [M][lda] with
 // K <= lda readable floats per row, B [K][N] with N a multiple of 128, C [M][ldc]; K a multiple of 32.
+// With a workspace (st::SK_WS_FLOATS floats, control words zero) a launch whose 64 x 128 tiles would leave the last round of
+// workgroups ragged runs as the persistent stream-K kernel instead (gemm_nn_bins_kernel).
 int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc,
-                        long c_batch, int M, int K, int N, int batches, hipStream_t s, float* tail_ws) {
+                        long c_batch, int M, int K, int N, int batches, hipStream_t s, float* sk_ws) {
   if (!(A && B && C && M > 0 && K > 0 && K % 32 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldc % 4 == 0)) {
     st::set_error("gemm_nn_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
+  }
+  // stream-K policy: tiles of 64 x 128 against the 512 workgroup slots the plain launch fills round by round.  Worth it when
+  // the last round is ragged (36 bins x 16 tiles: 576 = 1.125 rounds -> 0.56 of two rounds' slots; the first layer's 720;
+  // the 32-tap layer's back-prop 768); a launch of whole rounds (32-tap forward: 3 072 tiles of 128 x 128) stays as it is.
+  // st_set_tuning("streamk", 1) forces it wherever the shape allows, 2 turns it off.
+  const int knob = st::tuning(st::TUNE_STREAMK);
+  if (sk_ws && knob != 2 && M % 64 == 0 && a_batch % 4 == 0 && b_batch % 4 == 0) {
+    const long tiles = (long)batches * (M / 64) * (N / 128);
+    const long tiles128 = (long)st::ceil_div(M, 128) * (N / 128) * batches;
+    const double fill = (double)tiles / (double)(st::ceil_div((int)tiles, 512) * 512L);
+    st::SkPlan plan;
+    if ((knob == 1 || (tiles128 < 512 && tiles >= 128 && fill < 0.9)) && tiles < (1L << 24) && st::sk_make_plan((int)tiles, K / BK, plan)) {
+      BinsParams q{};
+      q.A = A; q.B = B; q.C = C;
+      q.lda = lda; q.ldb = N; q.ldc = ldc;
+      q.a_batch = a_batch; q.b_batch = b_batch; q.c_batch = c_batch;
+      q.tiles_m = M / 64; q.tiles_n = N / 128;
+      q.plan = plan;
+      q.ctrl = reinterpret_cast<unsigned*>(sk_ws);
+      q.partial = sk_ws + st::SK_CTRL_WORDS;
+      st::trace("gemm_nn_bins<64,128,2,2> batched bins=%d M=%d Np=%d Kp=%d streamk wgs=%d upw=%d gflop=%.3f", batches, M, N, K,
+                8 * plan.wgs_per_xcd, plan.upw, 2e-9 * M * (double)N * K * batches);
+      {
+        st::LaunchTimer timer(s);
+        st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
+      }
+      return st::check_launch("gemm_nn_bins");
+    }
   }
   NNParams p{};
   p.A = A;
@@ -994,7 +1178,6 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
   p.cp = K;
   p.batches = batches;
   p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
-  p.tail_slab = tail_ws;                         // (launch_nn decides whether the tail of the bin list is K-split)
   return run_nn(p, 0, s);
 }
 

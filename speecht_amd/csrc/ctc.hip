@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __rest
 
 // One wave per (utterance, direction).  blockIdx.y: 0 = alpha, 1 = beta.
 // Storage is lane-major, one (mantissa, exponent bits) record of 8 bytes per state: state u = lane*KPL + j at frame t is
-// record (t*KPL + j)*64 + lane.  A state no path reaches has mantissa 0; its exponent is then meaningless but stays far
-// below every live one (it starts at EZ and moves by one emission exponent per frame), so it never wins the alignment.
+// record (t*KPL + j)*64 + lane.  A state no path reaches has mantissa 0 and exponent EZ, far below every live one, so it
+// never wins the alignment.
 // States u >= U: beta's stay 0 by themselves (they only receive from states above them), alpha's hold numbers nobody reads.
 template <int KPL>
 __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ emis, int T, int C,
@@ -212,8 +212,11 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       const float sum = aligned_sum3(am[j], ae[j], bm_[j], be_[j], cm[j], skip[j] ? ce[j] : EZ, big);   // (2^(EZ - big) = 0)
       if (sum_m) { sum_m[j] = sum; sum_e[j] = big; }
       const float v = sum * em[j][0];
-      nm[j] = __builtin_amdgcn_frexp_mantf(v);                     // v = 0 stays (0, ...): see the kernel's header
-      ne[j] = big + ibits(em[j][1]) + __builtin_amdgcn_frexp_expf(v);
+      nm[j] = __builtin_amdgcn_frexp_mantf(v);
+      // a state without a path (all predecessors zero, or a dead emission: a logit of -inf) goes back to EZ: a zero
+      // mantissa under a live-scale exponent would win the next alignment and flush live neighbours more than 126 binades
+      // below it (round 3 kept `big + ...` here: harmless for finite logits, wrong for masked classes)
+      ne[j] = v > 0.f ? big + ibits(em[j][1]) + __builtin_amdgcn_frexp_expf(v) : EZ;
     }
 #pragma unroll
     for (int j = 0; j < KPL; ++j) { om[j] = nm[j]; oe[j] = ne[j]; }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       for (int j = 0; j < KPL; ++j) {
         const f32x2 q = *reinterpret_cast<const f32x2*>(e + coff[j]);
         sm[j] *= 0.5f * q[0];                  // stays in [0.5, 1) (or 0)
-        se[j] += ibits(q[1]) + 1;
+        se[j] = sm[j] > 0.f ? se[j] + ibits(q[1]) + 1 : EZ;
       }
     }
     auto frame = [&](int t, const float* e) {
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        const int* __restrict__ seq_lens,
                                                        const int* __restrict__ status, float scale,
                                                        float* __restrict__ grad, RowMap2 gmap, int gcols,
-                                                       float* __restrict__ loss, int lmax) {
+                                                       float* __restrict__ loss, float* __restrict__ loss_lo, int lmax) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   int* pos_off = smem;                 // [32]
   int* pos_list = smem + 32;           // [lmax]
@@ -368,7 +371,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const float sum = aligned_sum3(a1[0], ibits(a1[1]), a2[0], ibits(a2[1]), 0.f, EZ, pe);
     logp2 = sum > 0.f ? (double)pe + log2((double)sum) : -__builtin_inf();
   }
-  if (blockIdx.x == 0 && tid == 0) loss[b] = bad ? __builtin_inff() : (float)(-logp2 * (double)LN2);
+  if (blockIdx.x == 0 && tid == 0) {
+    // -log p is known here far better than a float of its magnitude can hold (the lattice rounds 6e-8 RELATIVE per step; one
+    // fp32 ulp of a loss of 1 239 is 1.2e-4): the double goes out as a (hi, lo) float pair, hi = the fp32 loss TF would return
+    const double nll = -logp2 * 0.69314718055994530942;
+    const float hi = bad ? __builtin_inff() : (float)nll;
+    loss[b] = hi;
+    if (loss_lo) loss_lo[b] = (bad || !(hi < __builtin_inff())) ? 0.f : (float)(nll - (double)hi);
+  }
 
   float* wb = wbuf + wave * lmax;
   for (int k = 0; k < GF / 4; ++k) {
@@ -508,6 +518,14 @@ int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, con
                          const int32_t* seq_lens, int max_label_len, float grad_scale, float* loss,
                          const st_tensor3* grad, int32_t* status, void* workspace, size_t workspace_bytes,
                          void* stream) {
+  return st_ctc_loss_grad_hilo_f32(logits, label_ids, label_offsets, seq_lens, max_label_len, grad_scale, loss, nullptr, grad, status,
+                                   workspace, workspace_bytes, stream);
+}
+
+int st_ctc_loss_grad_hilo_f32(const st_tensor3* logits, const int32_t* label_ids, const int32_t* label_offsets,
+                              const int32_t* seq_lens, int max_label_len, float grad_scale, float* loss, float* loss_lo,
+                              const st_tensor3* grad, int32_t* status, void* workspace, size_t workspace_bytes,
+                              void* stream) {
   ST_REQUIRE(logits && logits->base && grad && grad->base && label_ids && label_offsets && seq_lens && loss &&
                  status && workspace, "ctc: null argument");
   ST_REQUIRE(logits->channels >= 2 && logits->channels <= CP && logits->c_pitch >= CP && logits->c_pitch % 4 == 0,
@@ -537,7 +555,7 @@ int st_ctc_loss_grad_f32(const st_tensor3* logits, const int32_t* label_ids, con
   switch (kpl) {
 #define ST_GR(K) case K: hipLaunchKernelGGL(ctc_grad_kernel<K>, dim3(st::ceil_div(T, GF), B), dim3(256), shm, s, logy, alpha, beta, \
                                             T, C, label_ids, label_offsets, seq_lens, status, grad_scale, grad->base,            \
-                                            make_map2(*grad), std::min(grad->c_pitch, CP), loss, lmax); break;
+                                            make_map2(*grad), std::min(grad->c_pitch, CP), loss, loss_lo, lmax); break;
     ST_GR(1) ST_GR(2) ST_GR(3) ST_GR(4) ST_GR(5) ST_GR(6) ST_GR(8) ST_GR(10) ST_GR(12) ST_GR(16)
 #undef ST_GR
   }

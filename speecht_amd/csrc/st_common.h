@@ -30,21 +30,26 @@ class LaunchTimer {
  private:
   hipEvent_t start_, stop_;
 };
-template <typename... Args, typename F = void (*)(Args...)>
-inline void launch_timed(const LaunchTimer& t, F kernel, const dim3& grid, const dim3& block, hipStream_t s, Args... args) {
-  if (t.active()) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, t.start(), t.stop(), 0, args...);
-  else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+// (the arguments are converted to the kernel's own parameter types here: hipExtLaunchKernelGGL packs what it is given)
+template <typename... KArgs, typename... Args>
+inline void launch_timed(const LaunchTimer& t, void (*kernel)(KArgs...), const dim3& grid, const dim3& block, hipStream_t s,
+                         Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "launch_timed: argument count does not match the kernel");
+  if (t.active()) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, t.start(), t.stop(), 0, static_cast<KArgs>(args)...);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, s, static_cast<KArgs>(args)...);
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_TAIL_SPLIT, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
-// tail_ws: optional TAIL_WS_FLOATS floats of scratch (arrival counters, zeroed on the stream per call, + partial tiles):
-// lets the launch cut the tiles of the last, partial set of 8 bins into reduction slices (conv_gemm.hip, NNParams)
-constexpr long TAIL_COUNT_FLOATS = 256, TAIL_SLAB_FLOATS = 256L * 64 * 128, TAIL_WS_FLOATS = TAIL_COUNT_FLOATS + TAIL_SLAB_FLOATS;
+// sk_ws: optional SK_WS_FLOATS floats of scratch for the persistent stream-K form of a ragged launch (conv_gemm.hip,
+// gemm_nn_bins_kernel): [control words: 8 head words 32 words apart | 512 flags | timeout count] then 512 partial tiles of
+// 64 x 128.  The control words must be ZERO before the first call; every call leaves them zero (self-resetting).
+constexpr int SK_HEAD_STRIDE = 32, SK_FLAGS = 256, SK_TIMEOUTS = SK_FLAGS + 512, SK_CTRL_WORDS = 1024;
+constexpr long SK_WS_FLOATS = SK_CTRL_WORDS + 512L * 64 * 128;
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,
-                    int M, int K, int N, int batches, hipStream_t s, float* tail_ws = nullptr);
+                    int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr);
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
                     int M, int K, int N, int batches, hipStream_t s);
 

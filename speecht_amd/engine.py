@@ -333,7 +333,11 @@ class Wav2LetterEngine:
     if self._side_wgrad_top:
       ws_top = lib.st_conv1d_bwd_filter_ws(self.X[top].ref, self.dZ[top].ref, self.layers[top].width)
       self.wgrad_ws_top, _ = self._storage.view('wgrad_ws_top', ws_top // 4 + 64)
-    self.loss = self._storage.view('loss', batch)[0][:batch]
+    # per-utterance CTC losses as (hi, lo) float pairs: `loss` is the fp32 value (what tf.nn.ctc_loss returns), `loss_lo` what
+    # fp32 cannot hold of -log p at that magnitude (st_ctc_loss_grad_hilo_f32); one buffer, so one copy brings both back
+    loss_buf = self._storage.view('loss', 2 * batch)[0]
+    self.loss_pair = loss_buf[:2 * batch]
+    self.loss, self.loss_lo = loss_buf[:batch], loss_buf[batch:2 * batch]
     self.ctc_status = self._storage.view('ctc_status', batch, torch.int32)[0][:batch]
     self.dec_ids = self._storage.view('dec_ids', batch * self.t_out, torch.int32)[0][:batch * self.t_out]
     self.dec_lens = self._storage.view('dec_lens', batch, torch.int32)[0][:batch]
@@ -695,25 +699,40 @@ class Wav2LetterEngine:
     if not hasattr(self, '_h2d'):
       self._h2d = dict(stream=torch.cuda.Stream(self.device), slots=[None, None], turn=0)
     h = self._h2d
-    h['turn'] ^= 1
     x = torch.as_tensor(x_host)
     if x.dtype != torch.float32:
       x = x.to(torch.float32)
-    slot = h['slots'][h['turn']]
-    if slot is not None and not slot.taken:
-      # two staging buffers: a third batch staged before the first was handed to load_batch would overwrite it
-      raise RuntimeError('stage_host_batch: both staging buffers hold batches that load_batch has not consumed yet')
+    # the slot whose turn it is, else the other one if that is free: the turn only moves once a slot is really taken, so a
+    # refused call (both busy) leaves the state as it was and the next call succeeds as soon as either batch is consumed
+    turn = h['turn'] ^ 1
+    for cand in (turn, turn ^ 1):
+      slot = h['slots'][cand]
+      if slot is None or slot.taken:
+        turn = cand
+        break
+    else:
+      # two staging buffers: a third batch staged before either was handed to load_batch would overwrite one
+      raise RuntimeError('stage_host_batch: both staging buffers hold batches that load_batch has not consumed yet '
+                         '(discard_staged_batch(handle) releases one that will not be used)')
+    h['turn'] = turn
     if slot is None or slot.tensor.shape != x.shape:
       if slot is not None:
         slot.consumed.synchronize()
       slot = _StagedHostBatch(torch.empty(x.shape, dtype=torch.float32, device=self.device))
-      h['slots'][h['turn']] = slot
+      h['slots'][turn] = slot
     slot.taken = False
     with torch.cuda.stream(h['stream']):
       h['stream'].wait_event(slot.consumed)            # the compute stream is done reading this buffer
       slot.tensor.copy_(x, non_blocking=True)
       slot.event.record(h['stream'])
     return slot
+
+  def discard_staged_batch(self, staged):
+    """Release a staged batch that will not be handed to ``load_batch`` (end of an epoch, an exception in the feeder): its
+    staging buffer becomes free for the next ``stage_host_batch`` once the copy into it has finished."""
+    if not staged.taken:
+      staged.taken = True
+      staged.consumed.record(self._h2d['stream'])      # "consumed" right behind the copy on the copy stream
 
   def _upload_i32(self, values):
     """Small int32 host array -> device through a ring of pinned slots.  A hipMemcpyAsync from pageable memory
@@ -905,8 +924,8 @@ class Wav2LetterEngine:
     elif not self._packed_t_fresh or (self.fft and not self._gbwd_fresh):
       self._on_side_stream(self._refresh_backward_operands)
     self._wait_uploads()
-    call('st_ctc_loss_grad_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
-         self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self.dZ[-1].ref,
+    call('st_ctc_loss_grad_hilo_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
+         self._ptr(self.ctc_lens), self.max_label_len, float(grad_scale), self._ptr(self.loss), self._ptr(self.loss_lo), self.dZ[-1].ref,
          self._ptr(self.ctc_status), self._ptr(self.ctc_ws), self.ctc_ws.numel() * 4, self.stream_ptr)
     if getattr(self, '_rejected_labels', None):            # labels refused on the host (deferred mode): status 2
       stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
@@ -1136,18 +1155,20 @@ class Wav2LetterEngine:
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
     return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
 
-  def fetch_losses(self):
+  def fetch_losses(self, precise=False):
     """Per-utterance CTC losses [B] on the host, after checking the status words: both arrays come back in one
-    pinned, asynchronous copy each and a single event wait (a step's only host synchronisation)."""
+    pinned, asynchronous copy each and a single event wait (a step's only host synchronisation).  float32 like
+    tf.nn.ctc_loss; ``precise=True`` returns float64 = hi + lo of the kernel's (hi, lo) pairs (-log p to ~1e-6 where one
+    fp32 ulp of a 10 s utterance's loss is 1.2e-4)."""
     B = self.loss.numel()
-    if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < B:
-      self._loss_host = (torch.empty(max(B, 64), dtype=torch.float32, pin_memory=True),
+    if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < 2 * B:
+      self._loss_host = (torch.empty(max(2 * B, 128), dtype=torch.float32, pin_memory=True),
                          torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True), torch.cuda.Event(),
                          torch.empty(16, dtype=torch.float32, pin_memory=True))
     loss_h, status_h, event, gate_h = self._loss_host
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     with torch.cuda.stream(stream):
-      loss_h[:B].copy_(self.loss, non_blocking=True)
+      loss_h[:2 * B].copy_(self.loss_pair, non_blocking=True)
       status_h[:B].copy_(self.ctc_status, non_blocking=True)
       gate_h[:1].copy_(self.gate, non_blocking=True)
       event.record(stream)
@@ -1166,7 +1187,16 @@ class Wav2LetterEngine:
         raise ValueError('Not enough time for target transition sequence (utterances {})'.format(np.nonzero(st)[0].tolist()))
       raise ValueError('batch rejected: {:g} utterance(s) on other ranks had no valid CTC alignment or out-of-range label ids'
                        .format(float(gate_h[0])))
-    return loss_h[:B].numpy().copy()
+    pair = loss_h[:2 * B].numpy()
+    if precise:
+      return pair[:B].astype(np.float64) + pair[B:].astype(np.float64)
+    return pair[:B].copy()
+
+  def losses_precise(self):
+    """float64 losses (hi + lo) straight from the device buffers, no status check (tests, bench parity)."""
+    pair = self.loss_pair.cpu().numpy().astype(np.float64)
+    B = self.loss.numel()
+    return pair[:B] + pair[B:]
 
   def check_ctc_status(self):
     st = self.ctc_status.cpu().numpy()

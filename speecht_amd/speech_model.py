@@ -366,7 +366,7 @@ class SpeechModel:
         eng.apply_update(self.learning_rate.value, self.max_gradient_norm)   # no-op on the device if CTC rejected the batch
       # raises on a CTC status word (of any rank) -- before global_step moves: like TF's failed sess.run, a rejected
       # batch leaves weights, Adam state and counters as they were
-      avg_loss = np.float32(eng.fetch_losses().mean(dtype=np.float32))
+      avg_loss = np.float32(eng.fetch_losses(precise=True).mean())     # mean of -log p in float64, returned as TF's float32
       if update:
         self.global_step.value += 1
       if self._world > 1:

@@ -408,6 +408,30 @@ def test_input_pipeline_stages_batches_on_the_device(dev, tmp_path):
   coord.request_stop()
 
 
+def test_staging_buffers_refuse_a_third_batch_and_recover(dev):
+  """engine.stage_host_batch: two staging buffers; a third batch before either is consumed is refused WITHOUT
+  moving the turn, so the next call succeeds as soon as one is consumed, whichever; an abandoned batch can be released."""
+  from speecht_amd.engine import Wav2LetterEngine
+  eng = Wav2LetterEngine(WL.w2l_layers(16, width=24, fc=40), device=dev)
+  eng.init_xavier(1)
+  xs = [np.full((2, 40, 16), float(k), dtype=np.float32) for k in range(5)]
+  a, b = eng.stage_host_batch(xs[0]), eng.stage_host_batch(xs[1])
+  for _ in range(2):
+    with pytest.raises(RuntimeError, match='both staging buffers'):
+      eng.stage_host_batch(xs[2])
+  eng.load_batch(b, [40, 40])                                  # the NEWER one is consumed first: its slot is the free one
+  assert float(eng.X[0].interior()[0, 0, 0]) == 1.0
+  c = eng.stage_host_batch(xs[2])
+  with pytest.raises(RuntimeError, match='both staging buffers'):
+    eng.stage_host_batch(xs[3])
+  eng.discard_staged_batch(a)                                  # abandoned: released without a load_batch
+  d = eng.stage_host_batch(xs[3])
+  eng.load_batch(c, [40, 40])
+  assert float(eng.X[0].interior()[1, 5, 3]) == 2.0
+  eng.load_batch(d, [40, 40])
+  assert float(eng.X[0].interior()[0, 0, 0]) == 3.0
+
+
 def test_tensorflow_checkpoint_bundle_round_trip(dev, tmp_path):
   """The reference's own checkpoint format (tf.train.Saver V2 bundles, speech_model.py:122,251-260): train a few
   steps, save as `speechT.ckpt-N.{index,data-00000-of-00001}` + TF's text `checkpoint` file with the reference's

@@ -71,7 +71,7 @@ def test_config2_bucketed_inference_at_full_size_matches_oracle():
     trace = '\n'.join(tr.lines)
     t_out = (max_t + 1) // 2
     rows = len(idx) * t_out
-    batched = lambda bins: sum(1 for l in tr.lines if l.startswith('gemm_nn<') and ' batched bins=%d ' % bins in l)
+    batched = lambda bins: sum(1 for l in tr.lines if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=%d ' % bins in l)
     # the policy of engine._use_fft: the 32-tap layer from 1 000 output rows, the 7-tap layers and the first layer from 3 000
     assert batched(48) == (1 if rows >= 1000 else 0), trace
     assert batched(36) == (7 if rows >= 3000 else 0), trace

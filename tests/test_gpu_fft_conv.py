@@ -251,49 +251,59 @@ def test_training_steps_agree_between_frequency_and_w_tap_kernels(dev):
 
 
 @pytest.mark.parametrize('bins,M,K,N', [(36, 256, 512, 512), (45, 256, 384, 512), (36, 128, 512, 512), (3, 256, 512, 512),
-                                       (48, 256, 512, 4096), (33, 256, 512, 512)])
-def test_batched_products_with_k_split_tail(dev, bins, M, K, N):
-  """st_gemm_nn_batched_ws_f32: the tiles of the bins beyond the last full set of 8 are cut into reduction slices that the
-  last-arriving slice sums in slice order (36 bins of the 7-tap layers: 4 slices; 45 bins of the first layer: 3) -- an
-  opt-in (st_set_tuning("tail_split", 1)): measured no faster than the idle half-round it fills, DESIGN 4.5.  Against
-  float64 matmul per bin, bit-identical across repetitions (no dependence on arrival order), counters left at zero, and
-  within fp32 rounding of the un-split launch (which sums the reduction in one chain)."""
+                                       (48, 256, 4096, 512), (48, 256, 512, 4096), (33, 256, 512, 512), (5, 64, 32, 128),
+                                       (37, 192, 96, 256)])
+def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N):
+  """st_gemm_nn_batched_ws_f32: a launch whose 64 x 128 tiles would leave the last round of workgroups ragged (36 bins of the
+  7-tap layers: 576 tiles on 512 slots; 45 bins of the first layer; the 32-tap layer's back-prop) runs as ONE persistent
+  launch that deals the (bin, tile, k-tile) list in equal runs (csrc/streamk_map.h); a tile cut in two is summed head + tail
+  by the workgroup holding its start.  Against float64 matmul per bin; bit-identical across repetitions -- also while another
+  stream keeps part of the chip busy (uneven load: the hand-off must not depend on who runs when) and with the reading CUs'
+  caches warm from the previous repetition; control words left at zero; within fp32 rounding of the plain launch."""
   from speecht_amd import _lib
   from speecht_amd._lib import call, launch_trace, set_tuning
   lib = _lib.load()
-  set_tuning('tail_split', 1)                     # measured slower than the idle half-round it fills: off by default
   rng = np.random.default_rng(bins * 1000 + K)
   A = torch.as_tensor(rng.standard_normal((bins, M, K)), dtype=torch.float32).to(dev)
   B = torch.as_tensor(rng.standard_normal((bins, K, N)) / np.sqrt(K), dtype=torch.float32).to(dev)
   P = lambda t: ctypes.c_void_p(t.data_ptr())
-  tail_bytes = lib.st_gemm_nn_batched_tail_ws()
-  tail = torch.full((tail_bytes // 4,), float('nan'), dtype=torch.float32, device=dev)        # scratch: any content
+  ws_bytes, ctrl_bytes = lib.st_gemm_nn_batched_ws_bytes(), lib.st_gemm_nn_batched_ctrl_bytes()
+  ws = torch.full((ws_bytes // 4,), float('nan'), dtype=torch.float32, device=dev)            # partial tiles: any content
+  ws[:ctrl_bytes // 4].zero_()                                                              # control words: zero before the first call
+  tiles = bins * (M // 64) * (N // 128)
+  ragged = tiles / (-(-tiles // 512) * 512) < 0.9 and tiles >= 128 and -(-M // 128) * (N // 128) * bins < 512
+  forced = not ragged and bins in (3, 5, 37)
+  if forced:
+    set_tuning('streamk', 1)
+  side = torch.cuda.Stream(dev)
+  busy = torch.randn(4096, 4096, device=dev)
   outs = []
-  for rep in range(3):
-    C = torch.full((bins, M, N), float('nan'), dtype=torch.float32, device=dev)
-    with launch_trace() as tr:
-      call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(tail), tail_bytes, None)
-    torch.cuda.synchronize()
-    outs.append(C)
-  set_tuning('tail_split', 0)
+  try:
+    for rep in range(4):
+      C = torch.full((bins, M, N), float('nan'), dtype=torch.float32, device=dev)
+      if rep >= 2:                                     # uneven load: a matmul of torch's on another stream takes CUs away
+        with torch.cuda.stream(side):
+          busy @ busy
+      with launch_trace() as tr:
+        call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(ws), ws_bytes, None)
+      torch.cuda.synchronize()
+      outs.append(C)
+  finally:
+    set_tuning('streamk', 0)
   line = tr.lines[0]
-  parts = int(line.split('tail=')[1].split()[0])
-  tiles128 = -(-M // 128) * (N // 128) * bins
-  if bins % 8 and tiles128 < 512:
-    assert parts > 1, line                                                        # the narrow products really split their tail
-  if bins == 36 and M == 256 and N == 512:
-    assert parts == 4 and 'gemm_nn<64,128,2,2,fast>' in line, line
-  if bins == 45:
-    assert parts == 3, line
-  if bins == 48:
-    assert parts == 1, line                                                       # six full sets: nothing to split
-  assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+  if ragged or forced:
+    assert line.startswith('gemm_nn_bins<64,128,2,2> batched') and ' streamk ' in line, line
+  else:
+    assert line.startswith('gemm_nn<'), line                     # whole rounds (the 32-tap layer's forward products): the plain launch
+  if bins == 36 and M == 256 and N == 512 and K == 512:
+    assert 'wgs=512 upw=18' in line, line
+  for o in outs[1:]:
+    assert torch.equal(outs[0], o)
+  assert int(ws[:ctrl_bytes // 4].view(torch.int32).abs().sum()) == 0     # heads, flags and the timeout count: all back to zero
   ref = torch.matmul(A.double(), B.double())
   err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
   assert err < 2e-6, err
   plain = torch.empty_like(outs[0])
   call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(plain), N, M * N, M, K, N, bins, None)
   torch.cuda.synchronize()
-  full_sets = bins // 8 * 8
-  assert torch.equal(plain[:full_sets], outs[0][:full_sets])                        # bins of full sets: the same launch path
   assert float((plain.double() - ref).abs().max() / ref.abs().max()) < 2e-6

@@ -140,13 +140,13 @@ def test_fullsize_fp32_frequency_domain_l8_gradients_match_float64_reference(cas
   text = '\n'.join(trace)
   # L8 (48 bins): forward and back-prop products on the batched convolution kernel, lag products on the batched
   # filter-gradient kernel; the seven 7-tap layers (36 bins) likewise
-  assert sum(1 for l in trace if l.startswith('gemm_nn<') and ' batched bins=48 ' in l) == 2, text
+  assert sum(1 for l in trace if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=48 ' in l) == 2, text
   assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=48 ' in l) == 1, text
-  assert sum(1 for l in trace if l.startswith('gemm_nn<') and ' batched bins=36 ' in l) == 14, text
+  assert sum(1 for l in trace if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=36 ' in l) == 14, text
   assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=36 ' in l) == 7, text
   assert not any('Kp=8192' in l or 'Kp=64512' in l or 'Kp=1792' in l for l in trace if 'batched' not in l), text   # no W-tap launch of L1..L8
   # the stride-2 first layer on its polyphase view (25 taps over 2 x 80 channels, 45 bins): forward + filter gradient
-  assert sum(1 for l in trace if l.startswith('gemm_nn<') and ' batched bins=45 ' in l) == 1, text
+  assert sum(1 for l in trace if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=45 ' in l) == 1, text
   assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=45 ' in l) == 1, text
   assert not any('Kp=3840' in l for l in trace if 'batched' not in l), text
   compare(eng, case['ref'], case)

@@ -174,6 +174,34 @@ def test_ctc_loss_grad(dev, T, lengths):
     assert np.all(grad[lens[b]:, b] == 0)
 
 
+def test_ctc_with_masked_classes_and_the_loss_as_a_float_pair(dev):
+  """Logits of -inf (a masked class): a state killed by a dead emission must go back to the zero state, not keep
+  a zero mantissa under a live-scale exponent that wins the next alignment and flushes live neighbours.  Whole classes
+  masked for long runs, from the first frame, on states far from the start (unreachable AND dead for dozens of frames), on
+  the blank; loss and gradient against the float64 oracle.  And the loss pair: hi is the fp32 loss, hi + lo agrees with the
+  oracle's -log p far below one fp32 ulp."""
+  rng = np.random.default_rng(77)
+  T, C = 240, 29
+  lengths = [60, 90, 30, 100]
+  B = len(lengths)
+  logits, labels, lens = _ctc_case(rng, B, T, C, lengths)
+  labels = [[int(v) % 20 for v in l] for l in labels]          # classes 20..27 never occur in a label
+  logits[:, 0, 20:28] = -np.inf                                # unused classes masked for the whole utterance
+  logits[:40, 1, 25] = -np.inf                                 # ... from the first frame on for a while
+  logits[100:180, 2, 22] = -np.inf
+  logits[5:25, 3, labels[3][50]] = -np.inf                     # a class the label USES, dead while its states are still unreachable
+  logits[0:3, 1, 28] = -np.inf                                 # the blank itself at the start: the path must open with the first label
+  ref_loss, ref_grad = O.ctc_loss_and_grad(logits, labels, lens)
+  assert np.all(np.isfinite(ref_loss))
+  eng, loss, grad = run_ctc(dev, logits, labels, lens, scale=1.0)
+  assert not eng.ctc_status.cpu().numpy().any()
+  np.testing.assert_allclose(loss, ref_loss, rtol=1e-5)
+  assert np.all(np.isfinite(grad)) and np.max(np.abs(grad - ref_grad)) < 5e-5
+  precise = eng.losses_precise()
+  assert np.max(np.abs(precise - ref_loss)) < 2e-5, (precise - ref_loss)
+  assert np.array_equal(loss, precise.astype(np.float32))       # hi is the rounded double, lo the remainder
+
+
 def test_ctc_closed_forms_and_errors(dev):
   C = 29
   T = 7

@@ -100,10 +100,12 @@ def test_bench_trace_line_parsing():
   bench = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(bench)
   nn = 'gemm_nn<128,128,2,2,fast> epi=1 splits=2 M=16032 Np=256 Kp=64512 taps=32 xcd=8x1 gflop=1059.5 ms=0.54321'
-  bt = 'gemm_nn<64,128,2,2,fast> batched bins=36 M=256 Np=512 Kp=512 tail=1 gflop=4.832'
+  bt = 'gemm_nn<64,128,2,2,fast> batched bins=36 M=256 Np=512 Kp=512 gflop=4.832'
+  sk = 'gemm_nn_bins<64,128,2,2> batched bins=36 M=256 Np=512 Kp=512 streamk wgs=512 upw=18 gflop=4.832'
   tn = 'gemm_tn<128> batched bins=36 M=256 Kp=512 Np=512 gflop=4.832 ms=0.06100'
   assert bench.trace_symbol(nn) == 'gemm_nn<128,128,2,2,fast> epi=1'
   assert bench.trace_symbol(bt) == 'gemm_nn<64,128,2,2,fast> epi=0'          # batched products: the plain epilogue
+  assert bench.trace_symbol(sk) == 'gemm_nn_bins<64,128,2,2>'                 # the persistent stream-K form: a symbol of its own
   assert bench.trace_symbol(tn) == 'gemm_tn<128>' and bench.trace_symbol('dft_rows<3> rows=256 chunks=8 bins=36 gflop=0.9') == 'dft_rows<3>'
   assert bench.trace_key(nn) == 'gemm_nn<128,128,2,2,fast> epi=1 splits=2 M=16032 Np=256 Kp=64512 taps=32 xcd=8x1'
   assert bench.trace_key(tn) == bench.trace_key(tn.replace('ms=0.06100', 'ms=0.09'))

@@ -60,7 +60,7 @@ const char* st_last_error(void);
  * launches); st_trace_end then waits for them and appends " ms=<duration>" to each line -- per-launch times INSIDE the
  * real launch sequence of a step, side streams and all (bench.py's in-step roofline).
  * Tuning overrides for performance experiments ("gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm",
- * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "streamk", "transform_wgs", "bf16_wgrad_target"); value 0 restores the library's own policy.
+ * "no_fast", "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "streamk", "transform_wgs", "bf16_wgrad_target", "streamk_slots"); value 0 restores the library's own policy.
  * The launch path never reads the environment. */
 int st_trace_begin(void);
 int st_trace_begin_timed(void);
@@ -118,19 +118,19 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  *             the filter-gradient call
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
  *             st_conv1d_fft_dz_spectra_f32, read by both gradient calls
- *   workspace st_conv1d_fft_ws bytes, scratch of one call, headed by st_gemm_nn_batched_ws_f32's area (control words zero before the
- *             first call: allocate it zero-filled; one workspace per stream) */
+ *   workspace st_conv1d_fft_ws bytes, scratch of one call, headed by st_gemm_nn_batched_ws_f32's area (one workspace per stream) */
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad);
 /* the per-bin products themselves: `batches` independent row-major fp32 GEMMs C[i] = A[i] * B[i] (A [m][lda], B [k][n],
  * C [m][ldc]; k a multiple of 32, n of 128; strides in floats) on the convolution MFMA kernel, bin i on XCD i % 8 */
 int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                            int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* stream);
-/* The same with st_gemm_nn_batched_ws_bytes() bytes of scratch: a launch whose 64 x 128 tiles would leave the last round of
- * workgroups ragged (the 7-tap layers: 36 bins x 16 tiles = 576 workgroups on 512 slots) then runs as ONE persistent launch
- * that deals the (bin, tile, k-tile) list in equal runs to 512 workgroups; a tile cut in two is summed head + tail by the
- * workgroup that holds its start (bit-reproducible, no atomics on data).  The first st_gemm_nn_batched_ctrl_bytes() bytes of
- * the scratch are control words: ZERO before the first call, left zero by every call; one scratch per stream.  The
- * frequency-domain entry points below carry this area at the head of their workspace. */
+/* The same with st_gemm_nn_batched_ws_bytes() bytes of scratch: a launch whose 64 x 128 tiles would load the CUs unevenly
+ * (the 7-tap layers: 36 bins x 16 tiles = 576 workgroups, three on a quarter of the CUs, two on the rest) then runs as ONE
+ * persistent launch that deals the (bin, tile, k-tile) list in equal runs to 512 (or 768) workgroups; a tile cut into pieces
+ * is summed head + next + ... by the workgroup that holds its start (bit-reproducible, no atomics on data).  The scratch may
+ * hold any content (its first st_gemm_nn_batched_ctrl_bytes() bytes are flags tagged with a per-launch epoch and reset by
+ * their reader); one scratch per stream.  The frequency-domain entry points below carry this area at the head of their
+ * workspace. */
 size_t st_gemm_nn_batched_ws_bytes(void);
 size_t st_gemm_nn_batched_ctrl_bytes(void);
 int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,

@@ -14,6 +14,8 @@
 // A^T * dz reduced over all (b, t) rows, split over row ranges into slabs that a second
 // kernel sums (deterministic, no atomics).  Staging is LDS-DMA everywhere (global_load_lds).
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstdlib>
 
 #include <type_traits>
@@ -410,19 +412,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 
 // ------------------------------------------------------------------------------------
 // Per-bin products of the frequency-domain layers as ONE persistent launch ("stream-K"): `bins` independent GEMMs
-// C[b] = A[b] * B[b] of a shape whose tile count does not fill whole rounds of the chip -- the seven 7-tap layers:
-// 36 bins x 16 tiles of 64 x 128 = 576 workgroups on 512 slots, the fullest CU runs three tiles for 2.25 tiles of work
-// (measured rounds 2-3: 32 bins 46 us, 36 bins 65 us; a K-split of the last bins only, round 3, bought nothing because its
-// slices started when the full tiles left).  Here the (bin, tile, k-tile) unit list is dealt from t = 0 in equal contiguous
-// runs to 8 x 64 workgroups (csrc/streamk_map.h): every workgroup walks 18 k-tiles -- the end of one tile, whole tiles, the
-// start of the next.  A tile cut in two is finished by the workgroup that holds its START (its last piece, computed late):
-// the workgroup holding the END computed it first thing and published it long before.  Hand-off per MI355X_MICROARCH.md
-// (R1: write-through `sc1` payload, every storing wave drains `vmcnt`, one relaxed agent-scope flag; the reader polls that one
-// word and reads the payload with `sc1` loads) -- placement-independent; the sum is head + tail, a fixed order.
-// Which run a workgroup takes is decided by a dequeue on its label's head word (blockIdx.x % 8), not by blockIdx: the run a
-// workgroup waits for then belongs to a workgroup that has started or will start as soon as ANY slot frees up, whatever
-// order the dispatcher uses (with a static map an out-of-order dispatch could park every resident workgroup on an unstarted
-// one).  Control words are self-resetting: zero before the first call, zero after every call (st_gemm_nn_batched_ws_f32).
+// C[b] = A[b] * B[b] of a shape whose tile count loads the CUs unevenly -- the seven 7-tap layers: 36 bins x 16 tiles of
+// 64 x 128 = 576 workgroups, three on 64 CUs and two on the other 192: the launch costs three tiles for 2.25 tiles of work
+// per CU (measured rounds 2-3: 32 bins 46 us, 36 bins 65 us; a K-split of the last bins only, round 3, bought nothing because
+// its slices started when the full tiles left).  Here the (bin, tile, k-tile) unit list is dealt from t = 0 in equal
+// contiguous runs to 8 x 64 (or 8 x 96) workgroups (csrc/streamk_map.h): every workgroup walks the same number of k-tiles --
+// the end of one tile, whole tiles, the start of the next.  A tile cut into pieces is finished by the workgroup that holds
+// its START (the last piece of its run, computed late); the workgroups holding the rest computed theirs first thing and
+// published them long before.  Hand-off per MI355X_MICROARCH.md (R1: write-through `sc1` payload, every storing wave drains
+// `vmcnt`, one relaxed agent-scope flag; the reader polls that one word and reads the payload with `sc1` loads) --
+// independent of where the workgroups run; the sum is head + next + next ..., a fixed order.
+// Flags carry the launch's epoch (a host counter, never 0) and are put back to 0 by the reader: the scratch may hold ANY
+// content before the first call (a flag equals the epoch by accident with probability 2^-32), and a launch replayed from a
+// graph -- its epoch frozen -- finds the zeros its previous replay left.  The reader waits for workgroups with HIGHER block
+// ids on the same XCD's dispatcher (blockIdx.x + 8, + 16), which that dispatcher starts no later than the reader's own
+// successors; the poll is bounded all the same (a lost producer must not hang the GPU; the timeout word counts).
 // Inner loop: the FAST stage of gemm_nn_kernel (whole k-tiles, LDS-DMA with source-side XOR swizzle, DMA slices between
 // MFMA quads); no row-offset tables (rows are plain multiples of lda).
 // ------------------------------------------------------------------------------------
@@ -431,12 +435,13 @@ struct BinsParams {
   long lda, ldb, ldc, a_batch, b_batch, c_batch;
   int tiles_m, tiles_n;               // per bin
   st::SkPlan plan;
-  unsigned* ctrl;                     // st::SK_CTRL_WORDS control words (heads, flags, timeout count)
+  unsigned* ctrl;                     // st::SK_CTRL_WORDS control words (flags, timeout count)
   float* partial;                     // [8 * wgs_per_xcd][BM * BN]
+  unsigned epoch;                     // != 0
 };
 
-template <int BM, int BN, int WMW, int WNW>
-__global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
+template <int BM, int BN, int WMW, int WNW, int MINW>
+__global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams p) {
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int A_DMA = BM / 32, B_DMA = BN / 32, B_LPR = BN / 4;
@@ -446,10 +451,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
   typedef typename FVec<NT>::type bvec;
   typedef unsigned long long u64;
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ + 4];
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ];
   float* const As = smem;
   float* const Bs = smem + 2 * A_SZ;
-  int* const bcast = reinterpret_cast<int*>(smem + 2 * A_SZ + 2 * B_SZ);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -457,33 +461,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WNW, wn = wave % WNW;
 
-  // which run: a dequeue on this label's head word; the last puller of the launch puts the word back to zero
-  const int xcd = blockIdx.x & 7;
-  if (tid == 0) {
-    unsigned* head = p.ctrl + xcd * st::SK_HEAD_STRIDE;
-    const unsigned got = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)got == p.plan.wgs_per_xcd - 1) __hip_atomic_store(head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bcast[0] = (int)got;
-  }
-  __syncthreads();
-  const int local = __builtin_amdgcn_readfirstlane(bcast[0]);
-  const int slot = local * 8 + xcd;                          // this workgroup's partial tile and flag
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int slot = blockIdx.x;                               // this workgroup's partial tile and flag
   st::SkCursor cur;
-  if (local >= p.plan.wgs_per_xcd || !st::sk_begin(p.plan, xcd, local, cur)) return;
+  if (!st::sk_begin(p.plan, xcd, local, cur)) return;
   const int per_bin = p.tiles_m * p.tiles_n;
 
   // lane-constant parts of the DMA sources (see gemm_nn_kernel): A instruction i of this wave covers rows
   // (wave * A_DMA + i) * 8 .. +8, lane -> (row, swizzled 16-byte slot); B instruction i covers 64 / B_LPR rows of k
-  long a_lane[A_DMA];
+  int a_lane[A_DMA];
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
     const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
-    a_lane[i] = (long)row * p.lda + (((lane & 7) ^ ((row >> 1) & 7))) * 4;
+    a_lane[i] = row * (int)p.lda + (((lane & 7) ^ ((row >> 1) & 7))) * 4;           // (BM rows of a bin: fits an int)
   }
-  long b_lane[B_DMA];
+  int b_lane[B_DMA];
 #pragma unroll
   for (int i = 0; i < B_DMA; ++i)
-    b_lane[i] = (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.ldb + (lane % B_LPR) * 4;
+    b_lane[i] = ((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * (int)p.ldb + (lane % B_LPR) * 4;   // (32 rows of B)
   int a_frag[4];
   {
     const int row = wm * WTM + l31;
@@ -594,7 +589,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
     }
 
     if (pc.kt0 > 0) {
-      // TAIL piece [kt0, nk): publish the partial tile (write-through stores, drained by every storing wave), then the flag
+      // a piece that does not hold the tile's start (always the first piece of this run): publish the partial tile --
+      // write-through stores, drained by every storing wave -- then the flag
       float* const mine = p.partial + (long)slot * (BM * BN);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -606,41 +602,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_bins_kernel(BinsParams p) {
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.ctrl + st::SK_FLAGS + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(p.ctrl + st::SK_FLAGS + slot, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
-    if (pc.kt1 < p.plan.nk) {
-      // HEAD piece [0, kt1): the rest of the tile is the first piece of the next run of this label (slot + 8), computed at
-      // the start of the launch.  One lane polls (bounded: a lost producer must not hang the GPU), takes the flag back.
+    // The piece holds the tile's start.  If it is not the whole tile, the rest are the FIRST pieces of the next runs of this
+    // label (blocks slot + 8, + 16, ...), computed at the start of the launch: add them in that order.
+    int covered = pc.kt1, src = slot;
+    while (covered < p.plan.nk) {
+      src += 8;
       if (tid == 0) {
-        unsigned* flag = p.ctrl + st::SK_FLAGS + slot + 8;
+        unsigned* flag = p.ctrl + st::SK_FLAGS + src;
         unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1u << 21)) {
             __hip_atomic_fetch_add(p.ctrl + st::SK_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
-        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // taken back: zero again for the next call
       }
       __syncthreads();
-      const float* const theirs = p.partial + (long)(slot + 8) * (BM * BN);
-      u64 part[MT][16];
+      const float* const theirs = p.partial + (long)src * (BM * BN);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
+        u64 part[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          part[i][r] = __hip_atomic_load(reinterpret_cast<const u64*>(theirs + row * BN + tcol), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          part[r] = __hip_atomic_load(reinterpret_cast<const u64*>(theirs + row * BN + tcol), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc[i][0][r] += __uint_as_float((unsigned)part[i][r]);
-          acc[i][1][r] += __uint_as_float((unsigned)(part[i][r] >> 32));
+          acc[i][0][r] += __uint_as_float((unsigned)part[r]);
+          acc[i][1][r] += __uint_as_float((unsigned)(part[r] >> 32));
         }
+      }
+      covered += min(p.plan.upw, p.plan.nk - covered);
     }
     float* __restrict__ Cb = p.C + (long)bin * p.c_batch + (long)m0 * p.ldc + n0 + tcol;
 #pragma unroll
@@ -1135,17 +1133,25 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
     st::set_error("gemm_nn_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
   }
-  // stream-K policy: tiles of 64 x 128 against the 512 workgroup slots the plain launch fills round by round.  Worth it when
-  // the last round is ragged (36 bins x 16 tiles: 576 = 1.125 rounds -> 0.56 of two rounds' slots; the first layer's 720;
-  // the 32-tap layer's back-prop 768); a launch of whole rounds (32-tap forward: 3 072 tiles of 128 x 128) stays as it is.
-  // st_set_tuning("streamk", 1) forces it wherever the shape allows, 2 turns it off.
+  // stream-K policy.  The plain launch of 64 x 128 tiles keeps three workgroups per CU resident (768 slots): up to 768
+  // tiles run as one round whose length is the FULLEST CU's.  Worth replacing when that CU holds much more than the average:
+  // 36 bins x 16 tiles = 576 -> 3 against 2.25 (66 -> 56 us measured, round 4); not for the first layer's 720 (3 against
+  // 2.8: 52 us either way) nor the 32-tap layer's back-prop (768 = 3 each: the persistent form with two workgroups per CU
+  // measured slower, 503 against 486 us); launches of several rounds stay as they are.
+  // st_set_tuning("streamk", 1) forces it wherever the shape allows, 2 turns it off; "streamk_slots" = workgroups per XCD
+  // (64 or 96; 0 = the policy's).
   const int knob = st::tuning(st::TUNE_STREAMK);
-  if (sk_ws && knob != 2 && M % 64 == 0 && a_batch % 4 == 0 && b_batch % 4 == 0) {
+  if (sk_ws && knob != 2 && M % 64 == 0 && a_batch % 4 == 0 && b_batch % 4 == 0 && (long)64 * lda < (1L << 30) && (long)32 * N < (1L << 30)) {
     const long tiles = (long)batches * (M / 64) * (N / 128);
-    const long tiles128 = (long)st::ceil_div(M, 128) * (N / 128) * batches;
-    const double fill = (double)tiles / (double)(st::ceil_div((int)tiles, 512) * 512L);
+    const double per_cu = (double)tiles / 256.0;
+    const bool uneven = tiles > 256 && tiles <= 768 && std::ceil(per_cu) / per_cu > 1.2;
+    int slots = st::tuning(st::TUNE_STREAMK_SLOTS);
+    if (slots != 64 && slots != 96) slots = 64;
     st::SkPlan plan;
-    if ((knob == 1 || (tiles128 < 512 && tiles >= 128 && fill < 0.9)) && tiles < (1L << 24) && st::sk_make_plan((int)tiles, K / BK, plan)) {
+    if ((knob == 1 || uneven) && tiles < (1L << 24) && st::sk_make_plan((int)tiles, K / BK, slots, plan)) {
+      static std::atomic<unsigned> g_epoch{0};
+      unsigned epoch = g_epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+      if (epoch == 0) epoch = g_epoch.fetch_add(1, std::memory_order_relaxed) + 1;
       BinsParams q{};
       q.A = A; q.B = B; q.C = C;
       q.lda = lda; q.ldb = N; q.ldc = ldc;
@@ -1154,11 +1160,13 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
       q.plan = plan;
       q.ctrl = reinterpret_cast<unsigned*>(sk_ws);
       q.partial = sk_ws + st::SK_CTRL_WORDS;
+      q.epoch = epoch;
       st::trace("gemm_nn_bins<64,128,2,2> batched bins=%d M=%d Np=%d Kp=%d streamk wgs=%d upw=%d gflop=%.3f", batches, M, N, K,
                 8 * plan.wgs_per_xcd, plan.upw, 2e-9 * M * (double)N * K * batches);
       {
         st::LaunchTimer timer(s);
-        st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
+        if (plan.wgs_per_xcd > 64) st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 3>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
+        else st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 2>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
       }
       return st::check_launch("gemm_nn_bins");
     }

@@ -73,48 +73,40 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
 // log2-softmax of every (b, t) row into the scratch [B*T][32], and the same numbers as emission factors for the recursion:
-// emis[row][c] = (m, e) with 2^logy = m * 2^e, m in [1, 2)
+// emis[row][c] = (m, e) with 2^logy = m * 2^e, m in [1, 2).
+// One lane per (row, class): two rows per wavefront, reductions over the 32 lanes of a row by DPP-free shuffles.  The
+// arithmetic is DOUBLE: log2 y has to be right to ~1e-8 ABSOLUTE, not to a float's 6e-8 relative -- on a fresh network every
+// frame's distribution is nearly the same (all logits ~0, log2 y ~ -4.86), so the float rounding of log2 y (2.4e-7) had the
+// same sign on all 501 frames and the loss came out 1e-4 low (measured round 4, scripts/diag_ctc_loss.py: -9.9e-5 on a loss
+// of 1 245; the recursion itself adds ~1e-6).  What remains is the float mantissa of the factor (3e-8 relative per frame).
 __global__ __launch_bounds__(256) void ctc_logsoftmax_kernel(const float* __restrict__ logits, RowMap2 map,
                                                              int B, int T, int C, float* __restrict__ logy,
                                                              float* __restrict__ emis) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * T) return;
-  int b = i / T, t = i - b * T;
-  const float* row = logits + map.off(b, t);
-  float v[CP];
+  const int lane = threadIdx.x & 63, c = lane & 31;
+  const int i = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const bool row_ok = i < B * T;
+  const int ii = row_ok ? i : B * T - 1;
+  const int b = ii / T, t = ii - b * T;
+  const float v = c < C ? logits[map.off(b, t) + c] : NEG_INF;
+  float m = v;
 #pragma unroll
-  for (int q = 0; q < CP / 4; ++q) {
-    f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * q);
-    v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
-  }
-  float m = NEG_INF;
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  double e = c < C ? exp((double)v - (double)m) : 0.0;
+  double s = e;
 #pragma unroll
-  for (int c = 0; c < CP; ++c) if (c < C) m = fmaxf(m, v[c]);
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < CP; ++c) if (c < C) s += expf(v[c] - m);
-  const float lz = m + logf(s);
-  float* out = logy + (long)i * CP;
-  float* eo = emis + (long)i * CP * 2;
-#pragma unroll
-  for (int q = 0; q < CP / 4; ++q) {
-    f32x4 o, e0, e1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float l2 = (4 * q + e < C) ? (v[4 * q + e] - lz) * LOG2E : 0.f;
-      o[e] = l2;
-      const float fl = floorf(l2);
-      // a class 2^-30000 below the frame's best cannot be emitted (a logit of -inf, in practice): factor 0.  (The bound also
-      // keeps every exponent sum of a 12 000-frame utterance inside int range.)
-      const bool dead = !(l2 > -30000.f);
-      const float mant = dead ? 0.f : ex2(l2 - fl);
-      const int ex = dead ? 0 : (int)fl;
-      if (e < 2) { e0[2 * e] = mant; e0[2 * e + 1] = __builtin_bit_cast(float, ex); }
-      else { e1[2 * (e - 2)] = mant; e1[2 * (e - 2) + 1] = __builtin_bit_cast(float, ex); }
-    }
-    *reinterpret_cast<f32x4*>(out + 4 * q) = o;
-    *reinterpret_cast<f32x4*>(eo + 8 * q) = e0;
-    *reinterpret_cast<f32x4*>(eo + 8 * q + 4) = e1;
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const double lz = (double)m + log(s);
+  const double l2 = c < C ? ((double)v - lz) * 1.4426950408889634074 : 0.0;
+  // a class 2^-30000 below the frame's best cannot be emitted (a logit of -inf, in practice): factor 0.  (The bound also
+  // keeps every exponent sum of a 12 000-frame utterance inside int range.)
+  const bool dead = !(l2 > -30000.0);
+  const double fl = floor(l2);
+  float mant = dead ? 0.f : (float)exp2(l2 - fl);
+  int ex = dead ? 0 : (int)fl;
+  if (mant >= 2.f) { mant = 1.f; ++ex; }                   // (2^0.99999999 rounds to 2.0f)
+  if (row_ok) {
+    logy[(long)i * CP + c] = (float)l2;
+    *reinterpret_cast<f32x2*>(emis + ((long)i * CP + c) * 2) = f32x2{mant, __builtin_bit_cast(float, ex)};
   }
 }
 
@@ -542,7 +534,7 @@ int st_ctc_loss_grad_hilo_f32(const st_tensor3* logits, const int32_t* label_ids
   float* emis = logy + rows * CP;
   float* alpha = emis + rows * CP * 2;             // (mantissa, exponent) records
   float* beta = alpha + rows * kpl * 64 * 2;
-  hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, logits->base,
+  hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, logits->base,
                      make_map2(*logits), B, T, C, logy, emis);
   switch (kpl) {
 #define ST_AB(K) case K: launch_ab<K>(B, s, emis, T, C, label_ids, label_offsets, seq_lens, alpha, beta, status); break;

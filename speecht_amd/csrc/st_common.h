@@ -39,15 +39,15 @@ inline void launch_timed(const LaunchTimer& t, void (*kernel)(KArgs...), const d
   else hipLaunchKernelGGL(kernel, grid, block, 0, s, static_cast<KArgs>(args)...);
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
-       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_COUNT };
+       TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_STREAMK_SLOTS, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
-// sk_ws: optional SK_WS_FLOATS floats of scratch for the persistent stream-K form of a ragged launch (conv_gemm.hip,
-// gemm_nn_bins_kernel): [control words: 8 head words 32 words apart | 512 flags | timeout count] then 512 partial tiles of
-// 64 x 128.  The control words must be ZERO before the first call; every call leaves them zero (self-resetting).
-constexpr int SK_HEAD_STRIDE = 32, SK_FLAGS = 256, SK_TIMEOUTS = SK_FLAGS + 512, SK_CTRL_WORDS = 1024;
-constexpr long SK_WS_FLOATS = SK_CTRL_WORDS + 512L * 64 * 128;
+// sk_ws: optional SK_WS_FLOATS floats of scratch for the persistent stream-K form of an uneven launch (conv_gemm.hip,
+// gemm_nn_bins_kernel): [control words: 768 flags | timeout count] then 768 partial tiles of 64 x 128.  Any content before the
+// first call (flags carry the launch's epoch and are put back to zero by their reader); one scratch per stream.
+constexpr int SK_FLAGS = 0, SK_TIMEOUTS = 768, SK_CTRL_WORDS = 1024;
+constexpr long SK_WS_FLOATS = SK_CTRL_WORDS + 768L * 64 * 128;
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,
                     int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr);
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,

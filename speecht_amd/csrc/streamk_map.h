@@ -8,9 +8,10 @@
 // XCD in practice -- used for L2 locality only, never for correctness):
 //   tiles [x * tiles_per_xcd, (x + 1) * tiles_per_xcd) of the global tile list (bin-major, then column panel, row tile fastest),
 //   each `nk` k-tiles long; workgroup l of that XCD owns units [l * upw, (l + 1) * upw).
-// upw >= nk, so a tile is cut into at most two pieces: a TAIL piece [kt0, nk) is always the first piece of its workgroup, a
-// HEAD piece [0, kt1) always the last piece of the workgroup before it.  The tail's owner publishes its partial tile, the
-// head's owner adds it (head + tail, a fixed order) and writes the tile.
+// A tile's pieces therefore belong to CONSECUTIVE workgroups l, l + 1, ...: the first (it holds k-tile 0, the HEAD) is the last
+// piece of workgroup l's run, every other one is the FIRST piece of its workgroup's run (and, unless it reaches the tile's end,
+// that workgroup's whole run).  Pieces that do not hold k-tile 0 publish their partial tile; the head's owner adds them in
+// workgroup order (head + next + next ..., a fixed order) and writes the tile.
 #pragma once
 
 #ifdef __HIPCC__
@@ -22,27 +23,28 @@
 namespace st {
 
 constexpr int SK_XCDS = 8;
-constexpr int SK_SLOTS_PER_XCD = 64;                 // two resident workgroups on each of an XCD's 32 CUs
+constexpr int SK_MAX_SLOTS_PER_XCD = 96;             // up to three resident workgroups on each of an XCD's 32 CUs
 
 struct SkPlan {
   int tiles_total;                                   // bins * tiles per bin
   int nk;                                            // k-tiles per tile
   int tiles_per_xcd;                                 // ceil(tiles_total / 8)
   int wgs_per_xcd;                                   // grid = 8 * wgs_per_xcd
-  int upw;                                           // units per workgroup, >= nk
+  int upw;                                           // units per workgroup
 };
 
 struct SkCursor { int u, u_end, tile_lo; };
 struct SkPiece { int tile, kt0, kt1; };
 
-// false: nothing to launch this way (no tiles)
-inline bool sk_make_plan(int tiles_total, int nk, SkPlan& p) {
-  if (tiles_total <= 0 || nk <= 0) return false;
+// slots_per_xcd: workgroups per XCD the launch should use (64 = two per CU, 96 = three; fewer only when there are fewer
+// units).  false: nothing to launch this way (no tiles)
+inline bool sk_make_plan(int tiles_total, int nk, int slots_per_xcd, SkPlan& p) {
+  if (tiles_total <= 0 || nk <= 0 || slots_per_xcd <= 0 || slots_per_xcd > SK_MAX_SLOTS_PER_XCD) return false;
   p.tiles_total = tiles_total;
   p.nk = nk;
   p.tiles_per_xcd = (tiles_total + SK_XCDS - 1) / SK_XCDS;
-  p.wgs_per_xcd = p.tiles_per_xcd < SK_SLOTS_PER_XCD ? p.tiles_per_xcd : SK_SLOTS_PER_XCD;   // >= one tile of work each: upw >= nk
   const long units = (long)p.tiles_per_xcd * nk;
+  p.wgs_per_xcd = units < slots_per_xcd ? (int)units : slots_per_xcd;
   p.upw = (int)((units + p.wgs_per_xcd - 1) / p.wgs_per_xcd);
   return true;
 }

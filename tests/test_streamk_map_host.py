@@ -1,6 +1,6 @@
 """The work partition of the persistent per-bin product kernels (csrc/streamk_map.h) walked exhaustively on the host:
-every (tile, k-tile) unit exactly once, at most two pieces per tile, every tail piece paired with the head piece of the
-workgroup before it -- the index algebra and the hand-off pairing of the kernel, pinned without a GPU."""
+every (tile, k-tile) unit exactly once, a tile's pieces on consecutive workgroups, every published piece the first piece of
+its workgroup and as long as the head's owner predicts -- the index algebra and the hand-off pairing of the kernel, pinned without a GPU."""
 import os
 import subprocess
 
@@ -13,4 +13,4 @@ def test_streamk_partition_on_host(tmp_path):
                          os.path.join(ROOT, 'tests', 'host_cpp', 'streamk_map_check.cpp'), '-o', exe])
   r = subprocess.run([exe], capture_output=True, text=True)
   assert r.returncode == 0, r.stdout + r.stderr
-  assert 'wgs_per_xcd=64 upw=18' in r.stdout, r.stdout
+  assert 'wgs_per_xcd=64 upw=18 / wgs_per_xcd=96 upw=12' in r.stdout, r.stdout

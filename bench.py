@@ -140,17 +140,23 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
       launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
           'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
       if i > 0:
-        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, nbk=nbk, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
-            'st_gemm_nn_batched_ws_f32', P(f['zf']), nf, rp * nf, P(f['gbwd']), nf * nbk, outp, nbk, rp * nbk, rp, nf, nbk, nb, tail, tail_bytes, s)))
+        # back-prop to the input: the same spectra read as a transposed operand (X = Z gfwd^T)
+        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
+            'st_gemm_nn_batched_bt_ws_f32', P(f['zf']), nf, rp * nf, P(f['gfwd']), ka * nf, outp, ka, rp * ka, rp, nf, ka, nb, tail, tail_bytes, s)))
       launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, outp=outp: call(
           'st_gemm_tn_batched_f32', P(f['sf']), ka, rp * ka, P(f['zf']), nf, rp * nf, outp, ka * nf, rp, ka, nf, nb, s)))
       continue
     launches.append(('L%d fwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, pf=pf, pb=pb: call(
         'st_conv1d_nwc_fwd_ws_f32', eng.X[i].ref, P(pf), P(pb), l.width, l.stride, pl, int(l.relu), eng.X[i + 1].ref, ws, wsb, s)))
     if i > 0:
-      launches.append(('L%d bwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl: call(
-          'st_conv1d_nwc_bwd_data_bias_f32', eng.dZ[i].ref, P(eng.packed_t[i]), l.width, pl,
-          eng.X[i].ref if eng.layers[i - 1].relu else None, eng.dZ[i - 1].ref, P(eng._slice(eng.grads, i - 1)[1]), ws, wsb, s)))
+      if eng._transposed_in_place(i):
+        launches.append(('L%d bwd' % i, flops[i], io_bytes, lambda i=i, l=l, pf=pf: call(
+            'st_conv1d_1tap_bwd_data_bias_f32', eng.dZ[i].ref, P(pf), eng.X[i].ref if eng.layers[i - 1].relu else None,
+            eng.dZ[i - 1].ref, P(eng._slice(eng.grads, i - 1)[1]), ws, wsb, s)))
+      else:
+        launches.append(('L%d bwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl: call(
+            'st_conv1d_nwc_bwd_data_bias_f32', eng.dZ[i].ref, P(eng.packed_t[i]), l.width, pl,
+            eng.X[i].ref if eng.layers[i - 1].relu else None, eng.dZ[i - 1].ref, P(eng._slice(eng.grads, i - 1)[1]), ws, wsb, s)))
     launches.append(('L%d wgrad' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, gf=gf: call(
         'st_conv1d_nwc_bwd_filter_f32', eng.X[i].ref, eng.dZ[i].ref, l.width, l.stride, pl, P(gf), None, ws, wsb, s)))
   if not launches:
@@ -470,9 +476,10 @@ def attach_pmc_profiles(roofline):
       roofline['traffic_source'] = ('profiles/traffic.json (sources %s): FETCH_SIZE / WRITE_SIZE PMC passes of rocprofv3 over this '
                                     'command, read side doubled per MI355X_MICROARCH.md (scripts/gpu_traffic.sh)' % digest[:12])
     else:
-      m = re.match(r'gemm_nn<(\d+),(\d+),(\d+),(\d+),(fast|clamped)> epi=(\d)', roofline['kernel'])
-      key = ('gemm_nn_kernel<%s, %s, %s, %s, %s, %s>' % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(6),
-                                                         'true' if m.group(5) == 'fast' else 'false') if m else 'gemm_tn_kernel<128, 2, 2>')
+      m = re.match(r'gemm_nn<(\d+),(\d+),(\d+),(\d+),(fast-bt|fast|clamped)> epi=(\d)', roofline['kernel'])
+      key = ('gemm_nn_kernel<%s, %s, %s, %s, %s, %s, %s>' % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(6),
+                                                             'false' if m.group(5) == 'clamped' else 'true',
+                                                             'true' if m.group(5) == 'fast-bt' else 'false') if m else 'gemm_tn_kernel<128, 2, 2>')
       roofline['mfma_busy_pmc'] = data.get(key, {}).get('mfma_busy_frac_at_2p4ghz')
 
 

@@ -112,8 +112,9 @@ int st_conv1d_nwc_fwd_ws_f32(const st_tensor3* x, const float* packed, const flo
  * channels), W/2 + 1 taps, the packed filters shifted by one c_pitch block (engine.py does this for
  * the model's first layer).
  *   tables    st_conv1d_fft_table_floats() floats, filled once per (width, pad_left) by st_conv1d_fft_tables_f32
- *   gfwd/gbwd the filter spectra in the two GEMM operand layouts (st_conv1d_fft_filter_floats floats), rebuilt by
- *             st_conv1d_fft_filters_f32 whenever the weights change (gbwd from the flipped / transposed copy)
+ *   gfwd      the filter spectra as a GEMM operand (st_conv1d_fft_filter_floats floats), rebuilt by
+ *             st_conv1d_fft_filters_f32 whenever the weights change; the forward pass multiplies by it, back-prop to the
+ *             input by its transpose (read in place: no second set of spectra, no flipped copy of the weights)
  *   sf        spectra of the layer input (st_conv1d_fft_sf_floats floats), written by the forward call and read by
  *             the filter-gradient call
  *   zf        spectra of the gradient wrt the layer output (st_conv1d_fft_zf_floats floats), written by
@@ -136,15 +137,20 @@ size_t st_gemm_nn_batched_ctrl_bytes(void);
 int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                               int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* C[i] = A[i] * Bt[i]^T with the second operand given TRANSPOSED, Bt [n][k] (k contiguous): the products of back-prop to the
+ * input, which read the forward filter spectra in place (X = Z gfwd^T) */
+int st_gemm_nn_batched_bt_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* bt, int64_t bt_batch, float* c,
+                                 int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* out[i] = A[i]^T * Z[i]: A [m][lda] (k columns), Z [m][ldz] (n columns), out [k][n]; the reduction runs over the m rows
  * (m a multiple of 32, k and n of 128) -- the lag products of the filter gradient */
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
                            float* out, int64_t out_batch, int m, int k, int n, int batches, void* stream);
 size_t st_conv1d_fft_table_floats(void);
 int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
-size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward);
-int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int cin, int cout, int cin_pitch,
-                              int cout_pitch, const float* tables, float* gfwd, float* gbwd, void* stream);
+size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cout);
+int st_conv1d_fft_filters_f32(const float* packed, int width, int cin, int cout, int cin_pitch, const float* tables, float* gfwd,
+                              void* stream);
 size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width);
 size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width);
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width);
@@ -155,7 +161,7 @@ int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* t
 /* dbias[o] = sum_{b,t} dz[b,t,o] read off bin 0 of the spectra zf (npad floats written, pads zero): the bias gradient of a
  * frequency-domain layer without another pass over dz */
 int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf, float* dbias, void* stream);
-int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
                                    const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
                                    size_t workspace_bytes, void* stream);
 int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* zf, int width,
@@ -180,6 +186,12 @@ size_t st_conv1d_bwd_data_bias_ws(const st_tensor3* dz, const st_tensor3* dx, in
 int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
                                     const st_tensor3* act, const st_tensor3* dx, float* dbias_dx,
                                     void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a ONE-TAP layer (speech_model.py:288,292: the two 1 x 1 layers on top) without any derived operand:
+ * dx = dz W^T with `packed` the layer's own forward filters [cin_pitch][n_pad(cout)], read as a transposed operand.
+ * Needs dz->c_pitch % 32 == 0 and an input width that packs to a multiple of 128; dbias_dx may be NULL.  Workspace as above
+ * with width = 1. */
+int st_conv1d_1tap_bwd_data_bias_f32(const st_tensor3* dz, const float* packed, const st_tensor3* act, const st_tensor3* dx,
+                                     float* dbias_dx, void* workspace, size_t workspace_bytes, void* stream);
 size_t st_conv1d_bwd_filter_ws(const st_tensor3* x, const st_tensor3* dz, int width);
 /* bias gradient alone: dbias[o] = sum_{b,t} dz[b,t,o]  (n_pad floats) */
 size_t st_bias_grad_ws(const st_tensor3* dz);

@@ -45,13 +45,14 @@ _SIGNATURES = {
     'st_gemm_nn_batched_ctrl_bytes': (c_size_t, []),
     'st_gemm_nn_batched_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'st_gemm_nn_batched_bt_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                             c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_gemm_tn_batched_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int,
                                        c_int, c_int, c_void_p]),
     'st_conv1d_fft_table_floats': (c_size_t, []),
     'st_conv1d_fft_tables_f32': (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    'st_conv1d_fft_filter_floats': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    'st_conv1d_fft_filters_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                          c_void_p]),
+    'st_conv1d_fft_filter_floats': (c_size_t, [c_int, c_int, c_int]),
+    'st_conv1d_fft_filters_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'st_conv1d_fft_sf_floats': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_fft_zf_floats': (c_size_t, [_T3P, c_int]),
     'st_conv1d_fft_ws': (c_size_t, [_T3P, _T3P, c_int]),
@@ -68,6 +69,7 @@ _SIGNATURES = {
     'st_conv1d_bwd_data_bias_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_data_bias_f32': (c_int, [_T3P, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p, c_size_t,
                                                 c_void_p]),
+    'st_conv1d_1tap_bwd_data_bias_f32': (c_int, [_T3P, c_void_p, _T3P, _T3P, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_bwd_filter_ws': (c_size_t, [_T3P, _T3P, c_int]),
     'st_conv1d_nwc_bwd_filter_f32': (c_int, [_T3P, _T3P, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                              c_size_t, c_void_p]),

@@ -12,7 +12,8 @@
 // (G = DFT of the zero-padded filter): one complex [rows x Cin] x [Cin x Cout] product per bin instead of W taps per
 // frame -- for 32 taps 48 bins x 8 flops per 64 frames against 64 flops per frame, a 10x cut of the multiplications.
 // The complex products run as REAL GEMMs on the exact-fp32 MFMA convolution kernels (st::gemm_nn_batched, one bin per
-// XCD at a time; st::gemm_tn_batched for the lag products) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]].
+// XCD at a time; st::gemm_tn_batched for the lag products) through the embedding [re | im] x [[Gr, -Gi], [Gi, Gr]]
+// (back-prop: x its transpose, read in place).
 // The transforms are dense DFTs on the same matrix instruction (v_mfma_f32_32x32x2_f32): a wavefront owns 32 channels
 // of one row, reads the 96 x 96 (forward) or 64 x 96 (inverse) DFT matrix from LDS as MFMA A fragments, loads the
 // frames straight from the NWC tensor as B fragments (128-byte runs per frame) in stages that stay one ahead of the
@@ -327,9 +328,12 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
   }
 }
 
-// ---- filters -> their spectra in the two GEMM operand layouts -------------------------------------------------
+// ---- filters -> their spectra as a GEMM operand -------------------------------------------------------------
 // G[k][c][o] = sum_w F[w][c][o] e^{-2 pi i k w / N}.
-//  forward operand  gfwd [bins][2 cph][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G); cph = spectra half width)
+//  gfwd [bins][2 cph][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G); cph = spectra half width).  Back-prop to the input
+//  (X = Z G) needs [[Gr^T, Gi^T], [-Gi^T, Gr^T]] = gfwd^T: the per-bin product kernels read gfwd as a TRANSPOSED operand
+//  (round 4) -- rounds 2-3 built that second set of spectra from a flipped / transposed copy of the weights every step
+//  (the 32-tap layer: 403 MB written and read again, plus the 128 MB of the flip).
 //  from packed [w * cpi + c][npo]; one thread per (c, o), o fastest (coalesced reads and writes); rows c >= cin zero.
 // (WT = compile-time width: the taps stay in registers; WT = 0: run-time width, taps in scratch)
 template <int WT>
@@ -360,39 +364,6 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
     g[(long)c * 2 * npo + npo + o] = -gi;
     g[(long)(cph + c) * 2 * npo + o] = gi;
     g[(long)(cph + c) * 2 * npo + npo + o] = gr;
-  }
-}
-
-//  back-prop operand  gbwd [bins][2 npo][2 npi]:  rows (re o | im o), columns (re c | im c):  [[Gr^T, Gi^T], [-Gi^T, Gr^T]]
-//  (X = Z G; the rows match the columns of the dz spectra, npo per half, zero for o >= cout)
-//  from the flipped / transposed copy packed_t [w' * cpo + o][npi] with w' = W - 1 - w (c fastest there).
-template <int WT>
-__global__ __launch_bounds__(256) void filters_dft_bwd_kernel(const float* __restrict__ packed_t, int width_rt, int cin, int cout,
-                                                              int cpo, int npo, int npi, int n, int bins,
-                                                              const f32x2* __restrict__ tw, float* __restrict__ gbwd) {
-  const int width = WT ? WT : width_rt;
-  const int c = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
-  if (c >= npi) return;
-  float f[WT ? WT : 64];
-  const bool live = c < cin && o < cout;
-#pragma unroll
-  for (int w = 0; w < width; ++w) f[w] = live ? packed_t[((long)(width - 1 - w) * cpo + o) * npi + c] : 0.f;
-  const long plane = (long)2 * npo * 2 * npi;
-  const int per = (bins + gridDim.z - 1) / gridDim.z, k_lo = blockIdx.z * per, k_hi = min(bins, k_lo + per);
-  for (int k = k_lo; k < k_hi; ++k) {
-    float gr = 0.f, gi = 0.f;
-    const f32x2* row = tw + k * width;                     // uniform: wide scalar loads
-#pragma unroll
-    for (int w = 0; w < width; ++w) {
-      const f32x2 t = row[w];
-      gr = fmaf(f[w], t[0], gr);
-      gi = fmaf(-f[w], t[1], gi);
-    }
-    float* g = gbwd + (long)k * plane;
-    g[(long)o * 2 * npi + c] = gr;
-    g[(long)o * 2 * npi + npi + c] = gi;
-    g[(long)(npo + o) * 2 * npi + c] = -gi;
-    g[(long)(npo + o) * 2 * npi + npi + c] = gr;
   }
 }
 
@@ -535,6 +506,13 @@ int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, cons
   return st::gemm_nn_batched(a, lda, a_batch, b, b_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream), sk);
 }
 
+int st_gemm_nn_batched_bt_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* bt, int64_t bt_batch, float* c, int64_t ldc,
+                                 int64_t c_batch, int m, int k, int n, int batches, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  float* sk = (workspace && workspace_bytes >= st_gemm_nn_batched_ws_bytes()) ? reinterpret_cast<float*>(workspace) : nullptr;
+  return st::gemm_nn_batched(a, lda, a_batch, bt, bt_batch, c, ldc, c_batch, m, k, n, batches, st::as_stream(stream), sk, true);
+}
+
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch, float* out,
                            int64_t out_batch, int m, int k, int n, int batches, void* stream) {
   return st::gemm_tn_batched(a, lda, a_batch, z, ldz, z_batch, out, out_batch, m, k, n, batches, st::as_stream(stream));
@@ -560,20 +538,20 @@ int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t tabl
   return st::check_launch("fft tables");
 }
 
-size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cin, int cout, int backward) {
+size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cout) {
   if (!width_ok(width)) return 0;
   const size_t bins = (V + width - 1) / 2 + 1;
-  return backward ? bins * 2 * npad_of(cout) * 2 * npad_of(cin) : bins * 2 * half_of(cin_pitch) * 2 * npad_of(cout);
+  return bins * 2 * half_of(cin_pitch) * 2 * npad_of(cout);
 }
 
-int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int width, int cin, int cout, int cin_pitch,
-                              int cout_pitch, const float* tables, float* gfwd, float* gbwd, void* stream) {
-  ST_REQUIRE(width_ok(width) && cin_pitch % 16 == 0 && cout_pitch % 16 == 0 && tables, "fft filters: bad shape");
+int st_conv1d_fft_filters_f32(const float* packed, int width, int cin, int cout, int cin_pitch, const float* tables, float* gfwd,
+                              void* stream) {
+  ST_REQUIRE(width_ok(width) && cin_pitch % 16 == 0 && tables && packed && gfwd, "fft filters: bad argument");
   ST_REQUIRE(npad_of(cout) % 128 == 0, "fft filters: the output channels must pack to a multiple of 128");
   hipStream_t s = st::as_stream(stream);
   const int n = V + width - 1, bins = n / 2 + 1;
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
-  const int npo = npad_of(cout), npi = npad_of(cin);
+  const int npo = npad_of(cout);
   // compile-time widths for the layers of the model (taps in registers); any other width runs the generic form
 #define ST_FFT_WIDTH_DISPATCH(KERNEL, ...)                                                                   \
   do {                                                                                                       \
@@ -582,20 +560,10 @@ int st_conv1d_fft_filters_f32(const float* packed, const float* packed_t, int wi
     else if (width == 7) hipLaunchKernelGGL(KERNEL<7>, grid, dim3(256), 0, s, __VA_ARGS__);                  \
     else hipLaunchKernelGGL(KERNEL<0>, grid, dim3(256), 0, s, __VA_ARGS__);                                  \
   } while (0)
-  if (gfwd) {
-    ST_REQUIRE(packed, "fft filters: packed filters missing");
-    // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
-    const int gx = st::ceil_div(npo, 256), gy = half_of(cin_pitch);
-    const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
-    ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd);
-  }
-  if (gbwd) {
-    ST_REQUIRE(packed_t, "fft filters: flipped / transposed filters missing");
-    ST_REQUIRE(npad_of(cin) % 128 == 0, "fft filters: the input channels must pack to a multiple of 128 for back-prop");
-    const int gx = st::ceil_div(npi, 256);
-    const dim3 grid(gx, npo, gx * npo < 1024 ? 4 : 1);
-    ST_FFT_WIDTH_DISPATCH(filters_dft_bwd_kernel, packed_t, width, cin, cout, cout_pitch, npo, npi, n, bins, tw, gbwd);
-  }
+  // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
+  const int gx = st::ceil_div(npo, 256), gy = half_of(cin_pitch);
+  const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
+  ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd);
   return st::check_launch("fft filters");
 }
 
@@ -615,7 +583,7 @@ size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
   if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
-  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)half_of(x->c_pitch), nb = 2 * (size_t)npad_of(x->channels);
+  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)half_of(x->c_pitch), nb = ka;
   const size_t yf = (size_t)p.bins * p.rows_pad * nf, xf = (size_t)p.bins * p.rows_pad * nb, qf = (size_t)p.bins * ka * nf;
   // [stream-K area of the per-bin products (control words + partial tiles, st_common.h) | spectra of the call's output]
   return (st::SK_WS_FLOATS + std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
@@ -658,26 +626,26 @@ int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf
   return st::check_launch("conv fft bias grad");
 }
 
-int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gbwd, int width, int pad_left,
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
                                    const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && zf && gbwd && workspace && tables && width_ok(width), "conv fft bwd_data: bad argument");
+  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && zf && gfwd && workspace && tables && width_ok(width), "conv fft bwd_data: bad argument");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames && pad_left >= 0 && pad_left < width, "conv fft bwd_data: stride-1 layers only");
-  ST_REQUIRE(npad_of(dx->channels) % 128 == 0 && npad_of(dz->channels) % 128 == 0 &&
-                 workspace_bytes >= st_conv1d_fft_ws(dx, dz, width), "conv fft bwd_data: workspace / shape");
+  ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(dx, dz, width), "conv fft bwd_data: workspace / shape");
   if (act) ST_REQUIRE(tensor_ok(act) && act->batch == dx->batch && act->frames == dx->frames && act->c_pitch >= dx->c_pitch,
                       "conv fft bwd_data: mask tensor mismatch");
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  const int kz = 2 * npad_of(dz->channels), npi = npad_of(dx->channels), nb = 2 * npi;
+  // X[bin] = Z[bin] (rows x 2 npo) * gfwd[bin]^T (2 npo x 2 cph): the forward spectra read as a transposed operand
+  const int kz = 2 * npad_of(dz->channels), cph = half_of(dx->c_pitch), nb = 2 * cph;
   float* const sk = reinterpret_cast<float*>(workspace);
   float* xf = sk + st::SK_WS_FLOATS;
-  if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gbwd, (long)kz * nb, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
-                                  nb, p.bins, s, sk))
+  if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gfwd, (long)nb * kz, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
+                                  nb, p.bins, s, sk, true))
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
-  launch_idft<3>(xf, tables + T_IX, p, npi, nchunks, out, nullptr, 0, act ? act->base + (long)act->halo * act->c_pitch : nullptr,
+  launch_idft<3>(xf, tables + T_IX, p, cph, nchunks, out, nullptr, 0, act ? act->base + (long)act->halo * act->c_pitch : nullptr,
                  act ? (long)act->t_pitch * act->c_pitch : 0L, act ? act->c_pitch : 0, s);
   return st::check_launch("conv fft bwd_data");
 }

@@ -60,6 +60,7 @@ struct NNParams {
   int colsum_rows;                   // (tile_m, wave row): [colsum_rows][Np] -- the bias gradient of the layer below
   int batches;                       // > 0: `batches` independent GEMMs of the same shape (the frequency bins of
   long a_batch, b_batch, c_batch;    // csrc/conv_fft.hip), operand strides in floats; workgroup -> (bin, tile) below
+  long bt_ld; int bt_rows;           // BT kernels: Bm is B TRANSPOSED, [bt_rows][bt_ld] with the reduction index contiguous
 };
 
 // ------------------------------------------------------------------------------------
@@ -103,9 +104,16 @@ template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v 
 
 // FAST: every k-tile is whole (channel pitch and reduction length multiples of 32), so the DMA source of a
 // piece is a per-lane pointer plus the uniform k0 -- no clamps, one 64-bit add per piece.
-template <int BM, int BN, int WMW, int WNW, int EPI, bool FAST = false>
+// BT (needs FAST, one tap): the filter operand is given TRANSPOSED, Bt[n][k] with k contiguous -- back-prop to the input of a
+// 1-tap layer reads the layer's own packed filters [cin][cout] (dx = dz W^T), back-prop of a frequency-domain layer the
+// FORWARD filter spectra (gbwd = gfwd^T, conv_fft.hip): no flipped / transposed copies, no second set of spectra.  The
+// B stage is then staged and read exactly like the A stage ([BN][32], XOR swizzle on the source, ds_read_b128 fragments of 4
+// consecutive k); a lane's NT columns are 32 apart (n * 32 + lane) instead of adjacent, so that the 32 fragment rows of a
+// read are consecutive LDS rows (conflict-free like A's), and the epilogue addresses its columns one by one.
+template <int BM, int BN, int WMW, int WNW, int EPI, bool FAST = false, bool BT = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
   constexpr bool SGB = true;
+  static_assert(!BT || FAST, "the transposed-operand variant exists for whole k-tiles only");
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int A_DMA = BM / 32;            // DMA instructions per wave for the [BM][32] A stage
@@ -199,7 +207,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) aptr[i] = asrc[i] + aslot4[i];
 #pragma unroll
-  for (int i = 0; i < B_DMA; ++i) bptr[i] = bsrc[i] + (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.Np;
+  for (int i = 0; i < B_DMA; ++i) {
+    if (BT) {            // rows of Bt like rows of A: instruction i covers tile rows (wave * B_DMA + i) * 8 .. +8 (clamped into Bt)
+      const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
+      bptr[i] = Bbase + (long)min(n0 + row, p.bt_rows - 1) * p.bt_ld + (((lane & 7) ^ ((row >> 1) & 7))) * 4;
+    } else {
+      bptr[i] = bsrc[i] + (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.Np;
+    }
+  }
   auto dma_piece = [&](int pc, int k0, int buf) {
     if (pc < A_DMA) {
       const int i = pc < A_DMA ? pc : 0;
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     } else {
       const int i = pc - A_DMA < B_DMA ? pc - A_DMA : 0;
       const int krow = min(k0 + (wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR, kplast);
-      const float* g = FAST ? bptr[i] + (long)k0 * p.Np : bsrc[i] + (long)krow * p.Np;
+      const float* g = BT ? bptr[i] + k0 : (FAST ? bptr[i] + (long)k0 * p.Np : bsrc[i] + (long)krow * p.Np);
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
     }
   };
@@ -235,6 +250,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     for (int q = 0; q < 4; ++q) a_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
   }
   const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
+  int bt_frag[4];        // BT: fragment of column tile n = bt_frag[q] + n * 32 * BK (row = wn * WTN + n * 32 + l31; same swizzle for every n)
+  {
+    const int row = wn * WTN + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bt_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
 
   // Reduction order.  k = tap * cp + channel.  With more than one tap the k-tiles are walked
   // channel-chunk OUTER, tap INNER: consecutive tiles then read the same 32-channel column of input
@@ -270,17 +292,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     const int nk0 = tile_k0(ntap, nchunk);
     tap = ntap; chunk = nchunk;
     const float* as = As + CUR * A_SZ;
-    const float* bs = Bs + CUR * B_SZ + b_frag;
+    const float* bs = Bs + CUR * B_SZ + (BT ? 0 : b_frag);
     // Software-pipelined fragment reads: the reads of k-quad q+1 are issued BEFORE the 16 MFMAs of
     // quad q (sched_barrier pins the order; hipcc otherwise sinks the reads behind the MFMAs to
     // save registers and then stalls on LDS latency four times per tile).
     f32x4 af[4][MT];
     bvec bf[4][4];
+    f32x4 bft[4][NT];
     auto read_frags = [&](int q) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + a_frag[q] + i * 32 * BK);
+      if (BT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+        for (int n = 0; n < NT; ++n) bft[q][n] = *reinterpret_cast<const f32x4*>(bs + bt_frag[q] + n * 32 * BK);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+      }
     };
     read_frags(0);
 #pragma unroll
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], BT ? bft[q][n][j] : vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
       }
       if (SGB) {
         // interleave request: one ds_read behind each of the first MFMAs, then the address VALU and
@@ -338,6 +366,72 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
     stage(integral_constant<int, 0>{}, false_type{});
   }
 
+  if constexpr (BT) {
+    // epilogue of the transposed-operand variant: column tile n of this lane is column n * 32 + l31 of the wave's block
+    // (one float per lane and row: 128-byte runs per half-wave); same arithmetic as below, column by column
+    const int colb = n0 + wn * WTN + l31;
+    if (p.splits > 1) {
+      float* slab = p.slab + (long)blockIdx.y * p.M * p.Np;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < p.M) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) slab[(long)m * p.Np + colb + n * 32] = acc[i][n][r];
+          }
+        }
+      return;
+    }
+    float csum[NT], bv[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      ok[n] = colb + n * 32 < p.n_store;
+      csum[n] = 0.f;
+      bv[n] = (EPI == 0 && p.bias && ok[n]) ? p.bias[colb + n * 32] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float mk[16][NT];
+      if (EPI == 1 && p.mask) {                    // the ReLU mask of the 16 rows first, branch-free (see below)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) mk[r][n] = p.mask[m_off[row] + (ok[n] ? colb + n * 32 : 0)];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long co = c_off[row];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          float v = acc[i][n][r];
+          if (EPI == 0) {
+            v += bv[n];
+            if (p.relu) v = fmaxf(v, 0.f);
+          } else if (p.mask) {
+            v = mk[r][n] > 0.f ? v : 0.f;
+          }
+          if (co >= 0 && ok[n]) {
+            if (EPI == 1) csum[n] += v;
+            Cbase[co + colb + n * 32] = v;
+          }
+        }
+      }
+    }
+    if (EPI == 1 && p.colsum) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float tot = csum[n] + __shfl_xor(csum[n], 32, 64);
+        if (h == 0) p.colsum[(long)(tile_m * WMW + wm) * p.Np + colb + n * 32] = tot;
+      }
+    }
+    return;
+  }
   // epilogue: C/D layout of 32x32 MFMA: tile column = lane&31 (-> output column NT*l31 + nt),
   // row = (r&3) + 8*(r>>2) + 4*(lane>>5); every lane stores NT adjacent floats per row.
   const int col0 = n0 + wn * WTN + NT * l31;
@@ -440,7 +534,9 @@ struct BinsParams {
   unsigned epoch;                     // != 0
 };
 
-template <int BM, int BN, int WMW, int WNW, int MINW>
+// BT: B given transposed ([N][ldb], the reduction index contiguous) -- back-prop to the input reads the FORWARD filter spectra
+// (gbwd = gfwd^T); staged and read like the A operand, a lane's two columns 32 apart (see gemm_nn_kernel).
+template <int BM, int BN, int WMW, int WNW, int MINW, bool BT>
 __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams p) {
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -477,8 +573,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
   }
   int b_lane[B_DMA];
 #pragma unroll
-  for (int i = 0; i < B_DMA; ++i)
-    b_lane[i] = ((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * (int)p.ldb + (lane % B_LPR) * 4;   // (32 rows of B)
+  for (int i = 0; i < B_DMA; ++i) {
+    if (BT) {
+      const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
+      b_lane[i] = row * (int)p.ldb + (((lane & 7) ^ ((row >> 1) & 7))) * 4;                             // (BN rows of Bt)
+    } else {
+      b_lane[i] = ((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * (int)p.ldb + (lane % B_LPR) * 4;   // (32 rows of B)
+    }
+  }
+  int bt_frag[4];
+  {
+    const int row = wn * WTN + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bt_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
   int a_frag[4];
   {
     const int row = wm * WTM + l31;
@@ -487,7 +596,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
     for (int q = 0; q < 4; ++q) a_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
   }
   const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
-  const int tcol = wn * WTN + NT * l31;                      // this lane's first column inside the tile
+  const int tcol = wn * WTN + NT * l31;                      // this lane's first column inside the tile (the partial tiles'
+                                                             // 8-byte slots keep this address also when the columns are 32 apart)
 
   while (cur.u < cur.u_end) {
     const st::SkPiece pc = st::sk_piece(p.plan, cur);
@@ -496,7 +606,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
     const int tile_n = t / p.tiles_m, tile_m = t - tile_n * p.tiles_m;   // row tiles fastest: neighbours share a filter panel
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const float* __restrict__ Ab = p.A + (long)bin * p.a_batch + (long)m0 * p.lda;
-    const float* __restrict__ Bb = p.B + (long)bin * p.b_batch + n0;
+    const float* __restrict__ Bb = p.B + (long)bin * p.b_batch + (BT ? (long)n0 * p.ldb : (long)n0);
     const float* aptr[A_DMA];
     const float* bptr[B_DMA];
 #pragma unroll
@@ -509,7 +619,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
         __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + k0), (lptr_t)(As + buf * A_SZ + (wave * A_DMA + i) * 256), 16, 0, 0);
       } else {
         const int i = pcx - A_DMA < B_DMA ? pcx - A_DMA : 0;
-        __builtin_amdgcn_global_load_lds((gptr_t)(bptr[i] + (long)k0 * p.ldb), (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(BT ? bptr[i] + k0 : bptr[i] + (long)k0 * p.ldb), (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
       }
     };
 
@@ -532,14 +642,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
       const int nk0 = k0 + BK;
       k0 = nk0;
       const float* as = As + CUR * A_SZ;
-      const float* bs = Bs + CUR * B_SZ + b_frag;
+      const float* bs = Bs + CUR * B_SZ + (BT ? 0 : b_frag);
       f32x4 af[4][MT];
       bvec bf[4][4];
+      f32x4 bft[4][NT];
       auto read_frags = [&](int q) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + a_frag[q] + i * 32 * BK);
+        if (BT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+          for (int n = 0; n < NT; ++n) bft[q][n] = *reinterpret_cast<const f32x4*>(bs + bt_frag[q] + n * 32 * BK);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+        }
       };
       read_frags(0);
 #pragma unroll
@@ -555,7 +671,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], BT ? bft[q][n][j] : vget<NT>(bf[q][j], n), acc[i][n], 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -640,16 +756,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
       }
       covered += min(p.plan.upw, p.plan.nk - covered);
     }
-    float* __restrict__ Cb = p.C + (long)bin * p.c_batch + (long)m0 * p.ldc + n0 + tcol;
+    float* __restrict__ Cb = p.C + (long)bin * p.c_batch + (long)m0 * p.ldc + n0 + (BT ? wn * WTN + l31 : tcol);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        bvec out;
+        if (BT) {                            // this lane's columns are 32 apart
 #pragma unroll
-        for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
-        *reinterpret_cast<bvec*>(Cb + (long)row * p.ldc) = out;
+          for (int n = 0; n < NT; ++n) Cb[(long)row * p.ldc + n * 32] = acc[i][n][r];
+        } else {
+          bvec out;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) vset<NT>(out, n, acc[i][n][r]);
+          *reinterpret_cast<bvec*>(Cb + (long)row * p.ldc) = out;
+        }
       }
   }
 }
@@ -1049,7 +1170,7 @@ int fwd_splits(int M, int Np, int nk) {
   return (int)std::max<long>(1, std::min<long>(256 / tiles128, nk / 4));
 }
 
-template <int BM, int BN, int WMW, int WNW, bool FAST = false>
+template <int BM, int BN, int WMW, int WNW, bool FAST = false, bool BT = false>
 void launch_nn(NNParams& p, int epi, hipStream_t s) {
   p.tiles_m = st::ceil_div(p.M, BM);
   p.tiles_n = p.Np / BN;
@@ -1078,15 +1199,15 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
   dim3 grid(p.chunk * 8, p.splits > 1 ? p.splits : 1), block(NTHREADS);
   const double gflop = 2e-9 * p.tiles_m * BM * (double)p.Np * p.Kp * std::max(1, p.batches);      // executed, padding included
   if (p.batches > 0)
-    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? "fast" : "clamped",
+    st::trace("gemm_nn<%d,%d,%d,%d,%s> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", BM, BN, WMW, WNW, FAST ? (BT ? "fast-bt" : "fast") : "clamped",
               p.batches, p.M, p.Np, p.Kp, gflop);
   else
     st::trace("gemm_nn<%d,%d,%d,%d,%s> epi=%d splits=%d M=%d Np=%d Kp=%d taps=%d xcd=%dx%d gflop=%.3f", BM, BN, WMW, WNW,
-              FAST ? "fast" : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
+              FAST ? (BT ? "fast-bt" : "fast") : "clamped", epi, p.splits > 1 ? p.splits : 1, p.M, p.Np, p.Kp, p.taps, p.gm, 8 / p.gm, gflop);
   {
     st::LaunchTimer timer(s);
-    if (epi == 0) st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST>, grid, block, s, p);
-    else st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST>, grid, block, s, p);
+    if (epi == 0) st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 0, FAST, BT>, grid, block, s, p);
+    else st::launch_timed(timer, gemm_nn_kernel<BM, BN, WMW, WNW, 1, FAST, BT>, grid, block, s, p);
   }
   if (p.splits > 1) {
     const long quads = (long)p.M * (p.n_store / 4);
@@ -1097,6 +1218,17 @@ void launch_nn(NNParams& p, int epi, hipStream_t s) {
 
 int run_nn(NNParams& p, int epi, hipStream_t s) {
   const int force = st::tuning(st::TUNE_GEMM_TILE);   // perf experiments (st_set_tuning)
+  if (p.bt_ld > 0) {
+    // the filter operand transposed (k contiguous): whole k-tiles, one tap, 128-column tiles only
+    if (!(p.Np % 128 == 0 && p.taps == 1 && p.cp % 32 == 0 && p.Kvalid % 32 == 0 && p.Kvalid == p.Kp && p.bt_ld % 4 == 0 && p.bt_rows > 0)) {
+      st::set_error("gemm_nn: the transposed-operand form needs n_pad %% 128 == 0, one tap and a reduction length that is a multiple of 32");
+      return ST_EINVAL;
+    }
+    const long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128) * std::max(1, p.batches);
+    if ((p.batches > 0 && tiles128 < 512) || (p.batches <= 0 && tiles128 < 192 && p.splits <= 1)) launch_nn<64, 128, 2, 2, true, true>(p, epi, s);
+    else launch_nn<128, 128, 2, 2, true, true>(p, epi, s);
+    return st::check_launch("gemm_nn (bt)");
+  }
   if (p.Np % 128 == 0) {
     long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128) * std::max(1, p.batches);
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
@@ -1128,7 +1260,7 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
 // With a workspace (st::SK_WS_FLOATS floats, control words zero) a launch whose 64 x 128 tiles would leave the last round of
 // workgroups ragged runs as the persistent stream-K kernel instead (gemm_nn_bins_kernel).
 int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc,
-                        long c_batch, int M, int K, int N, int batches, hipStream_t s, float* sk_ws) {
+                        long c_batch, int M, int K, int N, int batches, hipStream_t s, float* sk_ws, bool b_transposed) {
   if (!(A && B && C && M > 0 && K > 0 && K % 32 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldc % 4 == 0)) {
     st::set_error("gemm_nn_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
@@ -1154,19 +1286,25 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
       if (epoch == 0) epoch = g_epoch.fetch_add(1, std::memory_order_relaxed) + 1;
       BinsParams q{};
       q.A = A; q.B = B; q.C = C;
-      q.lda = lda; q.ldb = N; q.ldc = ldc;
+      q.lda = lda; q.ldb = b_transposed ? K : N; q.ldc = ldc;
       q.a_batch = a_batch; q.b_batch = b_batch; q.c_batch = c_batch;
       q.tiles_m = M / 64; q.tiles_n = N / 128;
       q.plan = plan;
       q.ctrl = reinterpret_cast<unsigned*>(sk_ws);
       q.partial = sk_ws + st::SK_CTRL_WORDS;
       q.epoch = epoch;
-      st::trace("gemm_nn_bins<64,128,2,2> batched bins=%d M=%d Np=%d Kp=%d streamk wgs=%d upw=%d gflop=%.3f", batches, M, N, K,
-                8 * plan.wgs_per_xcd, plan.upw, 2e-9 * M * (double)N * K * batches);
+      st::trace("gemm_nn_bins<64,128,2,2%s> batched bins=%d M=%d Np=%d Kp=%d streamk wgs=%d upw=%d gflop=%.3f", b_transposed ? ",bt" : "",
+                batches, M, N, K, 8 * plan.wgs_per_xcd, plan.upw, 2e-9 * M * (double)N * K * batches);
       {
         st::LaunchTimer timer(s);
-        if (plan.wgs_per_xcd > 64) st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 3>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
-        else st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 2>, dim3(8 * plan.wgs_per_xcd), dim3(NTHREADS), s, q);
+        const dim3 grid(8 * plan.wgs_per_xcd), block(NTHREADS);
+        if (b_transposed) {
+          if (plan.wgs_per_xcd > 64) st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 3, true>, grid, block, s, q);
+          else st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 2, true>, grid, block, s, q);
+        } else {
+          if (plan.wgs_per_xcd > 64) st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 3, false>, grid, block, s, q);
+          else st::launch_timed(timer, gemm_nn_bins_kernel<64, 128, 2, 2, 2, false>, grid, block, s, q);
+        }
       }
       return st::check_launch("gemm_nn_bins");
     }
@@ -1186,6 +1324,7 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
   p.cp = K;
   p.batches = batches;
   p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
+  if (b_transposed) { p.bt_ld = K; p.bt_rows = N; }
   return run_nn(p, 0, s);
 }
 
@@ -1231,6 +1370,10 @@ bool tensor_ok(const st_tensor3* t) {
 }
 
 }  // namespace
+
+static int bwd_data_impl(const st_tensor3* dz, const float* packed_t, bool forward_filters, int width, int pad_left,
+                         const st_tensor3* act, const st_tensor3* dx, float* dbias_dx, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 extern "C" {
 
@@ -1373,6 +1516,24 @@ size_t st_conv1d_bwd_data_bias_ws(const st_tensor3* dz, const st_tensor3* dx, in
 int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t, int width, int pad_left,
                                     const st_tensor3* act, const st_tensor3* dx, float* dbias_dx, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+  return bwd_data_impl(dz, packed_t, false, width, pad_left, act, dx, dbias_dx, workspace, workspace_bytes, stream);
+}
+
+int st_conv1d_1tap_bwd_data_bias_f32(const st_tensor3* dz, const float* packed, const st_tensor3* act, const st_tensor3* dx,
+                                     float* dbias_dx, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && dz->c_pitch % 32 == 0 && npad_of(dx->channels) % 128 == 0 &&
+                 npad_of(dz->channels) >= dz->c_pitch,
+             "conv 1-tap bwd_data: needs a channel pitch of dz that is a multiple of 32 and an input width that packs to 128s");
+  return bwd_data_impl(dz, packed, true, 1, 0, act, dx, dbias_dx, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+// back-prop to the input: dz (*) flipped / transposed filters (packed_t), or -- one tap, `forward_filters` -- dz W^T with the
+// layer's own packed filters [cin_pitch][n_pad(cout)] read as a transposed operand
+static int bwd_data_impl(const st_tensor3* dz, const float* packed_t, bool forward_filters, int width, int pad_left,
+                         const st_tensor3* act, const st_tensor3* dx, float* dbias_dx, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && packed_t, "conv bwd_data: bad tensor descriptor");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames, "conv bwd_data: stride-1 layers only");
   const int lead = width - 1 - pad_left;   // zero rows needed in front of dz frame 0
@@ -1398,6 +1559,10 @@ int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t,
   p.n_store = std::min(dx->c_pitch, p.Np);
   p.taps = width;
   p.cp = dz->c_pitch;
+  if (forward_filters) {                       // Bt[n = input channel][k = output channel]: rows of the forward operand
+    p.bt_ld = npad_of(dz->channels);
+    p.bt_rows = dx->c_pitch;
+  }
   // long reductions on few output tiles (L8: K = 64000, N = 256) are split over K; needs the workspace
   const int splits = nn_splits(p.M, p.Np, p.Kp);
   if (splits > 1 && workspace && workspace_bytes >= st_conv1d_bwd_data_ws(dz, dx, width)) {
@@ -1428,6 +1593,8 @@ int st_conv1d_nwc_bwd_data_bias_f32(const st_tensor3* dz, const float* packed_t,
   }
   return st::check_launch("bwd_data bias gradient");
 }
+
+extern "C" {
 
 static int bwd_filter_splits(int M, int kp, int np) {
   // Row-range splits of the M reduction.  The kernel runs 2 workgroups per CU (512 slots): pick the

@@ -49,7 +49,7 @@ int tuning(int key);
 constexpr int SK_FLAGS = 0, SK_TIMEOUTS = 768, SK_CTRL_WORDS = 1024;
 constexpr long SK_WS_FLOATS = SK_CTRL_WORDS + 768L * 64 * 128;
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,
-                    int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr);
+                    int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr, bool b_transposed = false);
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
                     int M, int K, int N, int batches, hipStream_t s);
 

@@ -190,7 +190,6 @@ class Wav2LetterEngine:
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
     self._gfwd_fresh = False
-    self._gbwd_fresh = False
     self.fft = {}
 
   # ---- plumbing --------------------------------------------------------------------------
@@ -251,7 +250,6 @@ class Wav2LetterEngine:
     self._wplanes_fresh = False
     self._wtplanes_fresh = False
     self._gfwd_fresh = False
-    self._gbwd_fresh = False
 
   def _unpack(self, flat):
     out = []
@@ -408,10 +406,9 @@ class Wav2LetterEngine:
       if getattr(self, '_fft_table_key', {}).get(i) != (f['width'], f['pl']):
         fresh_tables = True
       self.__dict__.setdefault('_fft_table_key', {})[i] = (f['width'], f['pl'])
-      gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(f['width'], f['cin_pitch'], f['cin'], l.cout, 0))
-      gbwd, fresh_b = (view('gbwd', lib.st_conv1d_fft_filter_floats(l.width, l.cin_pitch, l.cin, l.cout, 1)) if i > 0
-                       else (None, False))
-      f.update(tables=tables, gfwd=gfwd, gbwd=gbwd,
+      # ONE set of filter spectra: back-prop to the input reads it as a transposed operand (csrc/conv_fft.hip)
+      gfwd, fresh_f = view('gfwd', lib.st_conv1d_fft_filter_floats(f['width'], f['cin_pitch'], l.cout))
+      f.update(tables=tables, gfwd=gfwd,
                sf=view('sf', lib.st_conv1d_fft_sf_floats(f['xref'], self.X[i + 1].ref, f['width']))[0],
                zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, f['width']))[0],
                ws=view('ws', lib.st_conv1d_fft_ws(f['xref'], self.X[i + 1].ref, f['width']) // 4 + 64)[0])
@@ -423,18 +420,16 @@ class Wav2LetterEngine:
         call('st_conv1d_fft_tables_f32', f['width'], f['pl'], self._ptr(tables), tables.numel(), self.stream_ptr)
       if fresh_f:
         self._gfwd_fresh = False
-      if fresh_b:
-        self._gbwd_fresh = False
       self.fft[i] = f
     if set(self.fft) != getattr(self, '_fft_prev', None):     # a layer (re)joined the path: its spectra may be stale
       self._gfwd_fresh = False
-      self._gbwd_fresh = False
+      self._packed_t_fresh = False                             # (and a layer that left it needs its flipped copy again)
     self._fft_prev = set(self.fft)
 
   def _refresh_fft_filters(self, layers=None):
-    """Forward filter spectra of the frequency-domain layers (all, or the given ones) from the current weights, in layer
+    """Filter spectra of the frequency-domain layers (all, or the given ones) from the current weights, in layer
     order; on a side stream an event is recorded after each layer so that the forward pass waits for the layer it is
-    about to run, not for all.  (The back-prop operands: `_refresh_backward_operands`.)"""
+    about to run, not for all.  (Back-prop to the input reads the same spectra, transposed.)"""
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     if layers is None:
       self._gfwd_ready = {}
@@ -449,8 +444,8 @@ class Wav2LetterEngine:
         with torch.cuda.stream(stream):
           f['packed2'][f['shift'] * cp * l.n_pad:f['shift'] * cp * l.n_pad + n].copy_(pf[:n], non_blocking=True)
         pf = f['packed2']
-      call('st_conv1d_fft_filters_f32', self._ptr(pf), None, f['width'], f['cin'], l.cout, f['cin_pitch'], l.cout_pitch,
-           self._ptr(f['tables']), self._ptr(f['gfwd']), None, self.stream_ptr)
+      call('st_conv1d_fft_filters_f32', self._ptr(pf), f['width'], f['cin'], l.cout, f['cin_pitch'], self._ptr(f['tables']),
+           self._ptr(f['gfwd']), self.stream_ptr)
       if stream is getattr(self, '_side', None):
         ev = torch.cuda.Event()
         ev.record(stream)
@@ -921,7 +916,7 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16':
       if not self._wtplanes_fresh and hasattr(self, 'WTb'):
         self._on_side_stream(lambda: self._refresh_bf16_filters(True))
-    elif not self._packed_t_fresh or (self.fft and not self._gbwd_fresh):
+    elif not self._packed_t_fresh and self._flip_layers():
       self._on_side_stream(self._refresh_backward_operands)
     self._wait_uploads()
     call('st_ctc_loss_grad_hilo_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
@@ -933,32 +928,38 @@ class Wav2LetterEngine:
         self.ctc_status.index_fill_(0, torch.as_tensor(self._rejected_labels, dtype=torch.int64).to(self.device, non_blocking=True), 2)
     call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
 
+  def _transposed_in_place(self, i):
+    """Back-prop to the input of layer i reads the layer's own packed filters as a transposed operand
+    (st_conv1d_1tap_bwd_data_bias_f32): one tap, whole 32-deep k-tiles over the output channels."""
+    l = self.layers[i]
+    return (self.conv_mode == 'fp32' and i > 0 and l.width == 1 and l.stride == 1 and l.cout_pitch % 32 == 0 and
+            l.n_pad >= l.cout_pitch and l.nt_pad % 128 == 0 and os.environ.get('ST_BWD_TRANSPOSED', '1') != '0')
+
+  def _flip_layers(self):
+    """Layers whose back-prop to the input still needs the flipped / transposed copy of the weights: W-tap layers of
+    more than one tap (and everything on the bf16x6 path, whose operand planes are split from those copies).  The
+    frequency-domain layers read their forward spectra transposed, 1-tap layers their packed filters (round 4): at the
+    model's training shapes NO copy is rebuilt any more (rounds 1-3: ~0.33 ms of HBM-bound launches per step)."""
+    if self.conv_mode == 'bf16':
+      return []
+    return [i for i in range(1, len(self.layers))
+            if self.conv_mode == 'bf16x6' or not ((i in self.fft and self.fft_conv) or self._transposed_in_place(i))]
+
   def _refresh_backward_operands(self):
-    """The filter operands of back-prop to the input from the current weights -- the flipped / transposed copy of every
-    layer and, for a frequency-domain layer, its spectra in the back-prop layout -- top layer first, the order
-    back-prop consumes them in; an event after each layer lets the compute stream wait for what it is about to use
-    only (the 32-tap layer's 0.15 ms are needed 2 ms into the backward pass)."""
+    """The flipped / transposed weight copies of the layers that still need one (`_flip_layers`), top layer first, the order
+    back-prop consumes them in; an event after each lets the compute stream wait for what it is about to use only."""
     s = self.stream_ptr
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    flips, spectra = not self._packed_t_fresh, bool(self.fft) and self.fft_conv and not self._gbwd_fresh
     self._bwd_ready = {}
-    for i in reversed(range(1, len(self.layers))):
+    for i in reversed(self._flip_layers()):
       l = self.layers[i]
-      if flips:
-        call('st_filters_flip_transpose_f32', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
-             l.cout_pitch, self._ptr(self.packed_t[i]), s)
-      if spectra and i in self.fft:
-        f = self.fft[i]
-        call('st_conv1d_fft_filters_f32', None, self._ptr(self.packed_t[i]), f['width'], f['cin'], l.cout, f['cin_pitch'],
-             l.cout_pitch, self._ptr(f['tables']), None, self._ptr(f['gbwd']), s)
+      call('st_filters_flip_transpose_f32', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
+           l.cout_pitch, self._ptr(self.packed_t[i]), s)
       ev = torch.cuda.Event()
       ev.record(stream)
       self._bwd_ready[i] = ev
-    if flips:
-      self._packed_t_fresh = True
-      self._wtplanes_fresh = False
-    if spectra:
-      self._gbwd_fresh = True
+    self._packed_t_fresh = True
+    self._wtplanes_fresh = False
 
   def _wait_bwd_operands(self, i=None):
     """The compute stream waits for the back-prop operands of layer i (None: of every layer) if they were rebuilt on the
@@ -979,8 +980,12 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16':
       self._join_side_stream()
       return self._backward_bf16(on_layer_done)
-    if not self._packed_t_fresh or (self.fft and self.fft_conv and not self._gbwd_fresh):
-      self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad)
+    if not self._packed_t_fresh:
+      self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad; nothing at the model's shapes)
+    if self.fft and self.fft_conv and not self._gfwd_fresh:
+      self._join_side_stream()                    # (weights written after the forward pass: back-prop reads the same spectra)
+      self._refresh_fft_filters()
+    self._wait_gfwd()
     if self.conv_mode == 'bf16x6':
       self._wait_bwd_operands()                   # the split planes are derived from all transposed copies at once
     # waits per layer; after the two layers on top one wait covers everything below (by then the side stream is through)
@@ -1062,18 +1067,21 @@ class Wav2LetterEngine:
              self.geo[i][2], act, self.dZ[i - 1].ref, dxp, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i > 0 and i in self.fft and self.fft_conv:
         f = self.fft[i]
-        self._wait_bwd_operands(i if i > wait_all_below else None)
         act = self.X[i].ref if self.layers[i - 1].relu else None
-        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gbwd']), l.width,
+        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gfwd']), l.width,
              self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1
         act = self.X[i].ref if self.layers[i - 1].relu else None
-        self._wait_bwd_operands(i if i > wait_all_below else None)
-        call('st_conv1d_nwc_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
-             act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
-             self.wgrad_ws.numel() * 4, s)
+        if self._transposed_in_place(i):           # dx = dz W^T straight from the layer's packed filters
+          call('st_conv1d_1tap_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self._slice(self.params, i)[0]), act, self.dZ[i - 1].ref,
+               self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+        else:
+          self._wait_bwd_operands(i if i > wait_all_below else None)
+          call('st_conv1d_nwc_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
+               act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
+               self.wgrad_ws.numel() * 4, s)
         bias_from_above = True
       if deferred == i and on_layer_done is not None:
         # the gradient of this layer is complete when the side stream is: hand it to the all-reduce only now, with

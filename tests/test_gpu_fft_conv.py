@@ -69,9 +69,8 @@ def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
 
   tables = torch.zeros(lib.st_conv1d_fft_table_floats(), device=dev)
   call('st_conv1d_fft_tables_f32', W, pl, P(tables), tables.numel(), None)
-  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cin, cout, 0), device=dev)
-  gbwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cin, cout, 1), device=dev)
-  call('st_conv1d_fft_filters_f32', P(packed), P(packed_t), W, cin, cout, cpi, cpo, P(tables), P(gfwd), P(gbwd), None)
+  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W, cpi, cout), device=dev)
+  call('st_conv1d_fft_filters_f32', P(packed), W, cin, cout, cpi, P(tables), P(gfwd), None)
   sf = torch.empty(lib.st_conv1d_fft_sf_floats(xt.ref, yt.ref, W), device=dev)
   zf = torch.empty(lib.st_conv1d_fft_zf_floats(dzt.ref, W), device=dev)
   ws = torch.empty(lib.st_conv1d_fft_ws(xt.ref, yt.ref, W) // 4 + 64, device=dev)
@@ -85,7 +84,7 @@ def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
   assert float(whole[:, :, cout:].abs().max()) == 0.0 and float(whole[:, :yt.halo].abs().max()) == 0.0
 
   call('st_conv1d_fft_dz_spectra_f32', dzt.ref, W, P(tables), P(zf), None)
-  call('st_conv1d_nwc_bwd_data_fft_f32', dzt.ref, P(zf), P(gbwd), W, pl, act.ref, dxt.ref, P(tables), P(ws), ws.numel() * 4, None)
+  call('st_conv1d_nwc_bwd_data_fft_f32', dzt.ref, P(zf), P(gfwd), W, pl, act.ref, dxt.ref, P(tables), P(ws), ws.numel() * 4, None)
   dx = dxt.interior().cpu().numpy()
   assert np.max(np.abs(dx - dx_ref)) < 2e-5 * np.max(np.abs(dx_ref))
 
@@ -154,8 +153,8 @@ def test_stride2_layer_on_its_polyphase_view(dev, B, T, cin, cout):
   bias_d[:cout] = torch.as_tensor(bias, dtype=torch.float32)
   tables = torch.zeros(lib.st_conv1d_fft_table_floats(), device=dev)
   call('st_conv1d_fft_tables_f32', W2, pl2, P(tables), tables.numel(), None)
-  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W2, 2 * cp, 2 * cp, cout, 0), device=dev)
-  call('st_conv1d_fft_filters_f32', P(packed2), None, W2, 2 * cp, cout, 2 * cp, cpo, P(tables), P(gfwd), None, None)
+  gfwd = torch.empty(lib.st_conv1d_fft_filter_floats(W2, 2 * cp, cout), device=dev)
+  call('st_conv1d_fft_filters_f32', P(packed2), W2, 2 * cp, cout, 2 * cp, P(tables), P(gfwd), None)
   sf = torch.empty(lib.st_conv1d_fft_sf_floats(x2ref, yt.ref, W2), device=dev)
   zf = torch.empty(lib.st_conv1d_fft_zf_floats(dzt.ref, W2), device=dev)
   ws = torch.empty(lib.st_conv1d_fft_ws(x2ref, yt.ref, W2) // 4 + 64, device=dev)
@@ -251,11 +250,12 @@ def test_training_steps_agree_between_frequency_and_w_tap_kernels(dev):
     assert np.max(np.abs(ba - bb)) < 2e-4 * max(np.max(np.abs(bb)), 1e-3)
 
 
+@pytest.mark.parametrize('bt', [False, True])
 @pytest.mark.parametrize('slots', [64, 96])
 @pytest.mark.parametrize('bins,M,K,N', [(36, 256, 512, 512), (45, 256, 384, 512), (36, 128, 512, 512), (3, 256, 512, 512),
                                        (48, 256, 4096, 512), (48, 256, 512, 4096), (33, 256, 512, 512), (5, 64, 32, 128),
                                        (37, 192, 96, 256), (20, 256, 512, 512)])
-def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, slots):
+def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, slots, bt):
   """st_gemm_nn_batched_ws_f32: a launch whose 64 x 128 tiles would load the CUs unevenly (36 bins of the 7-tap layers: 576
   tiles, three on a quarter of the CUs and two on the rest) runs as ONE persistent launch that deals the (bin, tile, k-tile)
   list in equal runs to 8 x 64 or 8 x 96 workgroups (csrc/streamk_map.h); a tile cut into pieces is summed head + next + ...
@@ -263,13 +263,16 @@ def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, 
   content, while another stream keeps part of the chip busy (uneven load: the hand-off must not depend on who runs when) and
   with the reading CUs' caches warm from the previous repetition; flags back at zero and no poll timed out; within fp32
   rounding of the plain launch.  Other shapes are forced through the kernel (st_set_tuning("streamk", 1)): whole tiles only,
-  several pieces per tile (K = 4096 on 96 workgroups per XCD: 3 pieces), XCDs without tiles."""
+  several pieces per tile (K = 4096 on 96 workgroups per XCD: 3 pieces), XCDs without tiles.  bt: the second operand given
+  transposed ([n][k], what back-prop to the input reads the forward filter spectra as)."""
   from speecht_amd import _lib
   from speecht_amd._lib import call, launch_trace, set_tuning
   lib = _lib.load()
   rng = np.random.default_rng(bins * 1000 + K)
   A = torch.as_tensor(rng.standard_normal((bins, M, K)), dtype=torch.float32).to(dev)
   B = torch.as_tensor(rng.standard_normal((bins, K, N)) / np.sqrt(K), dtype=torch.float32).to(dev)
+  Bop = B.transpose(1, 2).contiguous() if bt else B               # [bins][N][K] when transposed
+  entry = 'st_gemm_nn_batched_bt_ws_f32' if bt else 'st_gemm_nn_batched_ws_f32'
   P = lambda t: ctypes.c_void_p(t.data_ptr())
   ws_bytes, ctrl_words = lib.st_gemm_nn_batched_ws_bytes(), lib.st_gemm_nn_batched_ctrl_bytes() // 4
   ws = torch.full((ws_bytes // 4,), float('nan'), dtype=torch.float32, device=dev)            # scratch: any content
@@ -291,7 +294,7 @@ def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, 
         with torch.cuda.stream(side):
           busy @ busy
       with launch_trace() as tr:
-        call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(ws), ws_bytes, None)
+        call(entry, P(A), K, M * K, P(Bop), K * N, P(C), N, M * N, M, K, N, bins, P(ws), ws_bytes, None)
       torch.cuda.synchronize()
       outs.append(C)
   finally:
@@ -299,9 +302,9 @@ def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, 
     set_tuning('streamk_slots', 0)
   line = tr.lines[0]
   if whole_rounds:
-    assert line.startswith('gemm_nn<'), line
+    assert line.startswith('gemm_nn<') and ('fast-bt' in line) == bt, line
   else:
-    assert line.startswith('gemm_nn_bins<64,128,2,2> batched') and ' streamk ' in line, line
+    assert line.startswith('gemm_nn_bins<64,128,2,2,bt> batched' if bt else 'gemm_nn_bins<64,128,2,2> batched') and ' streamk ' in line, line
     if bins == 36 and M == 256 and N == 512 and K == 512:
       assert ('wgs=512 upw=18' if slots == 64 else 'wgs=768 upw=12') in line, line
     assert int(ws[:ctrl_words].view(torch.int32).abs().sum()) == 0     # flags taken back, the timeout count still zero
@@ -312,6 +315,64 @@ def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, 
   err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
   assert err < tol, err
   plain = torch.empty_like(outs[0])
-  call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(plain), N, M * N, M, K, N, bins, None)
+  if bt:                                                       # without scratch: the plain transposed-operand launch
+    call(entry, P(A), K, M * K, P(Bop), K * N, P(plain), N, M * N, M, K, N, bins, None, 0, None)
+  else:
+    call('st_gemm_nn_batched_f32', P(A), K, M * K, P(B), K * N, P(plain), N, M * N, M, K, N, bins, None)
   torch.cuda.synchronize()
   assert float((plain.double() - ref).abs().max() / ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize('B,T,cin,cout,relu_below', [(3, 70, 2000, 2000, True), (2, 333, 2000, 29, True), (4, 40, 250, 2000, False),
+                                                     (1, 5, 130, 64, True)])
+def test_one_tap_back_prop_reads_the_forward_filters_transposed(dev, B, T, cin, cout, relu_below):
+  """st_conv1d_1tap_bwd_data_bias_f32 (the two 1 x 1 layers on top, speech_model.py:288,292): dx = mask * (dz W^T) and the
+  column sums of dx (the bias gradient of the layer below) straight from the layer's packed filters -- against the oracle
+  and against the flipped / transposed-copy form it replaces (same arithmetic per element: equal to fp32 rounding of the
+  reduction order, which is the same k order -> bit-identical dx)."""
+  from speecht_amd import _lib
+  from speecht_amd._lib import call
+  from speecht_amd.engine import channel_pitch
+  lib = _lib.load()
+  rng = np.random.default_rng(B * 1000 + cout)
+  x = rng.standard_normal((B, T, cin))
+  F = rng.standard_normal((1, cin, cout)) / np.sqrt(cin)
+  dz = rng.standard_normal((B, T, cout))
+  prev_act = rng.standard_normal(x.shape)
+  y = O.conv1d_same_fwd(x, F, np.zeros(cout), 1, False)
+  dx_ref, _, _ = O.conv1d_same_bwd(x, F, y, dz, 1, False)
+  if relu_below:
+    dx_ref = dx_ref * (prev_act > 0)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  cpi, cpo = channel_pitch(cin), channel_pitch(cout)
+  kv, kp, npad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  call('st_packed_dims', 1, cpi, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+  packed = torch.zeros(kp.value * npad.value, device=dev)
+  call('st_pack_filters_f32', P(torch.as_tensor(F, dtype=torch.float32).to(dev).contiguous()), 1, cin, cout, cpi, P(packed), None)
+  call('st_packed_dims', 1, cpo, cin, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+  packed_t = torch.zeros(kp.value * npad.value, device=dev)
+  call('st_filters_flip_transpose_f32', P(packed), 1, cin, cout, cpi, cpo, P(packed_t), None)
+  npi = npad.value
+  dzt = dev_tensor(dev, B, T, cout, 0, 0, dz)
+  act = dev_tensor(dev, B, T, cin, 0, 0, prev_act)
+  outs = []
+  for transposed in (True, False):
+    dxt = dev_tensor(dev, B, T, cin, 2, 1)
+    dxt.buf.fill_(float('nan'))
+    call('st_zero_halos_f32', dxt.ref, None)
+    db = torch.full((npi,), 7.0, device=dev)
+    ws = torch.empty(lib.st_conv1d_bwd_data_bias_ws(dzt.ref, dxt.ref, 1) // 4 + 64, device=dev)
+    if transposed:
+      call('st_conv1d_1tap_bwd_data_bias_f32', dzt.ref, P(packed), act.ref if relu_below else None, dxt.ref, P(db), P(ws),
+           ws.numel() * 4, None)
+    else:
+      call('st_conv1d_nwc_bwd_data_bias_f32', dzt.ref, P(packed_t), 1, 0, act.ref if relu_below else None, dxt.ref, P(db), P(ws),
+           ws.numel() * 4, None)
+    torch.cuda.synchronize()
+    dx = dxt.interior().cpu().numpy()
+    assert np.max(np.abs(dx - dx_ref)) < 2e-5 * np.max(np.abs(dx_ref))
+    assert np.max(np.abs(db[:cin].cpu().numpy() - dx_ref.reshape(-1, cin).sum(axis=0))) < 2e-5 * np.max(np.abs(dx_ref)) * np.sqrt(B * T)
+    whole = dxt.buf.view(B, dxt.t_pitch, dxt.c_pitch)
+    assert float(whole[:, :, cin:].nan_to_num(nan=0.0).abs().max()) == 0.0 if dxt.c_pitch > cin else True
+    outs.append(dxt.interior().clone())
+  assert torch.equal(outs[0], outs[1])

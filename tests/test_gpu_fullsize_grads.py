@@ -122,9 +122,10 @@ def test_fullsize_fp32_gradients_match_float64_reference(case):
   text = '\n'.join(trace)
   # the benchmark's kernels, not the small-problem ones
   fwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=0')]
-  bwd_fast = [l for l in trace if l.startswith('gemm_nn<128,128,2,2,fast> epi=1')]
+  bwd_fast = [l for l in trace if l.startswith(('gemm_nn<128,128,2,2,fast> epi=1', 'gemm_nn<128,128,2,2,fast-bt> epi=1'))]
   assert len(fwd_fast) == 9, text                                  # L1..L9 forward
   assert len(bwd_fast) == 10, text                                 # back-prop to the input of L10..L1
+  assert sum('fast-bt' in l for l in bwd_fast) == 2, text          # the two 1-tap layers read their packed filters transposed
   assert any('splits=2' in l and 'Kp=64512' in l for l in bwd_fast), text        # L8 back-prop: 2 K-halves
   slabbed = [l for l in trace if l.startswith('gemm_tn<') and 'slabs=1 ' not in l]
   assert len(slabbed) >= 9 and all('M=16032' in l for l in trace if l.startswith('gemm_tn<')), text

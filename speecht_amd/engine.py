@@ -114,6 +114,61 @@ class _PendingDecode:
     return [ids[b, :lens[b]].tolist() for b in range(self._batch)]
 
 
+class _PendingBeamDecode:
+  """Prefix-beam-search outputs on their way to pinned host memory (``Wav2LetterEngine.beam_search_decode_async``):
+  ``result()`` waits for that batch only and returns (list of id lists, log_prob [B, 1])."""
+
+  def __init__(self, slot, batch, t_out):
+    self._slot, self._batch, self._t_out = slot, batch, t_out
+
+  def result(self):
+    s = self._slot
+    s['event'].synchronize()
+    lens = s['lens_h'][:self._batch].numpy()
+    ids = s['ids_h'][:self._batch * self._t_out].numpy().reshape(self._batch, self._t_out)
+    return ([ids[b, :lens[b]].tolist() for b in range(self._batch)],
+            s['score_h'][:self._batch].numpy().reshape(-1, 1).copy())
+
+
+def decoder_stream_pair(device):
+  """(compute stream, decoder stream) for overlapping a one-wave-per-utterance decoder with the NEXT batch's forward pass.
+
+  fp32 MFMAs execute on the VALU datapath: a VALU / LDS chain that shares its SIMD with the waves of an fp32 GEMM gets an
+  issue slot every ~25 cycles instead of every ~4 (measured round 4: the CTC recursion under a GEMM 122 -> 560 us, the beam
+  search beside the next forward pass 3.9 -> 6.5 ms per batch).  So the two run on DISJOINT compute units: streams created
+  with hipExtStreamCreateWithCUMask, the decoder on 16 CUs (mask bits 0..15 -- observed on MI355X: two CUs of every XCD; any
+  other layout tried costs the GEMMs 10-70 %), the forward pass on the other 240 (+11 % on the forward pass alone, 3.6 -> 4.0
+  ms at configs[4]; overlapped 4.4 ms per batch against 8.0 serial).  Placement is a matter of speed only.  Falls back to two
+  plain streams where the runtime lacks the call."""
+  import ctypes as C
+  import glob
+  key = str(device)
+  if key in _DECODER_STREAMS:
+    return _DECODER_STREAMS[key]
+  pair = None
+  if os.environ.get('ST_DECODER_CU_MASK', '1') != '0':
+    try:
+      hip = C.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64*'))[0])
+      made = []
+      with torch.cuda.device(device):
+        for words in ([0x0000ffff] + [0] * 7, [0xffff0000] + [0xffffffff] * 7):
+          arr = (C.c_uint32 * 8)(*words)
+          handle = C.c_void_p()
+          if hip.hipExtStreamCreateWithCUMask(C.byref(handle), 8, arr) != 0 or not handle.value:
+            raise OSError('hipExtStreamCreateWithCUMask failed')
+          made.append(torch.cuda.ExternalStream(handle.value, device=device))
+      pair = (made[1], made[0])
+    except (OSError, IndexError, AttributeError):
+      pair = None
+  if pair is None:
+    pair = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+  _DECODER_STREAMS[key] = pair
+  return pair
+
+
+_DECODER_STREAMS = {}
+
+
 class _StagedHostBatch:
   """One of the engine's two H2D staging buffers: ``event`` = copy finished, ``consumed`` = the compute stream has
   read it (``Wav2LetterEngine.stage_host_batch`` / ``load_batch``)."""
@@ -1162,6 +1217,56 @@ class Wav2LetterEngine:
     lens = self.dec_lens.cpu().numpy()
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
     return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
+
+  def beam_search_decode_async(self, beam_width=16, decode_stream=None):
+    """``beam_search_decode`` without the host synchronisation and OFF the compute stream: the logits and lengths of this
+    batch are copied into one of two decoder slots, the search runs on ``decode_stream`` (default: a stream of the engine's
+    own; `decoder_stream_pair` gives a CU-masked one) and its outputs go to pinned host memory; returns a handle whose
+    ``result()`` waits for this batch only.  The caller enqueues the next batch's forward pass meanwhile -- the search is ONE
+    wavefront per utterance (3.9 ms for 16 x 30 s, beam 16: as long as the forward pass) and leaves the chip to it."""
+    lib = _lib.load()
+    B, T = self.dec_lens.numel(), self.t_out
+    xl = self.X[-1]
+    need = lib.st_ctc_beam_ws(B, T, int(beam_width))
+    if not hasattr(self, '_beam_slots'):
+      self._beam_slots, self._beam_turn = [None, None], 0
+    self._beam_turn ^= 1
+    slot = self._beam_slots[self._beam_turn]
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    if decode_stream is None:
+      if getattr(self, '_decode_stream', None) is None:
+        self._decode_stream = torch.cuda.Stream(self.device)
+      decode_stream = self._decode_stream
+    if slot is None or slot['logits'].numel() < xl.buf.numel() or slot['ids'].numel() < B * T or slot['ws'].numel() * 4 < need or \
+        slot['lens'].numel() < B:
+      if slot is not None:
+        slot['event'].synchronize()                               # the old buffers may still be in use
+      i32 = lambda n, **kw: torch.empty(max(n, 1), dtype=torch.int32, **kw)
+      slot = dict(logits=torch.empty(xl.buf.numel(), dtype=torch.float32, device=self.device), lens=i32(B, device=self.device),
+                  ids=i32(B * T, device=self.device), out_lens=i32(B, device=self.device),
+                  score=torch.empty(max(B, 1), dtype=torch.float32, device=self.device), ws=i32(need // 4 + 16, device=self.device),
+                  ids_h=i32(B * T, pin_memory=True), lens_h=i32(B, pin_memory=True),
+                  score_h=torch.empty(max(B, 1), dtype=torch.float32, pin_memory=True), event=torch.cuda.Event())
+      slot['event'].record(decode_stream)
+      self._beam_slots[self._beam_turn] = slot
+    self._wait_uploads()
+    main.wait_event(slot['event'])                               # the search that last read this slot is through
+    with torch.cuda.stream(main):
+      slot['logits'][:xl.buf.numel()].copy_(xl.buf, non_blocking=True)
+      slot['lens'][:B].copy_(self.ctc_lens, non_blocking=True)
+      ready = torch.cuda.Event()
+      ready.record(main)
+    desc = Tensor3(slot['logits'].data_ptr(), xl.batch, xl.frames, xl.channels, xl.halo, xl.t_pitch, xl.c_pitch)
+    decode_stream.wait_event(ready)
+    call('st_ctc_beam_search_decode', ctypes.byref(desc), self._ptr(slot['lens']), int(beam_width), self._ptr(slot['ids']), T,
+         self._ptr(slot['out_lens']), self._ptr(slot['score']), self._ptr(slot['ws']), slot['ws'].numel() * 4,
+         ctypes.c_void_p(decode_stream.cuda_stream))
+    with torch.cuda.stream(decode_stream):
+      slot['ids_h'][:B * T].copy_(slot['ids'][:B * T], non_blocking=True)
+      slot['lens_h'][:B].copy_(slot['out_lens'][:B], non_blocking=True)
+      slot['score_h'][:B].copy_(slot['score'][:B], non_blocking=True)
+      slot['event'].record(decode_stream)
+    return _PendingBeamDecode(slot, B, T)
 
   def fetch_losses(self, precise=False):
     """Per-utterance CTC losses [B] on the host, after checking the status words: both arrays come back in one

@@ -556,6 +556,42 @@ def test_bucketed_inference_matches_oracle_per_bucket(dev):
   assert len(transcribe(eng, feats[:4], batch_size=2)[0]) == 4          # and the engine is still usable
 
 
+def test_pipelined_beam_search_matches_the_serial_loop_and_the_oracle(dev):
+  """inference.transcribe(beam_width=...): the prefix beam search of batch k on a decoder stream of its own (CU-masked where
+  the runtime has hipExtStreamCreateWithCUMask) under the forward pass of batch k + 1, logits double-buffered -- the ids of
+  every utterance equal the serial loop's and, batch by batch, the oracle's search on the device's own logits; the async
+  entry point alone returns what the synchronous one returns (ids and log-probabilities)."""
+  from speecht_amd.inference import transcribe
+  layers = WL.w2l_layers(16, width=40, fc=72)
+  params = WL.xavier_params(layers, seed=21, bias_range=0.3)
+  # sharper logits than a fresh network's (near-flat rows make every candidate a near tie): scale up the top layer
+  params[-1] = (params[-1][0] * 12.0, params[-1][1] * 4.0)
+  rng = np.random.default_rng(8)
+  lengths = rng.integers(60, 260, 21).tolist()
+  feats = [WL.synthetic_features(300 + i, t, 16).astype(np.float32) for i, t in enumerate(lengths)]
+  eng = make_engine(layers, dev)
+  eng.set_weights(params)
+  for bucket in (True, False):
+    a, _ = transcribe(eng, feats, batch_size=4, bucket=bucket, pipeline=True, beam_width=8)
+    b, _ = transcribe(eng, feats, batch_size=4, bucket=bucket, pipeline=False, beam_width=8)
+    assert a == b and any(len(s) > 0 for s in a)
+  # against the oracle's search on the device's own logits, one batch; and async == sync
+  idx = list(range(4))
+  x, seq, _ = O.pad_batch([feats[i].astype(np.float64) for i in idx], 16)
+  eng.load_batch(x, seq)
+  eng.forward()
+  sync_ids, sync_lp = eng.beam_search_decode(8)
+  async_ids, async_lp = eng.beam_search_decode_async(8).result()
+  assert async_ids == sync_ids and np.array_equal(async_lp, sync_lp)
+  torch.cuda.synchronize()
+  logits = eng.logits_time_major().cpu().numpy().astype(np.float64)
+  ref_ids, ref_lp = O.ctc_beam_search_decode(logits, seq // 2, 8)
+  assert sync_ids == ref_ids
+  np.testing.assert_allclose(sync_lp, ref_lp, rtol=1e-4, atol=1e-4)
+  serial, _ = transcribe(eng, [feats[i] for i in idx], batch_size=4, bucket=False, pipeline=False, beam_width=8)
+  assert serial == ref_ids
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16x6'])
 @pytest.mark.parametrize('frames', [[1], [7, 3, 5], [48, 47, 2, 31, 96]])
 def test_odd_shapes_mfcc_width(dev, mode, frames):

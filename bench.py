@@ -483,6 +483,58 @@ def attach_pmc_profiles(roofline):
       roofline['mfma_busy_pmc'] = data.get(key, {}).get('mfma_busy_frac_at_2p4ghz')
 
 
+class c_stdout_to_stderr:
+  """RCCL prints a version banner to the C-level stdout when a communicator is created; the driver reads ONE JSON line from
+  stdout.  Inside this context file descriptor 1 is stderr (and C stdio is flushed before it comes back)."""
+
+  def __enter__(self):
+    import ctypes
+    self._libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    self._libc.fflush(None)
+    self._saved = os.dup(1)
+    os.dup2(2, 1)
+    return self
+
+  def __exit__(self, *exc):
+    sys.stdout.flush()
+    self._libc.fflush(None)
+    os.dup2(self._saved, 1)
+    os.close(self._saved)
+    return False
+
+
+def comm_probe_world1(eng, feed, lr, global_batch, steps, ahead):
+  """What the data-parallel plumbing costs a step on ONE GPU: the same steps with the four-bucket exchange forced through the
+  library's RCCL communicator at world size 1 (per-layer hooks, the collective stream, its events, ncclAllReduce launches
+  beside back-prop) against the plain steps.  It cannot show what the transfers of N > 1 cost the GEMMs (a 1-rank all-reduce
+  moves nothing over xGMI); it bounds everything else."""
+  try:
+    with c_stdout_to_stderr():
+      probe = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, force=True, transport='rccl')
+  except Exception as e:      # noqa: BLE001
+    return dict(error=repr(e))
+  res = {}
+  for name, red in (('compute_only_ms', None), ('with_collective_ms', probe), ('compute_only_ms_again', None)):
+    for _ in range(3):
+      train_step(eng, feed, red, lr, global_batch)
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event() for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+      if ahead and k >= ahead:
+        marks[k - ahead].synchronize()
+      train_step(eng, feed, red, lr, global_batch)
+      marks[k].record()
+    torch.cuda.synchronize()
+    res[name] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+  res.update(library_comm=probe.comm.count(), buckets=len(probe.buckets),
+             note='world size 1: hooks + collective stream + ncclAllReduce launches, no xGMI traffic')
+  with c_stdout_to_stderr():
+    probe.comm.close()
+  return res
+
+
 def free_port():
   with socket.socket() as sk:
     sk.bind(('127.0.0.1', 0))
@@ -519,7 +571,8 @@ def main():
   ap.add_argument('--conv-mode', choices=('fp32', 'bf16x6', 'bf16'), default=None,
                   help='arithmetic of the timed loop (default fp32 = BASELINE configs[1]; bf16 = configs[3] arithmetic)')
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
-                  help='gradient exchange transport: torch.distributed (default) or the library\'s st_allreduce_* (RCCL)')
+                  help='gradient exchange transport: the library\'s own RCCL communicator behind the C ABI (st_allreduce_buckets_f32; '
+                       'default for --gpus > 1, falls back to torch.distributed if it cannot be set up) or torch.distributed')
   ap.add_argument('--tune', action='append', default=[], help='name=value override of a library policy (st_set_tuning; experiments only)')
   args = ap.parse_args()
   for kv in args.tune:
@@ -541,10 +594,13 @@ def main():
     if os.environ.get('ST_SHARE_GPU'):
       local_rank = 0
     torch.cuda.set_device(local_rank)
-    if backend == 'nccl':
-      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    else:
-      dist.init_process_group(backend, rank=rank, world_size=world)
+    with c_stdout_to_stderr():                     # (RCCL's version banner goes to the C stdout of rank 0)
+      if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.all_reduce(torch.zeros(1, device=torch.device('cuda', local_rank)))      # the communicator exists from here on
+        torch.cuda.synchronize()
+      else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
   assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus)
   dev = torch.device('cuda', local_rank)
   torch.cuda.set_device(dev)
@@ -562,7 +618,33 @@ def main():
           file=sys.stderr)
     sys.exit(3)
   feed = HostFeed(eng, x, seq_lens, labels)
-  reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, force=args.force_allreduce, transport=args.allreduce) if (world > 1 or args.force_allreduce) else None
+  reducer, transport_note = None, None
+  if world > 1 or args.force_allreduce:
+    # Default transport for N > 1: the library's own RCCL communicator (the C ABI's st_comm_* / st_allreduce_buckets_f32) -- but
+    # only if it really spans the job: its rank count (ncclCommCount) must equal the world size on every rank, else every rank
+    # falls back to torch.distributed together and the line says so.
+    # (ranks that share one GPU -- the ST_SHARE_GPU test knob -- cannot form an RCCL communicator: torch.distributed there)
+    want = args.allreduce or os.environ.get('ST_ALLREDUCE') or ('rccl' if (world > 1 and not os.environ.get('ST_SHARE_GPU')) else 'torch')
+    if want == 'rccl':
+      ok = 1
+      try:
+        with c_stdout_to_stderr():
+          reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, force=args.force_allreduce, transport='rccl')
+        ok = int(reducer.comm is not None and reducer.comm.count() == world)
+      except Exception as e:      # noqa: BLE001 -- whatever the set-up raises, the exchange must still happen somehow
+        ok, transport_note = 0, 'library communicator failed: %r' % (e,)
+      if dist.is_initialized() and world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag[0])
+      if not ok:
+        transport_note = transport_note or 'library communicator does not span the job (count != world) on some rank'
+        if args.allreduce == 'rccl':
+          print('bench.py: --allreduce rccl asked for, but ' + transport_note, file=sys.stderr)
+          sys.exit(5)
+        reducer = None
+    if reducer is None:
+      reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, force=args.force_allreduce, transport='torch')
   global_batch = args.batch * world
   lr = 1e-4
 
@@ -650,7 +732,9 @@ def main():
     # who is really exchanging: torch.distributed's view and -- with the library transport -- the RCCL communicator's own count
     ranks_info = dict(torch_distributed=dist.get_world_size() if dist.is_initialized() else 1,
                       backend=dist.get_backend() if dist.is_initialized() else None,
-                      library_comm=reducer.comm.count() if reducer.comm is not None else None, transport=reducer.transport)
+                      library_comm=reducer.comm.count() if reducer.comm is not None else None, transport=reducer.transport,
+                      library_comm_spans_job=(reducer.comm.count() == world) if reducer.comm is not None else None,
+                      fallback=transport_note)
     if world > 1 and not replicas_identical:
       if rank == 0:
         print('bench.py: the replicas are NOT bit-identical after %d data-parallel steps (rccl_ranks %s): the exchange is '
@@ -688,7 +772,8 @@ def main():
                    'allreduce': reducer.transport if reducer else None},
         'final_avg_loss': round(loss, 4),
         'ctc_loss_delta': parity['ctc_loss_delta'], 'max_logit_err': parity['max_logit_err'],
-        'ctc_loss_delta_kind': 'absolute (reported); the asserted bound is ctc_loss_delta_rel < 1e-4, see parity.asserted',
+        'ctc_loss_delta_kind': 'absolute, ASSERTED < 1e-4: |hi + lo - oracle| of the kernel\'s (hi, lo) loss pair; the fp32 hi part alone '
+                               '(what TF returns) is ctc_loss_delta_fp32_output in `parity`',
         'ctc_loss_delta_rel': parity['ctc_loss_delta_rel'], 'parity': parity,
         'replicas_identical': replicas_identical, 'rccl_ranks': ranks_info,
         'per_rank_ms_per_step': [round(v, 3) for v in rank_ms], 'comm': comm,
@@ -707,6 +792,8 @@ def main():
       attach_pmc_profiles(out['roofline'])
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
+    if world == 1 and reducer is None and eng.conv_mode == 'fp32':
+      out['comm_probe_world1'] = comm_probe_world1(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
       # Side measurements on the same box and inputs, NOT the headline:
       #  * bf16x6 (experimental): fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on the bf16

@@ -144,6 +144,8 @@ def test_bench_rccl_transport_through_the_self_launch_path_at_world_one():
   assert len(lines) == 1, r.stdout
   out = json.loads(lines[0])
   assert out['n_gpus'] == 1 and out['config']['allreduce'] == 'rccl'
-  assert out['rccl_ranks'] == dict(torch_distributed=1, backend='nccl', library_comm=1, transport='rccl'), out['rccl_ranks']
+  assert out['rccl_ranks'] == dict(torch_distributed=1, backend='nccl', library_comm=1, transport='rccl', library_comm_spans_job=True,
+                                   fallback=None), out['rccl_ranks']
+  assert not any(l.strip() and not l.startswith('{') for l in r.stdout.splitlines()), r.stdout      # nothing but the line on stdout
   assert 'gradient all-reduce' in out['step_includes']
   assert out['parity']['passed'] is True and out['roofline']['frac'] > 0

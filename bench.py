@@ -68,7 +68,7 @@ def train_step(eng, feed, reducer, lr, global_batch):
   feed.next()
   eng.forward()
   eng.ctc_loss_grad(1.0 / global_batch)
-  eng.backward(reducer.on_layer_done if reducer else None)
+  eng.backward(reducer.on_layer_done if reducer else None, reducer.hook_layers if reducer else None)
   if reducer:
     reducer.finish()
   eng.apply_update(lr)

@@ -136,6 +136,12 @@ class GradientAllReducer:
     self._compute_stream = compute_stream
     self.comm = RcclCommunicator(flat_grads.device, group) if (self.active and self.transport == 'rccl') else None
 
+  @property
+  def hook_layers(self):
+    """The layers whose completion makes a bucket ready (the lowest layer of each bucket): the only ones
+    ``engine.backward`` has to call ``on_layer_done`` for."""
+    return set(self._ready_at) if self.active else set()
+
   def _stream(self):
     return self._compute_stream if self._compute_stream is not None else torch.cuda.current_stream(self.flat.device)
 

@@ -618,7 +618,7 @@ class Wav2LetterEngine:
            None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None,
            self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4 if self.split_small_batches else 0, s)
 
-  def _backward_bf16(self, on_layer_done):
+  def _backward_bf16(self, on_layer_done, wanted=lambda i: True):
     s, L = self.stream_ptr, len(self.layers)
     if not self._wtplanes_fresh:
       self._refresh_bf16_filters(True)
@@ -640,14 +640,14 @@ class Wav2LetterEngine:
         side = True
       else:
         filter_gradient()
-        if on_layer_done is not None:
+        if on_layer_done is not None and wanted(i):
           on_layer_done(i)
       if i > 0:
         relu_in = self.layers[i - 1].relu
         call('st_conv1d_nwc_bwd_data_bf16', self.dZ[i].ref, self._ptr(self.dZb[i]), self._ptr(self.WTb[i]), l.width,
              self.geo[i][2], self.X[i].ref if relu_in else None, self._ptr(self.Xb[i]) if relu_in else None,
              self.dZ[i - 1].ref, self._ptr(self.dZb[i - 1]), self._ptr(self.wgrad_ws_b), self.wgrad_ws_b.numel() * 4, s)
-      if beside and on_layer_done is not None:
+      if beside and on_layer_done is not None and wanted(i):
         self._join_side_stream()
         side = False
         on_layer_done(i)
@@ -1028,13 +1028,18 @@ class Wav2LetterEngine:
       for k in keys:
         del ready[k]
 
-  def backward(self, on_layer_done=None):
+  def backward(self, on_layer_done=None, hook_layers=None):
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
-    called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce)."""
+    called after layer i's filter/bias gradients have been enqueued (for bucketed all-reduce) -- for every layer, or only
+    for those in ``hook_layers`` (the layers that complete a reduce bucket, `GradientAllReducer.hook_layers`): a hook on a
+    layer whose filter gradient runs on the side stream makes the compute stream WAIT for that stream first, so hooks
+    nobody needs cost the overlap of the two chains (round 4: a forced world-1 exchange cost the step 0.24 ms, most of it
+    six such waits)."""
     s = self.stream_ptr
+    wanted = (lambda i: True) if hook_layers is None else (lambda i: i in hook_layers)
     if self.conv_mode == 'bf16':
       self._join_side_stream()
-      return self._backward_bf16(on_layer_done)
+      return self._backward_bf16(on_layer_done, wanted)
     if not self._packed_t_fresh:
       self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad; nothing at the model's shapes)
     if self.fft and self.fft_conv and not self._gfwd_fresh:
@@ -1109,7 +1114,7 @@ class Wav2LetterEngine:
       else:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
-      if on_layer_done is not None and deferred != i:
+      if on_layer_done is not None and deferred != i and wanted(i):
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):
         act = self.X[i].ref if self.layers[i - 1].relu else None
@@ -1138,9 +1143,10 @@ class Wav2LetterEngine:
                act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
                self.wgrad_ws.numel() * 4, s)
         bias_from_above = True
-      if deferred == i and on_layer_done is not None:
-        # the gradient of this layer is complete when the side stream is: hand it to the all-reduce only now, with
-        # back-prop to the input already enqueued beside it
+      if deferred == i and on_layer_done is not None and wanted(i):
+        # the gradient of this layer is complete when the side stream is (and with it those of the layers above that went
+        # the same way: the stream runs in order): hand the bucket to the all-reduce only now, with back-prop to the input
+        # already enqueued beside it
         self._join_side_stream()
         side_wgrad = False
         on_layer_done(i)

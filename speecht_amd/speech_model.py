@@ -360,7 +360,7 @@ class SpeechModel:
       if update:
         if not self._training:
           raise RuntimeError('add_training_ops() was not called with labelled inputs')
-        eng.backward(self._reducer.on_layer_done if self._reducer else None)
+        eng.backward(self._reducer.on_layer_done if self._reducer else None, self._reducer.hook_layers if self._reducer else None)
         if self._reducer:
           self._reducer.finish()
         eng.apply_update(self.learning_rate.value, self.max_gradient_norm)   # no-op on the device if CTC rejected the batch

@@ -168,6 +168,35 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
                                      const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
                                      void* stream);
 
+/* ---- the same three operations with the per-bin products on the bf16 matrix pipe (round 4) --------------------------------
+ * planes = 1: BASELINE configs[3] arithmetic -- the tensors are read / written in their bf16 form (x_bf16, y_bf16, ...: same
+ *             padded NWC geometry as the descriptor, 2-byte elements), spectra and filter spectra are one bf16 plane; the
+ *             DFTs, the products' accumulation and the inverse DFTs are fp32.
+ * planes = 3: fp32 tensors (the *_bf16 arguments NULL); every spectrum value is split exactly into three bf16 planes and a
+ *             product taken as the six largest cross terms with fp32 accumulation: at least fp32-FMA accuracy at the bf16
+ *             pipe's rate.
+ * Buffers (elements of 2 bytes unless noted): sf_planes / zf_planes = planes x the fp32 form's float count
+ * (st_conv1d_fft_sf_floats / _zf_floats); g_planes, gt_planes = planes x st_conv1d_fft_filter_plane_elems each (the filter
+ * spectra and their per-bin transposes, rebuilt by st_conv1d_fft_filters_planes whenever the weights change); dc = fp32
+ * [rows_pad][n_pad]: the blocks' frame sums (bin 0) kept in fp32 for the bias gradient (st_conv1d_fft_bias_grad_dc_f32 with
+ * rows = batch x blocks); workspace st_conv1d_fft_planes_ws bytes. */
+size_t st_conv1d_fft_filter_plane_elems(int width, int cin_pitch, int cout);
+int st_conv1d_fft_filters_planes(const float* packed, int width, int cin, int cout, int cin_pitch, const float* tables, void* g_planes,
+                                 void* gt_planes, int planes, void* stream);
+size_t st_conv1d_fft_planes_ws(const st_tensor3* x, const st_tensor3* y, int width, int planes);
+int st_conv1d_nwc_fwd_fft_planes(const st_tensor3* x, const void* x_bf16, const void* gt_planes, const float* bias, int width,
+                                 int pad_left, int relu, const st_tensor3* y, void* y_bf16, const float* tables, void* sf_planes,
+                                 int planes, void* workspace, size_t workspace_bytes, void* stream);
+int st_conv1d_fft_dz_spectra_planes(const st_tensor3* dz, const void* dz_bf16, int width, const float* tables, void* zf_planes,
+                                    int planes, float* dc, void* stream);
+int st_conv1d_fft_bias_grad_dc_f32(const float* dc, int rows, int channels, int n_pad, float* dbias, void* stream);
+int st_conv1d_nwc_bwd_data_fft_planes(const st_tensor3* dz, const void* zf_planes, const void* g_planes, int width, int pad_left,
+                                      const st_tensor3* act, const void* act_bf16, const st_tensor3* dx, void* dx_bf16,
+                                      const float* tables, int planes, void* workspace, size_t workspace_bytes, void* stream);
+int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* dz, const void* sf_planes, const void* zf_planes, int width,
+                                        const float* tables, float* dpacked, int planes, void* workspace, size_t workspace_bytes,
+                                        void* stream);
+
 /* ---- K11: back-prop (optimizer.compute_gradients, speech_model.py:78) -------------------
  * bwd_data: dx[b,t,c] = mask * sum_{w,o} dz[b, t + pad_left - w, o] * F[w,c,o]   (stride 1),
  *   mask = (act[b,t,c] > 0) when act != NULL (tf.nn.relu's gradient of the producing layer).

@@ -248,6 +248,87 @@ def conv1d_same_bwd(x, filters, y, dy, stride=1, relu=True, need_dx=True):
   return dx, dF, db
 
 
+def block_dft_conv(x, filters, bias, relu=True, dz=None, prev_act=None, store=None, block=64, need_y=True):
+  """The SAME stride-1 convolution of ``conv1d_same_fwd`` (speech_model.py:155,173,177) and its gradients
+  (``conv1d_same_bwd``, speech_model.py:78) in the block-DFT form the frequency-domain kernels compute
+  (speecht_amd/csrc/conv_fft.hip): blocks of ``block`` output frames, N = block + W - 1 point DFTs over real input,
+  one complex channel contraction per bin, overlap-save forward / overlap-add back-prop, lag products for the filters.
+  Exactly equal to the direct form in exact arithmetic (tests/test_oracle_conv_ctc.py); ``store`` (e.g. ``bf16_round``)
+  is the STORAGE MODEL of the bf16-plane variant: applied to the real and imaginary parts of the input spectra S, of the
+  gradient spectra Z and of the filter spectra G -- the three things that variant writes to memory in bf16 -- and nowhere
+  else (transforms, products and inverse transforms accumulate in higher precision).  Not a reference behaviour.
+
+  x [B,T,Cin], filters [W,Cin,Cout] -> y [B,T,Cout]; with dz (gradient wrt the pre-activation output, [B,T,Cout]) also
+  (dx, dfilters, dbias); dx is multiplied by (prev_act > 0) when prev_act is given (the ReLU of the layer below)."""
+  q = store if store is not None else (lambda a: a)
+  W, cin, cout = filters.shape
+  B, T, _ = x.shape
+  V = block
+  N = V + W - 1
+  bins = N // 2 + 1
+  _, pl, _ = same_padding(T, W, 1)
+  blocks = -(-T // V)
+  k = np.arange(bins)[:, None]
+  wk = np.where((k[:, 0] == 0) | (2 * k[:, 0] == N), 1.0, 2.0) / N
+
+  def dft(seg):                                            # [rows, n <= N, C] real -> [bins, rows, C] complex
+    E = np.exp(-2j * np.pi * k * np.arange(seg.shape[1])[None, :] / N)
+    return np.tensordot(E.real, seg, axes=([1], [1])) + 1j * np.tensordot(E.imag, seg, axes=([1], [1]))
+
+  def idft_real(spec, m):                                  # [bins, rows, C] -> points m: [rows, len(m), C]
+    ph = wk[:, None] * np.exp(2j * np.pi * k * np.asarray(m)[None, :] / N)          # [bins, len(m)]
+    out = np.tensordot(ph.real, spec.real, axes=([0], [0])) - np.tensordot(ph.imag, spec.imag, axes=([0], [0]))
+    return np.transpose(out, (1, 0, 2))
+
+  def qc(z):
+    return q(z.real) + 1j * q(z.imag)
+
+  rows = [(b, j) for b in range(B) for j in range(blocks)]
+  xp = np.zeros((B, pl + blocks * V + N, cin))
+  xp[:, pl:pl + T] = x
+  S = qc(dft(np.stack([xp[b, j * V:j * V + N] for b, j in rows])))
+  Gw = np.exp(-2j * np.pi * k * np.arange(W)[None, :] / N)                           # [bins, W]
+  Fw = filters.reshape(W, cin * cout)
+  G = qc((Gw.real @ Fw + 1j * (Gw.imag @ Fw)).reshape(bins, cin, cout))
+  y = None
+  if need_y:
+    Y = np.matmul(S, np.conj(G))
+    yb = idft_real(Y, np.arange(V)) + bias
+    y = np.zeros((B, T, cout))
+    for r, (b, j) in enumerate(rows):
+      n = min(V, T - j * V)
+      y[b, j * V:j * V + n] = yb[r, :n]
+    if relu:
+      y = np.maximum(y, 0.0)
+  if dz is None:
+    return y
+  dzp = np.zeros((B, blocks * V, cout))
+  dzp[:, :T] = dz
+  Z = qc(dft(np.stack([dzp[b, j * V:j * V + V] for b, j in rows])))
+  X = np.matmul(Z, np.transpose(G, (0, 2, 1)))
+  tp = np.arange(V)
+  own, below, above = idft_real(X, tp + pl), idft_real(X, tp + V + pl), idft_real(X, tp - V + pl)
+  ok_below, ok_above = (tp + V + pl < N), (tp - V + pl >= 0)
+  dx = np.zeros((B, T, cin))
+  for r, (b, j) in enumerate(rows):
+    v = own[r].copy()
+    if j > 0:
+      v[ok_below] += below[r - 1][ok_below]
+    if j + 1 < blocks:
+      v[ok_above] += above[r + 1][ok_above]
+    n = min(V, T - j * V)
+    dx[b, j * V:j * V + n] = v[:n]
+  if prev_act is not None:
+    dx = dx * (prev_act > 0)
+  Qs = np.matmul(np.transpose(S, (0, 2, 1)), np.conj(Z))              # lag products per bin [bins, cin, cout]
+  ang = 2 * np.pi * k[:, 0, None] * np.arange(W)[None, :] / N         # [bins, W]
+  cw, sw = wk[:, None] * np.cos(ang), wk[:, None] * np.sin(ang)
+  dF = (cw.T @ Qs.real.reshape(bins, -1) - sw.T @ Qs.imag.reshape(bins, -1)).reshape(W, cin, cout)
+  # (the bias gradient is taken from the UNROUNDED block sums: the kernels keep bin 0 of the gradient spectra in fp32 for it)
+  db = dz.reshape(-1, cout).sum(axis=0)
+  return y, dx, dF, db
+
+
 def wav2letter_layers(input_size, num_classes=29):
   """speech_model.py:275-292: (width, stride, cin, cout, relu) for the 11 layers."""
   layers = [(48, 2, input_size, 250, True)]
@@ -277,17 +358,18 @@ def bf16_round(a):
   return u.view(np.float32).astype(np.float64)
 
 
-def wav2letter_forward(x, params, layers, keep=False, store=None):
+def wav2letter_forward(x, params, layers, keep=False, store=None, spectral=()):
   """speech_model.py:275-295 -> logits time-major [T', B, C] (and the per-layer outputs).
 
   ``store`` (e.g. ``bf16_round``) models reduced-precision storage: it is applied to the input, to the
   filters used in the products and to every layer output that is written back for the next layer -- not to
-  the biases, the accumulation or the logits."""
+  the biases, the accumulation or the logits.  Layers listed in ``spectral`` follow the storage model of the
+  frequency-domain form instead (``block_dft_conv``: spectra rounded, the fp32 master filters' spectra rounded)."""
   q = store if store is not None else (lambda a: a)
   h = q(x)
   acts = [h]
   for i, ((F, b), (W, s, cin, cout, relu)) in enumerate(zip(params, layers)):
-    h = conv1d_same_fwd(h, q(F), b, s, relu)
+    h = block_dft_conv(h, F, b, relu, store=store) if i in spectral else conv1d_same_fwd(h, q(F), b, s, relu)
     if i + 1 < len(layers):
       h = q(h)
     acts.append(h)
@@ -295,15 +377,18 @@ def wav2letter_forward(x, params, layers, keep=False, store=None):
   return (logits, acts) if keep else logits
 
 
-def wav2letter_backward(acts, params, layers, dlogits_tm, store=None):
+def wav2letter_backward(acts, params, layers, dlogits_tm, store=None, spectral=()):
   """Gradients of all filters/biases given d(avg_loss)/d(logits) time-major [T',B,C].
-  ``store``: see wav2letter_forward; also applied to every activation gradient that is written back."""
+  ``store`` / ``spectral``: see wav2letter_forward; ``store`` is also applied to every activation gradient that is written back."""
   q = store if store is not None else (lambda a: a)
   dy = q(np.transpose(dlogits_tm, (1, 0, 2)))
   grads = [None] * len(layers)
   for i in reversed(range(len(layers))):
     (F, b), (W, s, cin, cout, relu) = params[i], layers[i]
-    dx, dF, db = conv1d_same_bwd(acts[i], q(F), acts[i + 1], dy, s, relu, need_dx=(i > 0))
+    if i in spectral:
+      _, dx, dF, db = block_dft_conv(acts[i], F, b, relu, dz=dy * (acts[i + 1] > 0) if relu else dy, store=store, need_y=False)
+    else:
+      dx, dF, db = conv1d_same_bwd(acts[i], q(F), acts[i + 1], dy, s, relu, need_dx=(i > 0))
     grads[i] = (dF, db)
     dy = q(dx) if dx is not None else None
   return grads

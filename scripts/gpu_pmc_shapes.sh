@@ -50,7 +50,7 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('seconds_s', 0.0)):
                   l2_hit_rate=round(d['TCC_HIT_sum'] / max(d['TCC_HIT_sum'] + d['TCC_MISS_sum'], 1.0), 4),
                   l2_requests_m=round((d['TCC_HIT_sum'] + d['TCC_MISS_sum']) / max(d['launches_w'], 1.0) / 1e6, 2),
                   mfma_busy_frac_at_2p4ghz=round(d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['seconds_s'] * 2.4e9 * 1024), 4),
-                  clock_ghz=round(d['GRBM_GUI_ACTIVE'] / d['seconds_s'] / 1e9, 3) if d['GRBM_GUI_ACTIVE'] else None,
+                  clock_ghz=round(d['GRBM_GUI_ACTIVE'] / 8.0 / d['seconds_s'] / 1e9, 3) if d['GRBM_GUI_ACTIVE'] else None,   # (the counter sums the 8 XCDs)
                   wave_time_active=round(d['SQ_ACTIVE_INST_ANY'] / wc, 3), wave_time_issue_stall=round(d['SQ_WAIT_INST_ANY'] / wc, 3),
                   wave_time_parked=round(d['SQ_WAIT_ANY'] / wc, 3), wave_time_lds_issue_stall=round(d['SQ_WAIT_INST_LDS'] / wc, 3))
 json.dump(res, open(os.path.join(out_dir, 'summary.json'), 'w'), indent=1)

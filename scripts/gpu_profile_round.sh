@@ -31,10 +31,14 @@ digest = source_digest()
 
 def bench_key(name):
     """rocprof symbol -> the key bench.py's roofline uses (the library's launch-trace name)."""
-    m = re.search(r'gemm_nn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>', name)
+    m = re.search(r'gemm_nn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>', name)
     if m:
         return 'gemm_nn<%s,%s,%s,%s,%s> epi=%s' % (m.group(1), m.group(2), m.group(3), m.group(4),
-                                                     'fast' if m.group(6) == 'true' else 'clamped', m.group(5))
+                                                     ('fast-bt' if m.group(7) == 'true' else 'fast') if m.group(6) == 'true' else 'clamped',
+                                                     m.group(5))
+    m = re.search(r'gemm_nn_bins_kernel<(\d+), (\d+), (\d+), (\d+), \d+, (true|false)>', name)
+    if m:
+        return 'gemm_nn_bins<%s,%s,%s,%s%s>' % (m.group(1), m.group(2), m.group(3), m.group(4), ',bt' if m.group(5) == 'true' else '')
     m = re.search(r'gemm_tn_kernel<(\d+),', name)
     if m:
         return 'gemm_tn<%s>' % m.group(1)
@@ -104,8 +108,14 @@ PY
 # files just collected where it looks (on this box's copy; scripts/copy_round_profiles.sh does the same for the repository)
 cp $OUT/traffic.json $OUT/mfma_util.json $ROOT/profiles/
 S0=$SECONDS; python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py default run: $((SECONDS - S0)) s wall" | tee $OUT/bench_wall.txt
+# rocprofv3 --kernel-trace --stats twice: (a) over `bench.py --steps-only` -- every launch under a symbol is a training step's,
+# the file the in-step roofline of the bench line is checked against (kernel_stats_steps_only.csv: average duration of the
+# dominant symbol = roofline.avg_launch_ms); (b) over the bench command itself (isolated-measurement launches included)
+bash scripts/gpu_prof.sh round${TAG}_prof_steps python bench.py --steps-only --steps 40 --warmup 5 | head -40 > $OUT/kernel_top_steps_only.txt
+python scripts/step_timeline.py $(find gpurun_out/round${TAG}_prof_steps -name '*kernel_trace.csv' | head -1) > $OUT/step_timeline.txt 2>/dev/null
+cp $(find gpurun_out/round${TAG}_prof_steps -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_steps_only.csv
+grep '^{' gpurun_out/round${TAG}_prof_steps/stdout.log > $OUT/bench_steps_only_under_rocprof.json
 bash scripts/gpu_prof.sh round${TAG}_prof python bench.py --no-alt --no-cpu-baseline | head -40 > $OUT/kernel_top.txt
-python scripts/step_timeline.py $(find gpurun_out/round${TAG}_prof -name '*kernel_trace.csv' | head -1) > $OUT/step_timeline.txt 2>/dev/null
 cp $(find gpurun_out/round${TAG}_prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 grep '^{' gpurun_out/round${TAG}_prof/stdout.log > $OUT/bench_under_rocprof.json
 python - <<PY
@@ -116,5 +126,5 @@ print('bench: %.3f ms/step (median %.3f), %s in-step frac %.4f (isolated %s), st
     b['ms_per_step'], b['ms_per_step_median'], r['kernel'], r['frac'], (r.get('isolated') or {}).get('frac'), b.get('step_hw_frac'),
     'quoted' if r.get('traffic') else 'NOT quoted: ' + str(r.get('traffic_stale'))))
 PY
-find gpurun_out/round${TAG}_prof $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+find gpurun_out/round${TAG}_prof gpurun_out/round${TAG}_prof_steps $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name '*.csv' -size +5M -delete

@@ -233,6 +233,8 @@ struct X6Params {
   int tiles_m, tiles_n, chunk;           // XCD-aware tile order: the 8 XCDs as a gm x gn grid over the tile grid,
   int gm, tm_per, tn_per;                // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per), see launch_gemm
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+  int rows_per_bin; long b_bin;          // > 0: A / C are `M / rows_per_bin` matrices stacked along M (the frequency bins of
+                                         // conv_fft.hip), the B operand of the bin a tile lies in starts at B + bin * b_bin
 };
 
 // Square tile BM = BN = 32 * (number of waves); every wave stages rows [32w, 32w+32) of each of the
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     const int r = wave * RW + i * RPP + prow;
     asrc[i] = p.A + a_off[r];
     slot8[i] = (pslot ^ ((r / RPB) % SLOTS)) * 8;
-    bsrc[i] = p.B + (long)min(n0 + r, p.Np - 1) * p.Kp;
+    bsrc[i] = p.B + (p.rows_per_bin > 0 ? (long)(m0 / p.rows_per_bin) * p.b_bin : 0L) + (long)min(n0 + r, p.Np - 1) * p.Kp;
   }
   const int ktail = p.Kvalid - 8;
   constexpr int N_DMA = 2 * NP * PPW;
@@ -768,7 +770,8 @@ int launch_gemm(X6Params& p, hipStream_t s) {
   // The 250-channel layers (252 tiles of 128 x 128, ONE 128 KB workgroup per CU, 23-26 us for 14.4 GFLOP) were tried in round 3
   // as 64 x 64 tiles of two waves with 2-5 workgroups per CU (33-35 us) and in the one-wave-per-SIMD schedule (SCH = 1: 23 us
   // alone, no change of the step): the 128 x 128 tile of four waves stays.
-  const int BT = (forced_tile != 128 && fits256 && wide) ? 256 : 128;
+  // (stacked per-bin products: a tile must lie inside one bin)
+  const int BT = (forced_tile != 128 && fits256 && wide && (p.rows_per_bin <= 0 || p.rows_per_bin % 256 == 0)) ? 256 : 128;
   p.tiles_m = st::ceil_div(p.M, BT);
   p.tiles_n = st::ceil_div(p.Np, BT);
   {
@@ -791,14 +794,19 @@ int launch_gemm(X6Params& p, hipStream_t s) {
     }
     if (8 / p.gm > p.tiles_n) p.gm = 8;                       // fewer than 8/gm column panels: stack the XCDs along M
     if (p.gm > p.tiles_m && 8 / p.gm <= p.tiles_n) p.gm = 1;
+    if (p.rows_per_bin > 0 && p.tiles_m >= 8) p.gm = 8;      // per-bin filter operands: an XCD's L2 should see few bins, each whole
     p.tm_per = st::ceil_div(p.tiles_m, p.gm);
     p.tn_per = st::ceil_div(p.tiles_n, 8 / p.gm);
     p.chunk = p.tm_per * p.tn_per;
   }
   const dim3 grid(p.chunk * 8 * p.splits);
-  st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d sched=%d xcd=%dx%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np,
-            p.Kp, p.taps, st::tuning(st::TUNE_BF16_SCHED), p.gm, 8 / p.gm,
-            2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
+  if (p.rows_per_bin > 0)
+    st::trace("gemm_nn_bf16<%d,NP=%d> batched bins=%d M=%d Np=%d Kp=%d xcd=%dx%d gflop=%.3f", BT, NP, p.M / p.rows_per_bin, p.rows_per_bin,
+              p.Np, p.Kvalid, p.gm, 8 / p.gm, 2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kvalid * (NP == 3 ? 6 : 1));
+  else
+    st::trace("gemm_nn_bf16<%d,NP=%d> splits=%d M=%d Np=%d Kp=%d taps=%d sched=%d xcd=%dx%d gflop=%.3f", BT, NP, p.splits, p.M, p.Np,
+              p.Kp, p.taps, st::tuning(st::TUNE_BF16_SCHED), p.gm, 8 / p.gm,
+              2e-9 * p.tiles_m * BT * (double)(p.tiles_n * BT) * p.Kp * (NP == 3 ? 6 : 1));
   st::LaunchTimer timer(s);
   const auto whole = [&](int bk) { return (p.taps > 1 ? p.cp % bk : p.Kvalid % bk) == 0; };   // FAST eligibility
 #define ST_LAUNCH(T, W1, W2, K, N, R, P)                                                                       \
@@ -1028,6 +1036,76 @@ WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int s
   return w;
 }
 
+// ---- stacked per-bin products of the frequency-domain layers (conv_fft.hip) on this kernel -------------------------
+// C[b] = A[b] * Bt[b]^T for b < bins: A planes [bins][rows][lda] (k contiguous, rows a multiple of 128), Bt planes
+// [bins][n][ldb] (k contiguous), C fp32 [bins][rows][ldc].  `a_rows_apart` / `a_bin`: element distance between consecutive
+// rows of A and between the bins' first rows (a plain stack: lda and rows * lda; the transposed spectra of the lag products:
+// row = channel, `pitch` apart, bins `rows_of_reduction` apart inside a row -- see st::transpose_bf16_bins).
+template <int NP>
+static int gemm_bins(const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes, size_t b_plane,
+                     long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s) {
+  X6Params p{};
+  p.A = reinterpret_cast<const __bf16*>(a_planes);
+  p.a_plane = a_plane;
+  p.amap.frames = rows;                       // m = bin * rows + r
+  p.amap.row_stride = (int)a_rows_apart;
+  p.amap.batch_stride = a_bin;
+  p.B = reinterpret_cast<const __bf16*>(bt_planes);
+  p.b_plane = b_plane;
+  p.C = c;
+  p.cmap.frames = rows * bins;                // plain stack of the output matrices
+  p.cmap.row_stride = (int)ldc;
+  p.M = rows * bins;
+  p.Np = n;
+  p.Kvalid = k;
+  p.Kp = (int)ldb;
+  p.n_store = n;
+  p.taps = 1;
+  p.cp = k;
+  p.rows_per_bin = rows;
+  p.b_bin = b_bin;
+  return launch_gemm<NP>(p, s);
+}
+
+}  // namespace
+
+int st::gemm_bf16_bins(int planes, const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes,
+                       size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s) {
+  if (!(a_planes && bt_planes && c && rows > 0 && rows % 128 == 0 && k > 0 && k % 32 == 0 && n > 0 && n % 128 == 0 && bins > 0 &&
+        (planes == 1 || planes == 3) && a_rows_apart % 8 == 0 && a_bin % 8 == 0 && ldb % 8 == 0 && b_bin % 8 == 0 && ldc % 4 == 0)) {
+    st::set_error("gemm_bf16_bins: bad shape rows=%d k=%d n=%d bins=%d planes=%d", rows, k, n, bins, planes);
+    return ST_EINVAL;
+  }
+  return planes == 3 ? gemm_bins<3>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s)
+                     : gemm_bins<1>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s);
+}
+
+// dst[c][bin * rows + r] = src[bin][r][c] (2-byte elements, one plane): the reduction-major copies of the spectra that the lag
+// products of the filter gradient read -- row c of dst holds all bins behind each other, `bins * rows` elements per row
+int st::transpose_bf16_bins(const void* src, void* dst, int bins, int rows, int cols, hipStream_t s) {
+  if (!(src && dst && bins > 0 && rows > 0 && rows % 64 == 0 && cols > 0 && cols % 64 == 0)) {
+    st::set_error("transpose_bf16_bins: bad shape bins=%d rows=%d cols=%d", bins, rows, cols);
+    return ST_EINVAL;
+  }
+  TransposeJobs js{};
+  js.n = 1;
+  js.tq = rows;
+  js.pitch = (long)bins * rows;
+  js.job[0].src = reinterpret_cast<const unsigned short*>(src);
+  js.job[0].dst = reinterpret_cast<unsigned short*>(dst);
+  js.job[0].zero_tail = nullptr;
+  js.job[0].rows = rows;
+  js.job[0].row0 = 0;
+  js.job[0].step = 1;
+  js.job[0].t_pitch = rows;
+  js.job[0].c_pitch = cols;
+  js.job[0].c_rows = cols;
+  js.job[0].y_tiles = cols / 64;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(rows / 64, cols / 64, bins), dim3(256), 0, s, js);
+  return st::check_launch("transpose_bf16_bins");
+}
+
+namespace {
 }  // namespace
 
 extern "C" {

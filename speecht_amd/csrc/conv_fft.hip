@@ -108,7 +108,8 @@ __global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
 }
 
 struct RowsIn {                  // a padded NWC tensor, read frame-wise
-  const float* base;             // frame 0 of utterance 0
+  const float* base;             // frame 0 of utterance 0 (fp32 tensor) ...
+  const unsigned short* base_b;  // ... or of its bf16 form (same geometry; the kernels' IN_BF variants)
   long batch_stride;             // floats between utterances
   int c_pitch, channels_read;    // floats per frame; channels to transform (<= c_pitch)
   int t_lo, t_hi;                // readable frames [t_lo, t_hi) relative to frame 0 (halos included: they hold zeros)
@@ -143,10 +144,23 @@ __device__ inline void stage_matrix(float* __restrict__ dst, const float* __rest
   }
 }
 
-template <int NST>                           // stages of CH frame pairs: the matrix has no columns past 2 * NST * CH
+// IN_BF: the tensor is read in its bf16 form.  OUTP: 0 -> fp32 spectra `out`; 1 -> ONE bf16 plane `outb` (bf16 activations:
+// the per-bin products run on the bf16 matrix pipe); 3 -> the exact 3-way bf16 split of the fp32 value in three planes
+// `out_plane` elements apart (fp32-accurate products from six bf16 terms, conv_bf16.hip).  `dc` (optional): the fp32 value of
+// spectrum row 0 -- bin 0's real part, the plain sum of the block's frames -- [rows_pad][half]: the bias gradient is a sum of
+// these, and a bf16 spectrum would cost it its cancellation digits.
+__device__ __forceinline__ void split3_bits(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;          // exact
+  const __bf16 bm = (__bf16)r1;
+  const __bf16 bl = (__bf16)(r1 - (float)bm);
+  h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
+}
+template <int NST, bool IN_BF = false, int OUTP = 0>   // NST stages of CH frame pairs: the matrix has no columns past 2 * NST * CH
 __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, unsigned short* __restrict__ outb,
+                                                          size_t out_plane, float* __restrict__ dc) {
   __shared__ __attribute__((aligned(16))) float wl[KP * KP];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
@@ -165,14 +179,18 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
       const int b = row / blocks, j = row - b * blocks;
       const int t0 = j * V + start + h;
       const bool cok = c < x.channels_read;
-      const float* src = x.base + (long)b * x.batch_stride + min(c, x.channels_read - 1);
+      const long col = (long)b * x.batch_stride + min(c, x.channels_read - 1);
+      const float* src = x.base + col;
+      const unsigned short* srcb = x.base_b + col;
       // branch-free: every lane loads from a clamped, readable address; what it must not see is masked off when the
       // value is consumed (a select next to the load would make the wave wait for it there)
       auto load = [&](float (&bf)[CH], int st) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
           const int t = t0 + 2 * (st * CH + s);
-          bf[s] = src[(long)min(max(t, x.t_lo), x.t_hi - 1) * x.c_pitch];
+          const long o = (long)min(max(t, x.t_lo), x.t_hi - 1) * x.c_pitch;
+          if (IN_BF) bf[s] = __uint_as_float((unsigned)srcb[o] << 16);
+          else bf[s] = src[o];
         }
       };
       auto mac = [&](const float (&bf)[CH], int st) {
@@ -207,7 +225,17 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
         for (int r = 0; r < 16; ++r) {
           const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
-          if (bin < bins) out[(long)bin * plane + (long)row * 2 * half + col] = acc[i][r];
+          if (bin < bins) {
+            const long o = (long)bin * plane + (long)row * 2 * half + col;
+            if (OUTP == 0) out[o] = acc[i][r];
+            else if (OUTP == 1) outb[o] = __builtin_bit_cast(unsigned short, (__bf16)acc[i][r]);
+            else {
+              unsigned short sh, sm, sl;
+              split3_bits(acc[i][r], sh, sm, sl);
+              outb[o] = sh; outb[out_plane + o] = sm; outb[2 * out_plane + o] = sl;
+            }
+            if (dc && m == 0) dc[(long)row * half + c] = acc[i][r];
+          }
         }
     }
   }
@@ -221,11 +249,13 @@ struct RowsOut {
   float* base;
   long batch_stride;
   int c_pitch, channels, frames;
+  unsigned short* base_b;        // BF kernels: the output is written in bf16 here (same geometry), `base` is not touched
 };
 // One (row, 32 channels) item per wavefront: both 32-frame halves of the block from one pass over
 // the spectra (HP bin pairs of real parts, HP of imaginary parts: 2 * HP >= bins), loads one stage ahead of the MFMAs
 // across the terms; a neighbour term only feeds the half of the block it reaches.
-template <int TERMS, int HP>
+// BF (bf16 activations): the output goes out in bf16 (y.base_b) and the ReLU mask source `mask` is a bf16 tensor
+template <int TERMS, int HP, bool BF = false>
 __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restrict__ in, const float* __restrict__ winv, int blocks,
                                                            int rows, int rows_pad, int bins, int half_in, int nchunks,
                                                            RowsOut y, const float* __restrict__ bias, int relu,
@@ -252,12 +282,17 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
     // expose a full memory latency -- for all the compiler knows the output aliases the mask
     float mk[2][16];
     if (mask) {
-      const float* mp = mask + (long)b * mask_batch_stride + min(c, mask_c_pitch - 1);
+      const long mcol = (long)b * mask_batch_stride + min(c, mask_c_pitch - 1);
+      const float* mp = mask + mcol;
+      const unsigned short* mpb = reinterpret_cast<const unsigned short*>(mask) + mcol;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          mk[i][r] = mp[(long)min(j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, y.frames - 1) * mask_c_pitch];
+        for (int r = 0; r < 16; ++r) {
+          const long o = (long)min(j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, y.frames - 1) * mask_c_pitch;
+          if (BF) mk[i][r] = __uint_as_float((unsigned)mpb[o] << 16);
+          else mk[i][r] = mp[o];
+        }
     }
     const float* src = in + (long)row * 2 * half_in + min(c, half_in - 1);
     const bool cok = c < half_in;
@@ -317,12 +352,16 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
           acc[i][r] = val;
         }
       float* yp = y.base + (long)b * y.batch_stride + c;
+      unsigned short* ypb = y.base_b + (long)b * y.batch_stride + c;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (t < y.frames) yp[(long)t * y.c_pitch] = acc[i][r];
+          if (t < y.frames) {
+            if (BF) ypb[(long)t * y.c_pitch] = __builtin_bit_cast(unsigned short, (__bf16)acc[i][r]);
+            else yp[(long)t * y.c_pitch] = acc[i][r];
+          }
         }
     }
   }
@@ -336,10 +375,12 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
 //  (the 32-tap layer: 403 MB written and read again, plus the 128 MB of the flip).
 //  from packed [w * cpi + c][npo]; one thread per (c, o), o fastest (coalesced reads and writes); rows c >= cin zero.
 // (WT = compile-time width: the taps stay in registers; WT = 0: run-time width, taps in scratch)
-template <int WT>
+// OUTP 0: fp32 `gfwd`; 1 / 3: the same matrix as one bf16 plane / the exact 3-way bf16 split in three planes at `gb`
+template <int WT, int OUTP = 0>
 __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __restrict__ packed, int width_rt, int cin, int cout,
                                                               int cpi, int cph, int npo, int n, int bins,
-                                                              const f32x2* __restrict__ tw, float* __restrict__ gfwd) {
+                                                              const f32x2* __restrict__ tw, float* __restrict__ gfwd,
+                                                              unsigned short* __restrict__ gb, size_t g_plane) {
   const int width = WT ? WT : width_rt;
   const int o = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (o >= npo) return;
@@ -359,11 +400,20 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
       gr = fmaf(f[w], t[0], gr);
       gi = fmaf(-f[w], t[1], gi);
     }
-    float* g = gfwd + (long)k * plane;
-    g[(long)c * 2 * npo + o] = gr;
-    g[(long)c * 2 * npo + npo + o] = -gi;
-    g[(long)(cph + c) * 2 * npo + o] = gi;
-    g[(long)(cph + c) * 2 * npo + npo + o] = gr;
+    auto put = [&](long o_, float v) {
+      if (OUTP == 0) gfwd[o_] = v;
+      else if (OUTP == 1) gb[o_] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      else {
+        unsigned short sh, sm, sl;
+        split3_bits(v, sh, sm, sl);
+        gb[o_] = sh; gb[g_plane + o_] = sm; gb[2 * g_plane + o_] = sl;
+      }
+    };
+    const long g0 = (long)k * plane;
+    put(g0 + (long)c * 2 * npo + o, gr);
+    put(g0 + (long)c * 2 * npo + npo + o, -gi);
+    put(g0 + (long)(cph + c) * 2 * npo + o, gi);
+    put(g0 + (long)(cph + c) * 2 * npo + npo + o, gr);
   }
 }
 
@@ -441,6 +491,7 @@ bool tensor_ok(const st_tensor3* t) {
 
 RowsIn rows_in(const st_tensor3& t) {
   RowsIn r;
+  r.base_b = nullptr;
   r.base = t.base + (long)t.halo * t.c_pitch;        // frame 0 of utterance 0
   r.batch_stride = (long)t.t_pitch * t.c_pitch;
   r.c_pitch = t.c_pitch;
@@ -453,39 +504,62 @@ RowsIn rows_in(const st_tensor3& t) {
 constexpr int TRANSFORM_WGS_DEFAULT = 512;       // persistent: two workgroups per CU, every wave walks its share of the items
 inline int transform_wgs() { const int t = st::tuning(st::TUNE_TRANSFORM_WGS); return t > 0 ? t : TRANSFORM_WGS_DEFAULT; }
 
-void launch_dft(const st_tensor3& t, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
-                hipStream_t s) {
+// tb: the tensor's bf16 form (null: read the fp32 tensor); planes: 0 -> fp32 spectra `out`, 1 / 3 -> bf16 plane(s) `outb`
+void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
+                void* outb, int planes, size_t out_plane, float* dc, hipStream_t s) {
   const int nchunks = st::ceil_div(half, 32);
   const int wgs = std::min(transform_wgs(), st::ceil_div(pl.rows_pad * nchunks, 4));
-  const int nst = frames_used <= 6 * CH ? 3 : 4;
-  st::trace("dft_rows<%d> rows=%d chunks=%d bins=%d gflop=%.3f", nst, pl.rows, nchunks, pl.bins,
-            4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
+  const int nst = frames_used <= 6 * CH ? 3 : 4;                           // the matrix has no columns past frames_used
+  st::trace("dft_rows<%d%s%s> rows=%d chunks=%d bins=%d gflop=%.3f", nst, tb ? ",bf16-in" : "", planes == 1 ? ",bf16-out" : planes == 3 ? ",x3-out" : "",
+            pl.rows, nchunks, pl.bins, 4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
+  RowsIn x = rows_in(t);
+  if (tb) x.base_b = reinterpret_cast<const unsigned short*>(tb) + (long)t.halo * t.c_pitch;
+  unsigned short* ob = reinterpret_cast<unsigned short*>(outb);
   st::LaunchTimer timer(s);
-  if (frames_used <= 6 * CH)                                               // the matrix has no columns past frames_used
-    st::launch_timed(timer, dft_rows_kernel<3>, dim3(wgs), dim3(256), s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                     half, nchunks, out);
-  else
-    st::launch_timed(timer, dft_rows_kernel<4>, dim3(wgs), dim3(256), s, rows_in(t), wm, pl.blocks, pl.rows, pl.rows_pad, start, pl.bins,
-                     half, nchunks, out);
+#define ST_DFT(NSTV, INB, OUTPV)                                                                                         \
+  st::launch_timed(timer, dft_rows_kernel<NSTV, INB, OUTPV>, dim3(wgs), dim3(256), s, x, wm, pl.blocks, pl.rows, pl.rows_pad, start, \
+                   pl.bins, half, nchunks, out, ob, out_plane, dc)
+#define ST_DFT_N(INB, OUTPV) do { if (nst == 3) ST_DFT(3, INB, OUTPV); else ST_DFT(4, INB, OUTPV); } while (0)
+  if (!tb && planes == 0) ST_DFT_N(false, 0);
+  else if (!tb && planes == 3) ST_DFT_N(false, 3);
+  else if (tb && planes == 1) ST_DFT_N(true, 1);
+  else st::set_error("dft: unsupported operand form (bf16 in: %d, planes %d)", tb ? 1 : 0, planes);
+#undef ST_DFT_N
+#undef ST_DFT
 }
 
 template <int TERMS>
 void launch_idft(const float* in, const float* winv, const Plan& p, int half_in, int nchunks, const RowsOut& out, const float* bias,
-                 int relu, const float* mask, long mask_batch_stride, int mask_c_pitch, hipStream_t s) {
+                 int relu, const void* mask, long mask_batch_stride, int mask_c_pitch, hipStream_t s) {
   const dim3 grid(std::min(transform_wgs(), st::ceil_div(p.rows * nchunks, 4)));
   const int hp = p.bins <= 36 ? 18 : 24;
-  st::trace("idft_rows<%d,%d> rows=%d chunks=%d bins=%d gflop=%.3f", TERMS, hp, p.rows, nchunks, p.bins,
+  const bool bf = out.base_b != nullptr;                       // bf16 activations: bf16 output and bf16 mask source
+  st::trace("idft_rows<%d,%d%s> rows=%d chunks=%d bins=%d gflop=%.3f", TERMS, hp, bf ? ",bf16" : "", p.rows, nchunks, p.bins,
             4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1));
+  const float* mk = reinterpret_cast<const float*>(mask);
   st::LaunchTimer timer(s);
-  if (p.bins <= 36)
-    st::launch_timed(timer, idft_rows_kernel<TERMS, 18>, grid, dim3(256), s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                     nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
-  else
-    st::launch_timed(timer, idft_rows_kernel<TERMS, 24>, grid, dim3(256), s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in,
-                     nchunks, out, bias, relu, mask, mask_batch_stride, mask_c_pitch);
+#define ST_IDFT(HPV, BFV)                                                                                                     \
+  st::launch_timed(timer, idft_rows_kernel<TERMS, HPV, BFV>, grid, dim3(256), s, in, winv, p.blocks, p.rows, p.rows_pad, p.bins, half_in, \
+                   nchunks, out, bias, relu, mk, mask_batch_stride, mask_c_pitch)
+  if (p.bins <= 36) { if (bf) ST_IDFT(18, true); else ST_IDFT(18, false); }
+  else { if (bf) ST_IDFT(24, true); else ST_IDFT(24, false); }
+#undef ST_IDFT
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
+
+template <int OUTP>
+void launch_filters_planes(int width, const dim3& grid, hipStream_t s, const float* packed, int cin, int cout, int cin_pitch, int cph,
+                           int npo, int n, int bins, const f32x2* tw, unsigned short* gb, size_t g_plane) {
+  float* none = nullptr;
+  if (width == 32) hipLaunchKernelGGL((filters_dft_fwd_kernel<32, OUTP>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, cph, npo, n, bins, tw, none, gb, g_plane);
+  else if (width == 25) hipLaunchKernelGGL((filters_dft_fwd_kernel<25, OUTP>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, cph, npo, n, bins, tw, none, gb, g_plane);
+  else if (width == 7) hipLaunchKernelGGL((filters_dft_fwd_kernel<7, OUTP>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, cph, npo, n, bins, tw, none, gb, g_plane);
+  else hipLaunchKernelGGL((filters_dft_fwd_kernel<0, OUTP>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, cph, npo, n, bins, tw, none, gb, g_plane);
+}
+
+bool planes_ok(int planes) { return planes == 1 || planes == 3; }
+
 
 }  // namespace
 
@@ -563,7 +637,8 @@ int st_conv1d_fft_filters_f32(const float* packed, int width, int cin, int cout,
   // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
   const int gx = st::ceil_div(npo, 256), gy = half_of(cin_pitch);
   const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
-  ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd);
+  ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd,
+                        (unsigned short*)nullptr, (size_t)0);
   return st::check_launch("fft filters");
 }
 
@@ -600,11 +675,11 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
   const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
   float* const sk = reinterpret_cast<float*>(workspace);
   float* yf = sk + st::SK_WS_FLOATS;
-  launch_dft(*x, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), sf, s);
+  launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), sf, nullptr, 0, 0, nullptr, s);
   if (int e = st::gemm_nn_batched(sf, ka, (long)p.rows_pad * ka, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka,
                                   nf, p.bins, s, sk))
     return e;
-  RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames};
+  RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames, nullptr};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
   launch_idft<1>(yf, tables + T_IY, p, npo, nchunks, out, bias, relu, nullptr, 0L, 0, s);
   return st::check_launch("conv fft fwd");
@@ -613,7 +688,7 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tables && zf && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft dz spectra: bad argument");
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  launch_dft(*dz, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, st::as_stream(stream));
+  launch_dft(*dz, nullptr, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, nullptr, 0, 0, nullptr, st::as_stream(stream));
   return st::check_launch("conv fft dz spectra");
 }
 
@@ -643,11 +718,159 @@ int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const 
   if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gfwd, (long)nb * kz, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
                                   nb, p.bins, s, sk, true))
     return e;
-  RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames};
+  RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames, nullptr};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
   launch_idft<3>(xf, tables + T_IX, p, cph, nchunks, out, nullptr, 0, act ? act->base + (long)act->halo * act->c_pitch : nullptr,
                  act ? (long)act->t_pitch * act->c_pitch : 0L, act ? act->c_pitch : 0, s);
   return st::check_launch("conv fft bwd_data");
+}
+
+// ======== the same three operations with the per-bin products on the bf16 matrix pipe (conv_bf16.hip) ===================
+// planes = 1: bf16 activations (BASELINE configs[3]) -- tensors are read / written in their bf16 form, spectra and filter
+//             spectra are ONE bf16 plane, every accumulation (DFT, products, inverse DFT) is fp32;
+// planes = 3: fp32 tensors; every spectrum value is split EXACTLY into three bf16 planes and a product evaluated as the six
+//             largest cross terms with fp32 accumulation (the bf16x6 scheme of conv_bf16.hip: at least as accurate as an fp32
+//             FMA chain).
+// Layouts: spectra planes [bins][rows_pad][cols] as in the fp32 form; filter spectra twice -- `g_planes` [bins][2 cph][2 npo]
+// (the matrix gfwd; back-prop to the input multiplies by its transpose, so this is that product's k-contiguous operand) and
+// `gt_planes` [2 npo][bins][2 cph] (its transpose per bin, rows holding all bins: the forward product's operand).
+
+size_t st_conv1d_fft_filter_plane_elems(int width, int cin_pitch, int cout) { return st_conv1d_fft_filter_floats(width, cin_pitch, cout); }
+
+int st_conv1d_fft_filters_planes(const float* packed, int width, int cin, int cout, int cin_pitch, const float* tables, void* g_planes,
+                                 void* gt_planes, int planes, void* stream) {
+  ST_REQUIRE(width_ok(width) && cin_pitch % 16 == 0 && tables && packed && g_planes && gt_planes && planes_ok(planes), "fft filter planes: bad argument");
+  ST_REQUIRE(npad_of(cout) % 128 == 0, "fft filter planes: the output channels must pack to a multiple of 128");
+  hipStream_t s = st::as_stream(stream);
+  const int n = V + width - 1, bins = n / 2 + 1, npo = npad_of(cout), cph = half_of(cin_pitch);
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
+  const size_t plane = (size_t)bins * 2 * cph * 2 * npo;
+  const int gx = st::ceil_div(npo, 256), gy = cph;
+  const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
+  unsigned short* g = reinterpret_cast<unsigned short*>(g_planes);
+  if (planes == 1) launch_filters_planes<1>(width, grid, s, packed, cin, cout, cin_pitch, cph, npo, n, bins, tw, g, plane);
+  else launch_filters_planes<3>(width, grid, s, packed, cin, cout, cin_pitch, cph, npo, n, bins, tw, g, plane);
+  if (int e = st::check_launch("fft filter planes")) return e;
+  for (int pl = 0; pl < planes; ++pl)
+    if (int e = st::transpose_bf16_bins(g + pl * plane, reinterpret_cast<unsigned short*>(gt_planes) + pl * plane, bins, 2 * cph, 2 * npo, s))
+      return e;
+  return ST_OK;
+}
+
+// elements per plane of the input spectra / of the dz spectra (the fp32 forms' float counts)
+size_t st_conv1d_fft_planes_ws(const st_tensor3* x, const st_tensor3* y, int width, int planes) {
+  if (!x || !y || !width_ok(width) || !planes_ok(planes)) return 0;
+  const Plan p = make_plan(width, y->frames, y->batch);
+  const size_t nf = 2 * (size_t)npad_of(y->channels), ka = 2 * (size_t)half_of(x->c_pitch);
+  const size_t red = (size_t)p.bins * p.rows_pad;
+  // [stream-K area (unused here, kept for a common layout) | fp32 product spectra: max(yf, xf, qf) | reduction-major bf16 copies
+  //  of both spectra for the lag products, `planes` each]
+  const size_t prod = std::max((size_t)p.bins * p.rows_pad * nf, (size_t)p.bins * ka * nf);
+  return (st::SK_WS_FLOATS + prod + 64) * sizeof(float) + planes * (ka + nf) * red * 2 + 512;
+}
+
+int st_conv1d_nwc_fwd_fft_planes(const st_tensor3* x, const void* x_bf16, const void* gt_planes, const float* bias, int width,
+                                 int pad_left, int relu, const st_tensor3* y, void* y_bf16, const float* tables, void* sf_planes,
+                                 int planes, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && gt_planes && sf_planes && workspace && tables && width_ok(width) && planes_ok(planes),
+             "conv fft planes fwd: bad argument");
+  ST_REQUIRE((planes == 1) == (x_bf16 != nullptr) && (planes == 1) == (y_bf16 != nullptr),
+             "conv fft planes fwd: one plane goes with bf16 tensors, three planes with fp32 tensors");
+  ST_REQUIRE(x->batch == y->batch && x->frames == y->frames && pad_left >= 0 && pad_left < width, "conv fft planes fwd: stride-1 SAME layers only");
+  ST_REQUIRE(npad_of(y->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_planes_ws(x, y, width, planes), "conv fft planes fwd: workspace / shape");
+  hipStream_t s = st::as_stream(stream);
+  const Plan p = make_plan(width, y->frames, y->batch);
+  const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
+  const size_t s_plane = (size_t)p.bins * p.rows_pad * ka, g_plane = (size_t)p.bins * ka * nf;
+  float* yf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
+  launch_dft(*x, x_bf16, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), nullptr, sf_planes, planes, s_plane, nullptr, s);
+  // Y[bin] = S[bin] (rows x ka) * gfwd[bin] (ka x nf): the operand is gt[n][bin * ka + k]
+  if (int e = st::gemm_bf16_bins(planes, sf_planes, s_plane, ka, (long)p.rows_pad * ka, gt_planes, g_plane, (long)p.bins * ka, ka, yf, nf,
+                                 p.rows_pad, ka, nf, p.bins, s))
+    return e;
+  RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames,
+              y_bf16 ? reinterpret_cast<unsigned short*>(y_bf16) + (long)y->halo * y->c_pitch : nullptr};
+  launch_idft<1>(yf, tables + T_IY, p, npo, st::ceil_div(y->c_pitch, 32), out, bias, relu, nullptr, 0L, 0, s);
+  return st::check_launch("conv fft planes fwd");
+}
+
+int st_conv1d_fft_dz_spectra_planes(const st_tensor3* dz, const void* dz_bf16, int width, const float* tables, void* zf_planes,
+                                    int planes, float* dc, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && tables && zf_planes && width_ok(width) && planes_ok(planes) && npad_of(dz->channels) % 128 == 0 &&
+                 (planes == 1) == (dz_bf16 != nullptr), "conv fft planes dz spectra: bad argument");
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const int npo = npad_of(dz->channels);
+  launch_dft(*dz, dz_bf16, p, tables + T_FZ, 0, V, npo, nullptr, zf_planes, planes, (size_t)p.bins * p.rows_pad * 2 * npo, dc,
+             st::as_stream(stream));
+  return st::check_launch("conv fft planes dz spectra");
+}
+
+// dbias[o] = sum over the blocks of their fp32 frame sums dc[row][o] (st_conv1d_fft_dz_spectra_planes)
+int st_conv1d_fft_bias_grad_dc_f32(const float* dc, int rows, int channels, int n_pad, float* dbias, void* stream) {
+  ST_REQUIRE(dc && dbias && rows > 0 && channels > 0 && n_pad >= channels, "conv fft bias grad (dc): bad argument");
+  hipLaunchKernelGGL(bias_from_spectra_kernel, dim3(st::ceil_div(n_pad, 32)), dim3(256), 0, st::as_stream(stream), dc, rows, n_pad, channels,
+                     n_pad, dbias);
+  return st::check_launch("conv fft bias grad (dc)");
+}
+
+int st_conv1d_nwc_bwd_data_fft_planes(const st_tensor3* dz, const void* zf_planes, const void* g_planes, int width, int pad_left,
+                                      const st_tensor3* act, const void* act_bf16, const st_tensor3* dx, void* dx_bf16,
+                                      const float* tables, int planes, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && zf_planes && g_planes && workspace && tables && width_ok(width) && planes_ok(planes),
+             "conv fft planes bwd_data: bad argument");
+  ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames && pad_left >= 0 && pad_left < width, "conv fft planes bwd_data: stride-1 layers only");
+  ST_REQUIRE((planes == 1) == (dx_bf16 != nullptr) && (!act || (planes == 1) == (act_bf16 != nullptr)),
+             "conv fft planes bwd_data: one plane goes with bf16 tensors, three planes with fp32 tensors");
+  ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_planes_ws(dx, dz, width, planes), "conv fft planes bwd_data: workspace / shape");
+  if (act) ST_REQUIRE(tensor_ok(act) && act->batch == dx->batch && act->frames == dx->frames && act->c_pitch >= dx->c_pitch,
+                      "conv fft planes bwd_data: mask tensor mismatch");
+  hipStream_t s = st::as_stream(stream);
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const int kz = 2 * npad_of(dz->channels), cph = half_of(dx->c_pitch), nb = 2 * cph;
+  float* xf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
+  // X[bin] = Z[bin] (rows x kz) * gfwd[bin]^T (kz x nb): gfwd itself is the k-contiguous operand
+  if (int e = st::gemm_bf16_bins(planes, zf_planes, (size_t)p.bins * p.rows_pad * kz, kz, (long)p.rows_pad * kz, g_planes, (size_t)p.bins * nb * kz,
+                                 kz, (long)nb * kz, xf, nb, p.rows_pad, kz, nb, p.bins, s))
+    return e;
+  RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames,
+              dx_bf16 ? reinterpret_cast<unsigned short*>(dx_bf16) + (long)dx->halo * dx->c_pitch : nullptr};
+  const void* mask = nullptr;
+  if (act) mask = act_bf16 ? static_cast<const void*>(reinterpret_cast<const unsigned short*>(act_bf16) + (long)act->halo * act->c_pitch)
+                           : static_cast<const void*>(act->base + (long)act->halo * act->c_pitch);
+  launch_idft<3>(xf, tables + T_IX, p, cph, st::ceil_div(dx->c_pitch, 32), out, nullptr, 0, mask, act ? (long)act->t_pitch * act->c_pitch : 0L,
+                 act ? act->c_pitch : 0, s);
+  return st::check_launch("conv fft planes bwd_data");
+}
+
+int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* dz, const void* sf_planes, const void* zf_planes, int width,
+                                        const float* tables, float* dpacked, int planes, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  ST_REQUIRE(tensor_ok(x) && tensor_ok(dz) && sf_planes && zf_planes && dpacked && workspace && tables && width_ok(width) && planes_ok(planes),
+             "conv fft planes bwd_filter: bad argument");
+  ST_REQUIRE(x->batch == dz->batch && x->frames == dz->frames, "conv fft planes bwd_filter: stride-1 layers only");
+  ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_planes_ws(x, dz, width, planes), "conv fft planes bwd_filter: workspace / shape");
+  hipStream_t s = st::as_stream(stream);
+  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
+  const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
+  const long red = (long)p.bins * p.rows_pad;
+  const size_t prod = std::max((size_t)p.bins * p.rows_pad * nf, (size_t)p.bins * ka * nf);
+  float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
+  unsigned short* st_planes = reinterpret_cast<unsigned short*>(qf + prod + 64);           // [planes][ka][red]
+  unsigned short* zt_planes = st_planes + (size_t)planes * ka * red;                       // [planes][nf][red]
+  const unsigned short* sfp = reinterpret_cast<const unsigned short*>(sf_planes);
+  const unsigned short* zfp = reinterpret_cast<const unsigned short*>(zf_planes);
+  for (int pl = 0; pl < planes; ++pl) {
+    if (int e = st::transpose_bf16_bins(sfp + (size_t)pl * red * ka, st_planes + (size_t)pl * ka * red, p.bins, p.rows_pad, ka, s)) return e;
+    if (int e = st::transpose_bf16_bins(zfp + (size_t)pl * red * nf, zt_planes + (size_t)pl * nf * red, p.bins, p.rows_pad, nf, s)) return e;
+  }
+  // Q[bin] = S[bin]^T (ka x rows) * Z[bin] (rows x nf): both operands reduction-major, rows of all bins behind each other
+  if (int e = st::gemm_bf16_bins(planes, st_planes, (size_t)ka * red, red, p.rows_pad, zt_planes, (size_t)nf * red, red, p.rows_pad, qf, nf, ka,
+                                 p.rows_pad, nf, p.bins, s))
+    return e;
+  const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
+  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked);
+  return st::check_launch("conv fft planes bwd_filter");
 }
 
 int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* zf, int width,

@@ -53,6 +53,12 @@ int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
                     int M, int K, int N, int batches, hipStream_t s);
 
+// conv_bf16.hip: the same per-bin products on the bf16 matrix pipe (planes = 1: bf16 operands; 3: the exact 3-way split of fp32
+// operands, six product terms -- fp32-accurate), and the reduction-major copies of spectra the lag products read
+int gemm_bf16_bins(int planes, const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes,
+                   size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s);
+int transpose_bf16_bins(const void* src, void* dst, int bins, int rows, int cols, hipStream_t s);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int check_launch(const char* what) {

@@ -246,6 +246,7 @@ class Wav2LetterEngine:
     self._wtplanes_fresh = False
     self._gfwd_fresh = False
     self.fft = {}
+    self.fftb = {}
 
   # ---- plumbing --------------------------------------------------------------------------
   @property
@@ -397,10 +398,13 @@ class Wav2LetterEngine:
     self.dec_score = self._storage.view('dec_score', batch)[0][:batch]
     # which layers run in the frequency domain is decided first: they leave the bf16x6 plane plumbing alone
     self._fft_layers = {i for i in range(len(self.layers)) if self._use_fft(i, batch, geo[i][1])}
+    # bf16 activations: the wide long-filter layer in the frequency domain with its per-bin products on the bf16 matrix pipe
+    self._fftb_layers = {i for i in range(len(self.layers)) if self._use_fft_bf16(i, batch, geo[i][1])}
     if self.conv_mode == 'bf16x6':
       self._alloc_planes()
     if self.conv_mode == 'bf16':
       self._alloc_bf16()
+      self._alloc_fft_bf16(batch)
     self._alloc_fft(batch)
     self._shape = (batch, frames)
 
@@ -428,6 +432,45 @@ class Wav2LetterEngine:
       width2 = self._polyphase(i)[0]
       return i == 0 and self.fft_first_layer and self.fft_min_width <= width2 <= 33
     return i > 0 and l.stride == 1 and self.fft_min_width <= l.width <= 33 and l.nt_pad % 128 == 0
+
+  def _use_fft_bf16(self, i, batch, t_out):
+    """bf16 activations (configs[3]): the 32-tap 250 -> 2000 layer runs as block DFTs + per-bin products on the bf16 matrix pipe
+    (st_conv1d_*_fft_planes, one bf16 plane): 51.5 GFLOP per pass instead of the W-tap kernel's 513.  Only the wide
+    long-filter layer: the narrow layers' W-tap bf16 kernels are launch-bound (~30 us), nothing to gain there."""
+    l = self.layers[i]
+    return (self.conv_mode == 'bf16' and self.fft_conv and os.environ.get('ST_FFT_BF16', '1') != '0' and i > 0 and
+            l.stride == 1 and 16 <= l.width <= 33 and l.n_pad % 128 == 0 and batch * t_out >= self.fft_min_rows)
+
+  def _alloc_fft_bf16(self, batch):
+    lib = _lib.load()
+    self.fftb = {}
+    for i in sorted(self._fftb_layers):
+      l = self.layers[i]
+      t_in, t_out, pl, pr = self.geo[i]
+      view = lambda name, numel, dtype=None: self._storage.view('fftb%d_%s' % (i, name), numel, dtype)
+      bf = torch.bfloat16
+      tables, fresh_tables = view('tables', lib.st_conv1d_fft_table_floats())
+      if getattr(self, '_fftb_table_key', {}).get(i) != (l.width, pl):
+        fresh_tables = True
+      self.__dict__.setdefault('_fftb_table_key', {})[i] = (l.width, pl)
+      ge = lib.st_conv1d_fft_filter_plane_elems(l.width, l.cin_pitch, l.cout)
+      g, fresh_g = view('g', ge, bf)
+      rows_pad, blocks = ctypes.c_int(), ctypes.c_int()
+      call('st_conv1d_fft_plan', l.width, t_out, batch, None, None, ctypes.byref(blocks), None, ctypes.byref(rows_pad))
+      f = dict(tables=tables, g=g, gt=view('gt', ge, bf)[0],
+               sf=view('sf', lib.st_conv1d_fft_sf_floats(self.X[i].ref, self.X[i + 1].ref, l.width), bf)[0],
+               zf=view('zf', lib.st_conv1d_fft_zf_floats(self.dZ[i].ref, l.width), bf)[0],
+               dc=view('dc', rows_pad.value * l.n_pad)[0], rows=batch * blocks.value,
+               ws=view('ws', lib.st_conv1d_fft_planes_ws(self.X[i].ref, self.X[i + 1].ref, l.width, 1) // 4 + 64)[0], pl=pl)
+      if fresh_tables:
+        call('st_conv1d_fft_tables_f32', l.width, pl, self._ptr(tables), tables.numel(), self.stream_ptr)
+      if fresh_g:
+        self._wplanes_fresh = False
+      self.fftb[i] = f
+    if set(self.fftb) != getattr(self, '_fftb_prev', None):
+      self._wplanes_fresh = False
+      self._wtplanes_fresh = False
+    self._fftb_prev = set(self.fftb)
 
   def _alloc_fft(self, batch):
     """Per frequency-domain layer: the transform tables and the filter spectra in both operand layouts (functions of
@@ -561,8 +604,16 @@ class Wav2LetterEngine:
       self.WTb = [None] + [z(l.kt_pad * l.nt_pad) for l in self.layers[1:]]
 
   def _refresh_bf16_filters(self, transposed, layers=None):
+    fftb = getattr(self, 'fftb', {})
     for i, l in enumerate(self.layers):
       if layers is not None and i not in layers:
+        continue
+      if i in fftb:
+        # a frequency-domain layer: its filter spectra (one bf16 plane, both operand layouts) instead of the two bf16 copies
+        if not transposed:
+          f = fftb[i]
+          call('st_conv1d_fft_filters_planes', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
+               self._ptr(f['tables']), self._ptr(f['g']), self._ptr(f['gt']), 1, self.stream_ptr)
         continue
       if transposed and i > 0:
         call('st_filters_bwd_bf16', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
@@ -613,6 +664,12 @@ class Wav2LetterEngine:
           ready.clear()
         elif i in ready:
           main.wait_event(ready.pop(i))
+      if i in self.fftb and not last:
+        f = self.fftb[i]
+        call('st_conv1d_nwc_fwd_fft_planes', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(f['gt']), self._ptr(self._slice(self.params, i)[1]),
+             l.width, f['pl'], int(l.relu), self.X[i + 1].ref, self._ptr(self.Xb[i + 1]), self._ptr(f['tables']), self._ptr(f['sf']), 1,
+             self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        continue
       call('st_conv1d_nwc_fwd_ws_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self._ptr(self.Wb[i]),
            self._ptr(self._slice(self.params, i)[1]), l.width, l.stride, self.geo[i][2], int(l.relu), self.X[i + 1].ref,
            None if last else self._ptr(self.Xb[i + 1]), self._ptr(self.X[i + 1].buf) if last else None,
@@ -628,6 +685,23 @@ class Wav2LetterEngine:
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
       beside = i in self._side_wgrad_bf16      # this layer's filter gradient runs beside its back-prop to the input
+
+      if i in self.fftb:
+        # frequency-domain layer: ONE transform of dz (bf16 spectra + the fp32 block sums) serves the filter gradient, the bias
+        # gradient and back-prop to the input
+        f = self.fftb[i]
+        call('st_conv1d_fft_dz_spectra_planes', self.dZ[i].ref, self._ptr(self.dZb[i]), l.width, self._ptr(f['tables']), self._ptr(f['zf']), 1,
+             self._ptr(f['dc']), s)
+        call('st_conv1d_nwc_bwd_filter_fft_planes', self.X[i].ref, self.dZ[i].ref, self._ptr(f['sf']), self._ptr(f['zf']), l.width,
+             self._ptr(f['tables']), self._ptr(gf), 1, self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        call('st_conv1d_fft_bias_grad_dc_f32', self._ptr(f['dc']), f['rows'], l.cout, l.n_pad, self._ptr(gb), s)
+        if on_layer_done is not None and wanted(i):
+          on_layer_done(i)
+        relu_in = self.layers[i - 1].relu
+        call('st_conv1d_nwc_bwd_data_fft_planes', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['g']), l.width, f['pl'],
+             self.X[i].ref if relu_in else None, self._ptr(self.Xb[i]) if relu_in else None, self.dZ[i - 1].ref, self._ptr(self.dZb[i - 1]),
+             self._ptr(f['tables']), 1, self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        continue
 
       def filter_gradient(i=i, l=l, gf=gf, gb=gb, ws=(self.wgrad_ws_b3 if (i % 2 == 1 and self.wgrad_ws_b3 is not None)
                                                          else self.wgrad_ws_b2) if beside else self.wgrad_ws_b):

@@ -65,15 +65,17 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
     eng.backward()
   torch.cuda.synchronize()
   eng.check_ctc_status()
-  assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 6, '\n'.join(tr.lines)
+  assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 5, '\n'.join(tr.lines)   # L9's passes + two of L8's per-bin products
   p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
   grads = eng.get_grads()
 
   # ---- end to end from the inputs ----
   t0 = time.time()
-  logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round)
+  spectral = set(eng.fftb)            # the 32-tap layer: block DFTs + per-bin products on bf16 spectra (its own storage model)
+  assert spectral == {8} and sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<') and ' batched bins=48 ' in l) == 3, '\n'.join(tr.lines)
+  logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round, spectral=spectral)
   loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)
-  ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round)
+  ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round, spectral=spectral)
   print('bf16-storage oracle on the whole shard: %.1f s' % (time.time() - t0))
   got = eng.logits_time_major().cpu().numpy()
   mx, mean = scaled_err(got, logits)
@@ -95,24 +97,31 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
   Xs = [plane(eng.X[i], eng.Xb[i]) for i in range(L)]                 # stored bf16 inputs of every layer
   dZs = [plane(eng.dZ[i], eng.dZb[i]) for i in range(L)]              # stored bf16 gradients wrt every layer's output
   for i, ((F, b), (W, s, cin, cout, relu)) in enumerate(zip(p64, layers)):
-    y = O.conv1d_same_fwd(Xs[i], O.bf16_round(F), b, s, relu)
+    if i in spectral:
+      # the frequency-domain layer against ITS storage model on the stored operands: spectra of the stored input, of the stored
+      # gradient and of the fp32 master filters rounded to bf16, everything else exact (an element of a spectrum within fp32
+      # rounding of a bf16 boundary may land on the other side than in float64: slightly looser means than the W-tap layers')
+      y, dx, dF, db = O.block_dft_conv(Xs[i], F, b, relu, dz=dZs[i], store=O.bf16_round)
+    else:
+      y = O.conv1d_same_fwd(Xs[i], O.bf16_round(F), b, s, relu)
+      dx, dF, db = O.conv1d_same_bwd(Xs[i], O.bf16_round(F), None, dZs[i], s, relu=False, need_dx=(i > 0))
+    mean_tol = 0.05 if i in spectral else 0.01
     if i + 1 < L:
       mx, mean = scaled_err(Xs[i + 1], O.bf16_round(y))
-      assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('forward', i, mx / ULP, mean / ULP)
+      assert mx <= 2.01 * ULP and mean < mean_tol * ULP, ('forward', i, mx / ULP, mean / ULP)
     else:
       mx, _ = scaled_err(plane(eng.X[L], eng.X[L].buf), y)            # logits stay fp32
       assert mx < 1e-5, ('logits from stored X10', mx)
     # filter / bias gradient of layer i from its stored operands
-    dx, dF, db = O.conv1d_same_bwd(Xs[i], O.bf16_round(F), None, dZs[i], s, relu=False, need_dx=(i > 0))
     mxF, _ = scaled_err(grads[i][0], dF)
     mxb, _ = scaled_err(grads[i][1], db)
-    assert mxF < 2e-4 and mxb < 2e-4, ('filter/bias gradient', i, mxF, mxb)
+    assert mxF < (1e-3 if i in spectral else 2e-4) and mxb < 2e-4, ('filter/bias gradient', i, mxF, mxb)
     # gradient handed to the layer below: mask of the stored activation, rounded to bf16 when written
     if i > 0:
       if layers[i - 1][4]:
         dx = dx * (Xs[i] > 0)
       mx, mean = scaled_err(dZs[i - 1], O.bf16_round(dx))
-      assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('back-prop to the input', i, mx / ULP, mean / ULP)
+      assert mx <= 2.01 * ULP and mean < mean_tol * ULP, ('back-prop to the input', i, mx / ULP, mean / ULP)
     print('kernel-level L%d ok (filters %.1e, bias %.1e of max)' % (i, mxF, mxb))
   # the bf16 copy of d loss / d logits and the fp32 CTC gradient it was rounded from
   mx, _ = scaled_err(dZs[L - 1], O.bf16_round(plane(eng.dZ[L - 1], eng.dZ[L - 1].buf)))

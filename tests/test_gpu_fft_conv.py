@@ -109,6 +109,109 @@ def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
     assert float(V[:, cin:, :].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('planes', [3, 1])
+@pytest.mark.parametrize('W,B,T,cin,cout,relu', [(32, 3, 77, 130, 200, True), (32, 2, 200, 250, 300, False), (7, 4, 150, 250, 250, True),
+                                                 (12, 3, 100, 200, 250, True)])
+def test_fft_conv_on_the_bf16_matrix_pipe(dev, planes, W, B, T, cin, cout, relu):
+  """The frequency-domain layer with its per-bin products on the bf16 matrix pipe (st_conv1d_*_fft_planes, round 4).
+  planes = 3: fp32 tensors, every spectrum value split exactly into three bf16 planes, six product terms -- against the
+  float64 oracle at the fp32 path's own tolerance (2e-5 of the tensor maximum).
+  planes = 1: bf16 tensors (BASELINE configs[3] arithmetic), ONE bf16 plane per spectrum -- against the oracle's block-DFT
+  form with the same storage model (oracle.block_dft_conv(store=bf16_round): S, Z and G rounded to bf16, everything else
+  exact): a stored bf16 result may sit one spacing from the model's where the value is on a rounding boundary (<= 2 bf16 ulp of
+  the tensor maximum), the mean far below one; the fp32 gradients of filters and bias to 1e-3 / 2e-5."""
+  from speecht_amd import _lib
+  from speecht_amd._lib import call
+  from speecht_amd.engine import channel_pitch
+  lib = _lib.load()
+  ULP = 2.0 ** -8
+  rng = np.random.default_rng(B * 100 + T + planes)
+  bf = planes == 1
+  q = O.bf16_round if bf else (lambda a: a)
+  x = q(rng.standard_normal((B, T, cin)))
+  F = (rng.standard_normal((W, cin, cout)) / np.sqrt(W * cin)).astype(np.float32).astype(np.float64)
+  bias = rng.standard_normal(cout) * 0.1
+  prev_act = q(rng.standard_normal(x.shape))
+  y_exact = O.conv1d_same_fwd(x, F, bias, 1, relu)
+  dy = rng.standard_normal(y_exact.shape)
+  dz = q(dy * (y_exact > 0) if relu else dy)
+  y_ref, dx_ref, dF_ref, db_ref = O.block_dft_conv(x, F, bias, relu, dz=dz, prev_act=prev_act, store=O.bf16_round if bf else None)
+
+  _, pl, pr = O.same_padding(T, W, 1)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  cpi = channel_pitch(cin)
+  kv, kp, npad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  call('st_packed_dims', W, cpi, cout, ctypes.byref(kv), ctypes.byref(kp), ctypes.byref(npad))
+  packed = torch.zeros(kp.value * npad.value, device=dev)
+  call('st_pack_filters_f32', P(torch.as_tensor(F, dtype=torch.float32).to(dev).contiguous()), W, cin, cout, cpi, P(packed), None)
+  bias_d = torch.zeros(2048, device=dev)
+  bias_d[:cout] = torch.as_tensor(bias, dtype=torch.float32)
+  xt = dev_tensor(dev, B, T, cin, pl, pr, x)
+  yt = dev_tensor(dev, B, T, cout, W - 1 - pl, pl)
+  act = dev_tensor(dev, B, T, cin, pl, pr, prev_act)
+  dzt = dev_tensor(dev, B, T, cout, W - 1 - pl, pl, dz)
+  dxt = dev_tensor(dev, B, T, cin, 3, 3)
+  b16 = lambda t: t.buf.to(torch.bfloat16) if bf else None
+  xb, actb, dzb = b16(xt), b16(act), b16(dzt)
+  yb = torch.zeros_like(yt.buf, dtype=torch.bfloat16) if bf else None
+  dxb = torch.zeros_like(dxt.buf, dtype=torch.bfloat16) if bf else None
+  PB = lambda t: P(t) if t is not None else None
+
+  tables = torch.zeros(lib.st_conv1d_fft_table_floats(), device=dev)
+  call('st_conv1d_fft_tables_f32', W, pl, P(tables), tables.numel(), None)
+  ge = lib.st_conv1d_fft_filter_plane_elems(W, cpi, cout)
+  g = torch.empty(planes * ge, dtype=torch.bfloat16, device=dev)
+  gt = torch.empty(planes * ge, dtype=torch.bfloat16, device=dev)
+  call('st_conv1d_fft_filters_planes', P(packed), W, cin, cout, cpi, P(tables), P(g), P(gt), planes, None)
+  sf = torch.empty(planes * lib.st_conv1d_fft_sf_floats(xt.ref, yt.ref, W), dtype=torch.bfloat16, device=dev)
+  zf = torch.empty(planes * lib.st_conv1d_fft_zf_floats(dzt.ref, W), dtype=torch.bfloat16, device=dev)
+  ws = torch.empty(lib.st_conv1d_fft_planes_ws(xt.ref, yt.ref, W, planes) // 4 + 64, device=dev)
+  rows_pad = ctypes.c_int()
+  blocks = ctypes.c_int()
+  call('st_conv1d_fft_plan', W, T, B, None, None, ctypes.byref(blocks), None, ctypes.byref(rows_pad))
+  dc = torch.full((rows_pad.value * npad.value,), 7.0, device=dev)
+
+  def stored(t3, buf_b):
+    v = (buf_b if bf else t3.buf).view(t3.batch, t3.t_pitch, t3.c_pitch)
+    return v[:, t3.halo:t3.halo + t3.frames, :t3.channels].float().cpu().numpy().astype(np.float64), v
+
+  call('st_conv1d_nwc_fwd_fft_planes', xt.ref, PB(xb), P(gt), P(bias_d), W, pl, int(relu), yt.ref, PB(yb), P(tables), P(sf), planes,
+       P(ws), ws.numel() * 4, None)
+  y, whole = stored(yt, yb)
+  scale = np.max(np.abs(y_ref))
+  if bf:
+    d = np.abs(y - O.bf16_round(y_ref)) / scale
+    assert d.max() <= 2.01 * ULP and d.mean() < 0.05 * ULP, ('forward', d.max() / ULP, d.mean() / ULP)
+    assert np.max(np.abs(y - y_exact)) < 4 * ULP * np.max(np.abs(y_exact))        # and near the exact convolution: quantisation noise only
+  else:
+    assert np.max(np.abs(y - y_ref)) < 2e-5 * scale
+  assert float(whole[:, :, cout:].float().abs().max()) == 0.0 and float(whole[:, :yt.halo].float().abs().max()) == 0.0
+
+  call('st_conv1d_fft_dz_spectra_planes', dzt.ref, PB(dzb), W, P(tables), P(zf), planes, P(dc), None)
+  call('st_conv1d_nwc_bwd_data_fft_planes', dzt.ref, P(zf), P(g), W, pl, act.ref, PB(actb), dxt.ref, PB(dxb), P(tables), planes, P(ws),
+       ws.numel() * 4, None)
+  dx, _ = stored(dxt, dxb)
+  if bf:
+    d = np.abs(dx - O.bf16_round(dx_ref)) / np.max(np.abs(dx_ref))
+    assert d.max() <= 2.01 * ULP and d.mean() < 0.05 * ULP, ('back-prop to the input', d.max() / ULP, d.mean() / ULP)
+  else:
+    assert np.max(np.abs(dx - dx_ref)) < 2e-5 * np.max(np.abs(dx_ref))
+
+  dpacked = torch.full((kp.value * npad.value,), 7.0, device=dev)
+  call('st_conv1d_nwc_bwd_filter_fft_planes', xt.ref, dzt.ref, P(sf), P(zf), W, P(tables), P(dpacked), planes, P(ws), ws.numel() * 4, None)
+  dFd = torch.empty(W * cin * cout, device=dev)
+  call('st_unpack_filters_f32', P(dpacked), W, cin, cout, cpi, P(dFd), None)
+  dF = dFd.view(W, cin, cout).cpu().numpy()
+  # (bf16 spectra: an element within fp32 rounding of a bf16 boundary lands on the other side than in the float64 model)
+  assert np.max(np.abs(dF - dF_ref)) < (1e-3 if bf else 2e-5) * np.max(np.abs(dF_ref))
+  db = torch.full((npad.value,), 7.0, device=dev)
+  call('st_conv1d_fft_bias_grad_dc_f32', P(dc), B * blocks.value, cout, npad.value, P(db), None)
+  assert np.max(np.abs(db[:cout].cpu().numpy() - db_ref)) < 2e-5 * np.max(np.abs(db_ref))
+  assert float(db[cout:].abs().max()) == 0.0
+  G = dpacked.view(kp.value, npad.value)
+  assert float(G[:, cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('B,T,cin,cout', [(4, 1001, 80, 250), (3, 400, 128, 250), (2, 333, 40, 130)])
 def test_stride2_layer_on_its_polyphase_view(dev, B, T, cin, cout):
   """The model's first layer (48 taps, stride 2; speech_model.py:279) through the stride-1 entry points: the input read

@@ -417,3 +417,37 @@ def test_block_dft_formulation_of_the_convolution_and_its_gradients(T, W, cin, c
     dF += wk[q] * (re[None] * np.cos(ang)[:, None, None] - im[None] * np.sin(ang)[:, None, None])
   np.testing.assert_allclose(dF, dF_ref, rtol=1e-10, atol=1e-10)
   np.testing.assert_allclose(Z[0].real.sum(axis=0), db_ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize('T,W,cin,cout', [(150, 7, 5, 6), (201, 32, 4, 3), (64, 12, 3, 4)])
+def test_oracle_block_dft_conv_equals_the_direct_form_and_its_storage_model_is_mild(T, W, cin, cout):
+  """oracle.block_dft_conv -- the storage-model restatement of the frequency-domain layer that the bf16-plane kernels are
+  checked against -- equals conv1d_same_fwd / conv1d_same_bwd to 1e-12 without a storage hook; with spectra rounded to bf16 the
+  results move by well under one bf16 ulp of the tensor scale, and wav2letter_forward / _backward(spectral=...) route a layer
+  through it."""
+  rng = np.random.default_rng(T)
+  x = rng.standard_normal((2, T, cin))
+  F = rng.standard_normal((W, cin, cout)) / np.sqrt(W * cin)
+  b = rng.standard_normal(cout)
+  y_ref = O.conv1d_same_fwd(x, F, b, 1, True)
+  dy = rng.standard_normal(y_ref.shape)
+  pa = rng.standard_normal(x.shape)
+  dx_ref, dF_ref, db_ref = O.conv1d_same_bwd(x, F, y_ref, dy, 1, True)
+  dz = dy * (y_ref > 0)
+  y, dx, dF, db = O.block_dft_conv(x, F, b, True, dz=dz, prev_act=pa)
+  np.testing.assert_allclose(y, y_ref, atol=1e-12)
+  np.testing.assert_allclose(dx, dx_ref * (pa > 0), atol=1e-12)
+  np.testing.assert_allclose(dF, dF_ref, atol=1e-11)
+  np.testing.assert_allclose(db, db_ref, atol=1e-12)
+  y2, dx2, dF2, _ = O.block_dft_conv(x, F, b, True, dz=dz, prev_act=pa, store=O.bf16_round)
+  for got, ref in ((y2, y_ref), (dx2, dx_ref * (pa > 0)), (dF2, dF_ref)):
+    assert 0 < np.max(np.abs(got - ref)) < 2.0 ** -8 * np.max(np.abs(ref))
+  layers = [(W, 1, cin, cout, True), (1, 1, cout, 5, False)]
+  params = [(F, b), (rng.standard_normal((1, cout, 5)), np.zeros(5))]
+  la, acts_a = O.wav2letter_forward(x, params, layers, keep=True)
+  lb, acts_b = O.wav2letter_forward(x, params, layers, keep=True, spectral={0})
+  np.testing.assert_allclose(la, lb, atol=1e-11)
+  dl = rng.standard_normal(la.shape)
+  for (fa, ba), (fb, bb) in zip(O.wav2letter_backward(acts_a, params, layers, dl), O.wav2letter_backward(acts_b, params, layers, dl, spectral={0})):
+    np.testing.assert_allclose(fa, fb, atol=1e-10)
+    np.testing.assert_allclose(ba, bb, atol=1e-10)

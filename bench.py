@@ -138,13 +138,20 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
       tail_bytes = _lib_handle().st_gemm_nn_batched_ws_bytes()
       tail, outp = P(f['ws']), ctypes.c_void_p(f['ws'].data_ptr() + tail_bytes)
       launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
-          'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
+          'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, 2 * rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
       if i > 0:
         # back-prop to the input: the same spectra read as a transposed operand (X = Z gfwd^T)
         launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
             'st_gemm_nn_batched_bt_ws_f32', P(f['zf']), nf, rp * nf, P(f['gfwd']), ka * nf, outp, ka, rp * ka, rp, nf, ka, nb, tail, tail_bytes, s)))
-      launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, outp=outp: call(
-          'st_gemm_tn_batched_f32', P(f['sf']), ka, rp * ka, P(f['zf']), nf, rp * nf, outp, ka * nf, rp, ka, nf, nb, s)))
+      if (ka // 2) % 128 == 0:
+        # the lag products as the library runs them: spectra rows read as two half-length rows, the real and the imaginary
+        # product of a bin as batches 2 b and 2 b + 1 over the spectra and their rotated copy, both against the bin's dz spectra
+        launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, outp=outp: call(
+            'st_gemm_tn_batched_shared_f32', P(f['sf']), ka // 2, rp * ka, P(f['zf']), nf // 2, rp * nf, outp, (ka // 2) * (nf // 2), 2 * rp,
+            ka // 2, nf // 2, 2 * nb, 1, s)))
+      else:
+        launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, outp=outp: call(
+            'st_gemm_tn_batched_f32', P(f['sf']), ka, 2 * rp * ka, P(f['zf']), nf, rp * nf, outp, ka * nf, rp, ka, nf, nb, s)))
       continue
     launches.append(('L%d fwd' % i, flops[i], io_bytes, lambda i=i, l=l, pl=pl, pf=pf, pb=pb: call(
         'st_conv1d_nwc_fwd_ws_f32', eng.X[i].ref, P(pf), P(pb), l.width, l.stride, pl, int(l.relu), eng.X[i + 1].ref, ws, wsb, s)))

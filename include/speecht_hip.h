@@ -146,6 +146,11 @@ int st_gemm_nn_batched_bt_ws_f32(const float* a, int64_t lda, int64_t a_batch, c
  * (m a multiple of 32, k and n of 128) -- the lag products of the filter gradient */
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
                            float* out, int64_t out_batch, int m, int k, int n, int batches, void* stream);
+/* ... with the second operand SHARED by groups of 2^z_batch_shift consecutive products (product b reads Z of batch
+ * b >> z_batch_shift): the real and the imaginary lag products of a bin -- over the input spectra and their rotated copy,
+ * rows read at half length -- both against that bin's gradient spectra */
+int st_gemm_tn_batched_shared_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
+                                  float* out, int64_t out_batch, int m, int k, int n, int batches, int z_batch_shift, void* stream);
 size_t st_conv1d_fft_table_floats(void);
 int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
 size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cout);

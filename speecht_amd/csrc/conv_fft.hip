@@ -160,13 +160,16 @@ template <int NST, bool IN_BF = false, int OUTP = 0>   // NST stages of CH frame
 __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float* __restrict__ wm, int blocks, int rows,
                                                           int rows_pad, int start, int bins, int half, int nchunks,
                                                           float* __restrict__ out, unsigned short* __restrict__ outb,
-                                                          size_t out_plane, float* __restrict__ dc) {
+                                                          size_t out_plane, float* __restrict__ dc, long bin_stride,
+                                                          float* __restrict__ out2) {
   __shared__ __attribute__((aligned(16))) float wl[KP * KP];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
   stage_matrix<KP>(wl, wm);
   __syncthreads();
-  const long plane = (long)rows_pad * 2 * half;
+  // (bin_stride: elements between the planes of consecutive bins -- rows_pad * 2 * half, or twice that when the spectra of a
+  // bin are followed by their rotated copy out2 = [S_i | -S_r], the operand of the imaginary lag products)
+  const long plane = bin_stride;
   const float* afrag = wl + 2 * l31 + h;
   for (int item = gw; item < rows_pad * nchunks; item += total) {
     const int row = item / nchunks, c = (item - row * nchunks) * 32 + l31;
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
           const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half) + c;
           if (bin < bins) {
             const long o = (long)bin * plane + (long)row * 2 * half + col;
-            if (OUTP == 0) out[o] = acc[i][r];
+            if (OUTP == 0) {
+              out[o] = acc[i][r];
+              if (out2) out2[(long)bin * plane + (long)row * 2 * half + (m < HB ? half : 0) + c] = m < HB ? -acc[i][r] : acc[i][r];
+            }
             else if (OUTP == 1) outb[o] = __builtin_bit_cast(unsigned short, (__bf16)acc[i][r]);
             else {
               unsigned short sh, sm, sl;
@@ -420,10 +426,11 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
 // ---- filter gradient: spectra of the lag products back to the W taps ---------------------------------------------
 // q [bins][2 cph][2 npo] = [S_r | S_i]^T [Z_r | Z_i]:  Re = P00 + P11, Im = P10 - P01;
 // dF[w][c][o] = (1 / N) sum_k w_k (Re cos(2 pi k w / N) - Im sin(2 pi k w / N)) into dpacked [w * cpi + c][npo].
+// split != 0: q is [bins][2][cph][npo] -- the real and the imaginary lag products themselves (half the floats)
 template <int WT>
 __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restrict__ q, int width_rt, int cin, int cout, int cpi, int cph,
                                                            int npo, int n, int bins, const f32x2* __restrict__ tw,
-                                                           float* __restrict__ dpacked) {
+                                                           float* __restrict__ dpacked, int split) {
   const int width = WT ? WT : width_rt;
   const int o = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (o >= npo) return;
@@ -431,14 +438,20 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
 #pragma unroll
   for (int w = 0; w < width; ++w) acc[w] = 0.f;
   const bool live = c < cin && o < cout;
-  const long plane = (long)2 * cph * 2 * npo;
+  const long plane = split ? (long)2 * cph * npo : (long)2 * cph * 2 * npo;
   const float inv_n = 1.f / (float)n;
   if (live) {
     for (int k = 0; k < bins; ++k) {
       const float* p = q + (long)k * plane;
       const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;      // DC (and the Nyquist bin of an even N) count once
-      const float re = (p[(long)c * 2 * npo + o] + p[(long)(cph + c) * 2 * npo + npo + o]) * wk;
-      const float im = (p[(long)(cph + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
+      float re, im;
+      if (split) {
+        re = p[(long)c * npo + o] * wk;
+        im = p[(long)cph * npo + (long)c * npo + o] * wk;
+      } else {
+        re = (p[(long)c * 2 * npo + o] + p[(long)(cph + c) * 2 * npo + npo + o]) * wk;
+        im = (p[(long)(cph + c) * 2 * npo + o] - p[(long)c * 2 * npo + npo + o]) * wk;
+      }
       const f32x2* row = tw + k * width;                   // uniform: wide scalar loads
 #pragma unroll
       for (int w = 0; w < width; ++w) {
@@ -506,7 +519,8 @@ inline int transform_wgs() { const int t = st::tuning(st::TUNE_TRANSFORM_WGS); r
 
 // tb: the tensor's bf16 form (null: read the fp32 tensor); planes: 0 -> fp32 spectra `out`, 1 / 3 -> bf16 plane(s) `outb`
 void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
-                void* outb, int planes, size_t out_plane, float* dc, hipStream_t s) {
+                void* outb, int planes, size_t out_plane, float* dc, hipStream_t s, long bin_stride = 0, float* out2 = nullptr) {
+  if (bin_stride == 0) bin_stride = (long)pl.rows_pad * 2 * half;
   const int nchunks = st::ceil_div(half, 32);
   const int wgs = std::min(transform_wgs(), st::ceil_div(pl.rows_pad * nchunks, 4));
   const int nst = frames_used <= 6 * CH ? 3 : 4;                           // the matrix has no columns past frames_used
@@ -518,7 +532,7 @@ void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float
   st::LaunchTimer timer(s);
 #define ST_DFT(NSTV, INB, OUTPV)                                                                                         \
   st::launch_timed(timer, dft_rows_kernel<NSTV, INB, OUTPV>, dim3(wgs), dim3(256), s, x, wm, pl.blocks, pl.rows, pl.rows_pad, start, \
-                   pl.bins, half, nchunks, out, ob, out_plane, dc)
+                   pl.bins, half, nchunks, out, ob, out_plane, dc, bin_stride, out2)
 #define ST_DFT_N(INB, OUTPV) do { if (nst == 3) ST_DFT(3, INB, OUTPV); else ST_DFT(4, INB, OUTPV); } while (0)
   if (!tb && planes == 0) ST_DFT_N(false, 0);
   else if (!tb && planes == 3) ST_DFT_N(false, 3);
@@ -547,6 +561,9 @@ void launch_idft(const float* in, const float* winv, const Plan& p, int half_in,
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
+// the filter gradient's lag products as separate real / imaginary products over half-length rows (see bwd_filter): needs the
+// spectra halves to tile the filter-gradient kernel (128 columns)
+bool split_lag_products(int half) { return half % 128 == 0; }
 
 template <int OUTP>
 void launch_filters_planes(int width, const dim3& grid, hipStream_t s, const float* packed, int cin, int cout, int cin_pitch, int cph,
@@ -590,6 +607,12 @@ int st_gemm_nn_batched_bt_ws_f32(const float* a, int64_t lda, int64_t a_batch, c
 int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch, float* out,
                            int64_t out_batch, int m, int k, int n, int batches, void* stream) {
   return st::gemm_tn_batched(a, lda, a_batch, z, ldz, z_batch, out, out_batch, m, k, n, batches, st::as_stream(stream));
+}
+
+int st_gemm_tn_batched_shared_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch, float* out,
+                                  int64_t out_batch, int m, int k, int n, int batches, int z_batch_shift, void* stream) {
+  ST_REQUIRE(z_batch_shift >= 0 && z_batch_shift < 8, "gemm_tn_batched_shared: bad shift");
+  return st::gemm_tn_batched(a, lda, a_batch, z, ldz, z_batch, out, out_batch, m, k, n, batches, st::as_stream(stream), z_batch_shift);
 }
 
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad) {
@@ -643,10 +666,12 @@ int st_conv1d_fft_filters_f32(const float* packed, int width, int cin, int cout,
 }
 
 // floats of the input spectra sf and of the dz spectra zf
+// (the fp32 form keeps, per bin, the spectra [S_r | S_i] followed by their rotated copy [S_i | -S_r]: read as matrices of
+// half-length rows the two are the operands of the real and of the imaginary lag products of the filter gradient)
 size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int width) {
   if (!x || !y || !width_ok(width)) return 0;
   const Plan p = make_plan(width, y->frames, y->batch);
-  return (size_t)p.bins * p.rows_pad * 2 * half_of(x->c_pitch);
+  return (size_t)p.bins * 2 * p.rows_pad * 2 * half_of(x->c_pitch);
 }
 
 size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
@@ -675,9 +700,11 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
   const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
   float* const sk = reinterpret_cast<float*>(workspace);
   float* yf = sk + st::SK_WS_FLOATS;
-  launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half_of(x->c_pitch), sf, nullptr, 0, 0, nullptr, s);
-  if (int e = st::gemm_nn_batched(sf, ka, (long)p.rows_pad * ka, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka,
-                                  nf, p.bins, s, sk))
+  const int half = half_of(x->c_pitch);
+  const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin
+  launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half, sf, nullptr, 0, 0, nullptr, s, s_bin,
+             split_lag_products(half) ? sf + (long)p.rows_pad * ka : nullptr);
+  if (int e = st::gemm_nn_batched(sf, ka, s_bin, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka, nf, p.bins, s, sk))
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames, nullptr};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
@@ -869,7 +896,7 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
                                  p.rows_pad, nf, p.bins, s))
     return e;
   const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
-  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked);
+  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0);
   return st::check_launch("conv fft planes bwd_filter");
 }
 
@@ -883,13 +910,27 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
-  // Q[bin] = Sf[bin]^T (2 half x rows_pad) * Zf[bin] (rows_pad x 2 npo): the reduction-major kernel of the W-tap filter
-  // gradient takes both spectra as they are
-  if (int e = st::gemm_tn_batched(sf, ka, (long)p.rows_pad * ka, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf,
-                                  p.bins, s))
-    return e;
+  const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin (st_conv1d_fft_sf_floats)
   const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
-  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked);
+  if (split_lag_products(half)) {
+    // The lag products Q = S^H-like sums over the rows of a bin:  Re Q = S_r^T Z_r + S_i^T Z_i,  Im Q = S_i^T Z_r - S_r^T Z_i.
+    // A spectra row [re | im] read as TWO rows of half length turns each into ONE plain product over 2 * rows_pad rows:
+    // Re Q = S2^T Z2 with S2 = S as [2 rows][half], Z2 = Z as [2 rows][npo]; Im Q the same with the rotated copy [S_i | -S_r]
+    // the forward pass wrote behind S.  Against the 2 x 2 block form of rounds 2-3 ([S_r | S_i]^T [Z_r | Z_i], four blocks
+    // that filters_idft combined): half the output floats (L8: 403 -> 201 MB written and read back), a reduction twice as
+    // long per output tile (16 stages instead of 8 of a kernel whose prologue and 64 KB epilogue were most of its time), and
+    // the real and the imaginary product of a bin in one launch (batch 2 b + j reads Z of bin b).
+    if (int e = st::gemm_tn_batched(sf, half, (long)p.rows_pad * ka, zf, npo, (long)p.rows_pad * nf, qf, (long)half * npo, 2 * p.rows_pad,
+                                    half, npo, 2 * p.bins, s, 1))
+      return e;
+    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+  } else {
+    // (spectra halves that do not tile the kernel -- the polyphase first layer: 192 columns): Q[bin] = [S_r | S_i]^T [Z_r | Z_i],
+    // 2 half x 2 npo, combined by filters_idft
+    if (int e = st::gemm_tn_batched(sf, ka, s_bin, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf, p.bins, s))
+      return e;
+    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0);
+  }
   return st::check_launch("conv fft bwd_filter");
 }
 

@@ -793,6 +793,7 @@ struct TNParams {
   int amap_batches;      // utterances (rows never advance past the last one)
   int adv_b, adv_t;      // 32 rows = adv_b utterances + adv_t frames
   long a_batch, z_batch, o_batch;   // blockIdx.z: independent products of the same shape (csrc/conv_fft.hip), float strides
+  int z_shift;                      // ... product b reads Z of batch b >> z_shift (the real and imaginary lag products of a bin share Z)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source of rows past a split's end
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
   const int k0 = tile_k * BKO, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const float* __restrict__ Ab = p.A + (long)blockIdx.z * p.a_batch;
-  const float* __restrict__ Zb = p.Z + (long)blockIdx.z * p.z_batch;
+  const float* __restrict__ Zb = p.Z + (long)(blockIdx.z >> p.z_shift) * p.z_batch;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
 
@@ -1331,7 +1332,7 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
 // Plain batched out[b] = A[b]^T * Z[b] on the filter-gradient kernel: A [M][lda] (K <= lda columns used), Z [M][ldz]
 // (N columns), out [K][N]; the reduction runs over the M rows.  K a multiple of 128, N of 128, M of 32.
 int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out,
-                        long o_batch, int M, int K, int N, int batches, hipStream_t s) {
+                        long o_batch, int M, int K, int N, int batches, hipStream_t s, int z_batch_shift) {
   if (!(A && Z && out && M > 0 && M % 32 == 0 && K % 128 == 0 && N % 128 == 0 && batches > 0)) {
     st::set_error("gemm_tn_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
@@ -1354,6 +1355,7 @@ int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, 
   p.adv_b = 32 / M;
   p.adv_t = 32 % M;
   p.a_batch = a_batch; p.z_batch = z_batch; p.o_batch = o_batch;
+  p.z_shift = z_batch_shift;
   st::trace("gemm_tn<128> batched bins=%d M=%d Kp=%d Np=%d gflop=%.3f", batches, M, K, N, 2e-9 * M * (double)K * N * batches);
   {
     st::LaunchTimer timer(s);

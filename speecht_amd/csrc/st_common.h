@@ -51,7 +51,7 @@ constexpr long SK_WS_FLOATS = SK_CTRL_WORDS + 768L * 64 * 128;
 int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long b_batch, float* C, long ldc, long c_batch,
                     int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr, bool b_transposed = false);
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
-                    int M, int K, int N, int batches, hipStream_t s);
+                    int M, int K, int N, int batches, hipStream_t s, int z_batch_shift = 0);
 
 // conv_bf16.hip: the same per-bin products on the bf16 matrix pipe (planes = 1: bf16 operands; 3: the exact 3-way split of fp32
 // operands, six product terms -- fp32-accurate), and the reduction-major copies of spectra the lag products read

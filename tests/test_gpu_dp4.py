@@ -63,7 +63,7 @@ for k in range(3):
 torch.cuda.synchronize()
 # the frequency-domain path with its side-stream filter gradients really ran (36-bin products of the 7-tap layers)
 assert sorted(eng.fft) == list(range(9)) and all("ws2" in eng.fft[i] for i in range(1, 8)), sorted(eng.fft)
-assert sum(1 for l in lines if l.startswith("gemm_tn<") and " batched bins=36 " in l) == 7, "\n".join(lines)
+assert sum(1 for l in lines if l.startswith("gemm_tn<") and " batched bins=72 " in l) == 7, "\n".join(lines)
 mine = eng.params.clone()
 gathered = [torch.zeros_like(mine) for _ in range(world)]
 dist.all_gather(gathered, mine)

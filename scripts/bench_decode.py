@@ -36,6 +36,7 @@ def main():
   ap.add_argument('--reps', type=int, default=5)
   ap.add_argument('--samples', type=int, default=7)
   ap.add_argument('--pipeline-batches', type=int, default=12, help='batches through inference.transcribe for the pipelined figure')
+  ap.add_argument('--resident-batches', type=int, default=48, help='batches of the resident forward + search loop (a search is still running when the last forward pass ends: ~one batch time of drain, amortised over these)')
   args = ap.parse_args()
   dev = torch.device('cuda:0')
   frames = 1 + int(args.seconds * 16000) // 160
@@ -106,26 +107,29 @@ def main():
   res['ids_equal'] = res['pipelined']['ids_digest'] == res['serial_loop']['ids_digest']
   # the same overlap on a RESIDENT batch (what `utt_per_s_forward_plus_beam` above is, serially): forward of batch k + 1 on the
   # compute stream while batch k is searched on the decoder stream
-  cs, ds = E.decoder_stream_pair(dev)
   eng.load_batch(x, seq_lens)
   torch.cuda.synchronize()
-  per = []
-  for _ in range(3):
-    t0 = time.perf_counter()
-    pending = None
-    for _ in range(args.pipeline_batches):
-      with torch.cuda.stream(cs):
-        eng.forward()
-        h = eng.beam_search_decode_async(args.beam, ds)
-      if pending is not None:
-        pending.result()
-      pending = h
-    pending.result()
-    per.append((time.perf_counter() - t0) / args.pipeline_batches * 1e3)
-  out['utt_per_s_forward_plus_beam_overlapped'] = round(args.batch / float(np.median(per)) * 1e3, 1)
-  out['ms_per_batch_forward_plus_beam_overlapped'] = round(float(np.median(per)), 3)
-  res['decoder_streams'] = 'CU-masked (hipExtStreamCreateWithCUMask: decoder 16 CUs, forward 240)' if isinstance(
-      E.decoder_stream_pair(dev)[0], torch.cuda.ExternalStream) else 'plain streams'
+  for decoders in (1, 2):
+    cs, ds = E.decoder_streams(dev, decoders)
+    per = []
+    for _ in range(3):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      pending = []
+      for _ in range(args.resident_batches):
+        with torch.cuda.stream(cs):
+          eng.forward()
+          pending.append(eng.beam_search_decode_async(args.beam, ds))
+        if len(pending) > decoders:
+          pending.pop(0).result()
+      for h in pending:
+        h.result()
+      per.append((time.perf_counter() - t0) / args.resident_batches * 1e3)
+    tag = '' if decoders == 2 else '_one_decoder_stream'
+    out['utt_per_s_forward_plus_beam_overlapped' + tag] = round(args.batch / float(np.median(per)) * 1e3, 1)
+    out['ms_per_batch_forward_plus_beam_overlapped' + tag] = round(float(np.median(per)), 3)
+  res['decoder_streams'] = 'CU-masked (hipExtStreamCreateWithCUMask: two decoder streams on 16 CUs, forward 240)' if isinstance(
+      E.decoder_streams(dev, 2)[0], torch.cuda.ExternalStream) else 'plain streams'
   res['note'] = ('inference.transcribe(beam_width=%d) on %d batches of %d x %g s: host padding, H2D and read-back included; the '
                  'network\'s own logits with the output layer scaled to std 3' % (args.beam, args.pipeline_batches, args.batch, args.seconds))
   out['transcribe_beam'] = res

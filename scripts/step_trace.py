@@ -8,7 +8,7 @@ import sys
 import os
 f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'clip_adam' in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if 'sumsq_partial' in r['Kernel_Name']]
 a, b = marks[-2], marks[-1]
 total = 0.0
 for r in rows[a + 1:b + 1]:

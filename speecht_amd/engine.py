@@ -130,40 +130,47 @@ class _PendingBeamDecode:
             s['score_h'][:self._batch].numpy().reshape(-1, 1).copy())
 
 
-def decoder_stream_pair(device):
-  """(compute stream, decoder stream) for overlapping a one-wave-per-utterance decoder with the NEXT batch's forward pass.
+def decoder_streams(device, decoders=2):
+  """(compute stream, [decoder streams]) for overlapping a one-wave-per-utterance decoder with the NEXT batches' forward passes.
 
   fp32 MFMAs execute on the VALU datapath: a VALU / LDS chain that shares its SIMD with the waves of an fp32 GEMM gets an
   issue slot every ~25 cycles instead of every ~4 (measured round 4: the CTC recursion under a GEMM 122 -> 560 us, the beam
   search beside the next forward pass 3.9 -> 6.5 ms per batch).  So the two run on DISJOINT compute units: streams created
-  with hipExtStreamCreateWithCUMask, the decoder on 16 CUs (mask bits 0..15 -- observed on MI355X: two CUs of every XCD; any
+  with hipExtStreamCreateWithCUMask, the decoders on 16 CUs (mask bits 0..15 -- observed on MI355X: two CUs of every XCD; any
   other layout tried costs the GEMMs 10-70 %), the forward pass on the other 240 (+11 % on the forward pass alone, 3.6 -> 4.0
-  ms at configs[4]; overlapped 4.4 ms per batch against 8.0 serial).  Placement is a matter of speed only.  Falls back to two
-  plain streams where the runtime lacks the call."""
+  ms at configs[4]).  A search is one wavefront per utterance -- 16 of the decoder CUs' 64 SIMDs at configs[4] -- and takes a
+  little longer than the forward pass: with ONE decoder stream the search sets the pace (4.18 ms per batch against 7.4 serial),
+  with two the searches of consecutive batches run side by side on the same 16 CUs and the forward pass does (4.02 ms).
+  Placement is a matter of speed only.  Falls back to plain streams where the runtime lacks the call."""
   import ctypes as C
   import glob
-  key = str(device)
+  key = (str(device), int(decoders))
   if key in _DECODER_STREAMS:
     return _DECODER_STREAMS[key]
-  pair = None
+  made = None
   if os.environ.get('ST_DECODER_CU_MASK', '1') != '0':
     try:
       hip = C.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64*'))[0])
       made = []
       with torch.cuda.device(device):
-        for words in ([0x0000ffff] + [0] * 7, [0xffff0000] + [0xffffffff] * 7):
+        for words in [[0xffff0000] + [0xffffffff] * 7] + [[0x0000ffff] + [0] * 7] * int(decoders):
           arr = (C.c_uint32 * 8)(*words)
           handle = C.c_void_p()
           if hip.hipExtStreamCreateWithCUMask(C.byref(handle), 8, arr) != 0 or not handle.value:
             raise OSError('hipExtStreamCreateWithCUMask failed')
           made.append(torch.cuda.ExternalStream(handle.value, device=device))
-      pair = (made[1], made[0])
     except (OSError, IndexError, AttributeError):
-      pair = None
-  if pair is None:
-    pair = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-  _DECODER_STREAMS[key] = pair
-  return pair
+      made = None
+  if made is None:
+    made = [torch.cuda.Stream(device) for _ in range(1 + int(decoders))]
+  _DECODER_STREAMS[key] = (made[0], made[1:])
+  return _DECODER_STREAMS[key]
+
+
+def decoder_stream_pair(device):
+  """(compute stream, decoder stream): `decoder_streams` with one decoder."""
+  compute, decoders = decoder_streams(device, 1)
+  return compute, decoders[0]
 
 
 _DECODER_STREAMS = {}
@@ -1300,18 +1307,26 @@ class Wav2LetterEngine:
 
   def beam_search_decode_async(self, beam_width=16, decode_stream=None):
     """``beam_search_decode`` without the host synchronisation and OFF the compute stream: the logits and lengths of this
-    batch are copied into one of two decoder slots, the search runs on ``decode_stream`` (default: a stream of the engine's
-    own; `decoder_stream_pair` gives a CU-masked one) and its outputs go to pinned host memory; returns a handle whose
+    batch are copied into a decoder slot, the search runs on ``decode_stream`` (default: a stream of the engine's own;
+    `decoder_streams` gives CU-masked ones -- a list of streams is used in turn, consecutive batches' searches then run side by
+    side) and its outputs go to pinned host memory; returns a handle whose
     ``result()`` waits for this batch only.  The caller enqueues the next batch's forward pass meanwhile -- the search is ONE
     wavefront per utterance (3.9 ms for 16 x 30 s, beam 16: as long as the forward pass) and leaves the chip to it."""
     lib = _lib.load()
     B, T = self.dec_lens.numel(), self.t_out
     xl = self.X[-1]
     need = lib.st_ctc_beam_ws(B, T, int(beam_width))
-    if not hasattr(self, '_beam_slots'):
-      self._beam_slots, self._beam_turn = [None, None], 0
-    self._beam_turn ^= 1
-    slot = self._beam_slots[self._beam_turn]
+    streams = list(decode_stream) if isinstance(decode_stream, (list, tuple)) else [decode_stream]
+    # one slot more than decoder streams: the forward pass fills a slot while every stream searches one
+    if not hasattr(self, '_beam_slots') or len(self._beam_slots) != len(streams) + 1:
+      for old in getattr(self, '_beam_slots', []):
+        if old is not None:
+          old['event'].synchronize()
+      self._beam_slots, self._beam_turn = [None] * (len(streams) + 1), 0
+    self._beam_turn += 1
+    which = self._beam_turn % len(self._beam_slots)
+    slot = self._beam_slots[which]
+    decode_stream = streams[self._beam_turn % len(streams)]
     main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     if decode_stream is None:
       if getattr(self, '_decode_stream', None) is None:
@@ -1328,7 +1343,7 @@ class Wav2LetterEngine:
                   ids_h=i32(B * T, pin_memory=True), lens_h=i32(B, pin_memory=True),
                   score_h=torch.empty(max(B, 1), dtype=torch.float32, pin_memory=True), event=torch.cuda.Event())
       slot['event'].record(decode_stream)
-      self._beam_slots[self._beam_turn] = slot
+      self._beam_slots[which] = slot
     self._wait_uploads()
     main.wait_event(slot['event'])                               # the search that last read this slot is through
     with torch.cuda.stream(main):

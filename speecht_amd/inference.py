@@ -38,6 +38,10 @@ def _plan(features, batch_size, bucket):
 # Whether `transcribe` overlaps host staging / read-back with the GPU by default.  Decided by measurement
 # (scripts/bench_inference.py, profiles/r3_inference_config3_*.json: 2 048 utterances, windows >= 0.5 s, median of 5).
 DEFAULT_PIPELINE = True
+# Decoder streams of the pipelined beam search: a search (one wavefront per utterance) takes a little longer than the forward
+# pass of the next batch, so two consecutive batches are searched side by side on the decoder's compute units
+# (scripts/bench_decode.py, profiles/r4_decode_config5.json).
+BEAM_DECODERS = 2
 
 
 def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None, beam_width=None):
@@ -49,8 +53,9 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None, beam
   into pinned host memory and copies it to the device on its own stream while the GPU runs batch k, and the
   transcripts of batch k are read back (pinned, asynchronous) after batch k+1 has been enqueued.  Same
   launches on the same data as the serial loop, hence identical ids.  With ``beam_width`` the search of batch k runs on a
-  decoder stream of its own -- on compute units of its own, `engine.decoder_stream_pair` -- under the forward pass of batch
-  k+1: one wavefront per utterance searches as long as the whole chip convolves (configs[4]: 3.9 against 3.6 ms)."""
+  decoder stream -- on compute units of its own, `engine.decoder_streams` -- under the forward passes of batches k+1 and
+  k+2: one wavefront per utterance searches a little longer than the rest of the chip convolves (configs[4]: 3.9 against
+  3.6 ms), so two searches are in flight."""
   if not features:
     return [], []
   if pipeline is None:
@@ -77,9 +82,11 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None, beam
 
   import contextlib
   import torch
+  depth = 1                                      # batches whose transcripts are still on their way when the next is enqueued
   if beam_width:
-    from .engine import decoder_stream_pair
-    compute_stream, decode_stream = decoder_stream_pair(engine.device)
+    from .engine import decoder_streams
+    compute_stream, decode_stream = decoder_streams(engine.device, BEAM_DECODERS)
+    depth = len(decode_stream)
     torch.cuda.synchronize(engine.device)        # weights / buffers written on other streams are in place
     on_compute = lambda: torch.cuda.stream(compute_stream)
   else:
@@ -87,7 +94,7 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None, beam
   with _PIPELINE_LOCK:               # the pinned staging ring of a device serves one pipeline at a time
     stager = _Stager(engine.device, features, lengths, buckets)
     stager.start()
-    pending = None
+    pending = []
     try:
       for idx in buckets:
         staged = stager.get()
@@ -95,10 +102,11 @@ def transcribe(engine, features, batch_size=64, bucket=True, pipeline=None, beam
           engine.load_batch(staged, [lengths[i] for i in idx])
           engine.forward()
           handle = engine.beam_search_decode_async(beam_width, decode_stream) if beam_width else engine.greedy_decode_async()
-        if pending is not None:
-          collect(*pending)
-        pending = (handle, idx)
-      collect(*pending)
+        pending.append((handle, idx))
+        if len(pending) > depth:
+          collect(*pending.pop(0))
+      for item in pending:
+        collect(*item)
     finally:
       stager.close()
       if beam_width:

@@ -133,9 +133,10 @@ struct TransposeJob {
   unsigned short* dst;
   unsigned short* zero_tail;
   int rows, row0, step, t_pitch, c_pitch, c_rows, y_tiles;
+  unsigned short flip;                                 // 0x8000: the copy is negated (sign bit of every element)
 };
 struct TransposeJobs {
-  TransposeJob job[3];
+  TransposeJob job[4];
   int n, tq;
   long pitch;                                          // row pitch of the transposed planes, >= batch * tq
 };
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(TransposeJobs js) {
     if (c < jb.c_rows && j < tq) {                    // zeros outside the source
       u16x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = tile[q * 4 + e][it * 16 + r16];
+      for (int e = 0; e < 4; ++e) v[e] = tile[q * 4 + e][it * 16 + r16] ^ jb.flip;
       *reinterpret_cast<u16x4*>(jb.dst + (size_t)c * row_len + (size_t)b * tq + j) = v;
     }
   }
@@ -233,6 +234,7 @@ struct X6Params {
   int tiles_m, tiles_n, chunk;           // XCD-aware tile order: the 8 XCDs as a gm x gn grid over the tile grid,
   int gm, tm_per, tn_per;                // each XCD owns tm_per x tn_per tiles (chunk = tm_per * tn_per), see launch_gemm
   int splits; long slab_stride;          // reduction split (taps == 1): split s stores to C + s * slab_stride
+  int b_bin_shift;                       // matrices 2^shift at a time share a B operand (B + (bin >> shift) * b_bin)
   int rows_per_bin; long b_bin;          // > 0: A / C are `M / rows_per_bin` matrices stacked along M (the frequency bins of
                                          // conv_fft.hip), the B operand of the bin a tile lies in starts at B + bin * b_bin
 };
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nn_bf16_kernel(X6Params p) 
     const int r = wave * RW + i * RPP + prow;
     asrc[i] = p.A + a_off[r];
     slot8[i] = (pslot ^ ((r / RPB) % SLOTS)) * 8;
-    bsrc[i] = p.B + (p.rows_per_bin > 0 ? (long)(m0 / p.rows_per_bin) * p.b_bin : 0L) + (long)min(n0 + r, p.Np - 1) * p.Kp;
+    bsrc[i] = p.B + (p.rows_per_bin > 0 ? (long)((m0 / p.rows_per_bin) >> p.b_bin_shift) * p.b_bin : 0L) + (long)min(n0 + r, p.Np - 1) * p.Kp;
   }
   const int ktail = p.Kvalid - 8;
   constexpr int N_DMA = 2 * NP * PPW;
@@ -1043,7 +1045,7 @@ WgradPlan wgrad_plan(const st_tensor3& x, const st_tensor3& dz, int width, int s
 // row = channel, `pitch` apart, bins `rows_of_reduction` apart inside a row -- see st::transpose_bf16_bins).
 template <int NP>
 static int gemm_bins(const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes, size_t b_plane,
-                     long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s) {
+                     long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s, int b_bin_shift) {
   X6Params p{};
   p.A = reinterpret_cast<const __bf16*>(a_planes);
   p.a_plane = a_plane;
@@ -1064,20 +1066,22 @@ static int gemm_bins(const void* a_planes, size_t a_plane, long a_rows_apart, lo
   p.cp = k;
   p.rows_per_bin = rows;
   p.b_bin = b_bin;
+  p.b_bin_shift = b_bin_shift;
   return launch_gemm<NP>(p, s);
 }
 
 }  // namespace
 
 int st::gemm_bf16_bins(int planes, const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes,
-                       size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s) {
+                       size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s,
+                       int b_bin_shift) {
   if (!(a_planes && bt_planes && c && rows > 0 && rows % 128 == 0 && k > 0 && k % 32 == 0 && n > 0 && n % 128 == 0 && bins > 0 &&
-        (planes == 1 || planes == 3) && a_rows_apart % 8 == 0 && a_bin % 8 == 0 && ldb % 8 == 0 && b_bin % 8 == 0 && ldc % 4 == 0)) {
+        (planes == 1 || planes == 3) && b_bin_shift >= 0 && b_bin_shift <= 1 && a_rows_apart % 8 == 0 && a_bin % 8 == 0 && ldb % 8 == 0 && b_bin % 8 == 0 && ldc % 4 == 0)) {
     st::set_error("gemm_bf16_bins: bad shape rows=%d k=%d n=%d bins=%d planes=%d", rows, k, n, bins, planes);
     return ST_EINVAL;
   }
-  return planes == 3 ? gemm_bins<3>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s)
-                     : gemm_bins<1>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s);
+  return planes == 3 ? gemm_bins<3>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s, b_bin_shift)
+                     : gemm_bins<1>(a_planes, a_plane, a_rows_apart, a_bin, bt_planes, b_plane, ldb, b_bin, c, ldc, rows, k, n, bins, s, b_bin_shift);
 }
 
 // dst[c][bin * rows + r] = src[bin][r][c] (2-byte elements, one plane): the reduction-major copies of the spectra that the lag
@@ -1103,6 +1107,41 @@ int st::transpose_bf16_bins(const void* src, void* dst, int bins, int rows, int 
   js.job[0].y_tiles = cols / 64;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3(rows / 64, cols / 64, bins), dim3(256), 0, s, js);
   return st::check_launch("transpose_bf16_bins");
+}
+
+// The same copies for the lag products in their split form (conv_fft.hip: Re Q = S2^T Z2, Im Q = S'2^T Z2 over the half-length
+// row views of the spectra [re | im], cols = 2 * half): the reduction index of a bin runs over (part, r) -- real parts, then
+// imaginary parts.  forms = 1 (the dz spectra):  dst[c][(bin * 2 + part) * rows + r] = src[bin][r][part * half + c];
+// forms = 2 (the input spectra, both operands behind each other: batch 2 bin + j of the stacked product):
+//   dst[c][((bin * 2 + j) * 2 + part) * rows + r] = j == 0 ? S[part]  :  (part == 0 ? S[1] : -S[0])      (S' = [S_i | -S_r]).
+int st::transpose_bf16_bins_split(const void* src, void* dst, int bins, int rows, int cols, int forms, hipStream_t s) {
+  if (!(src && dst && bins > 0 && rows > 0 && rows % 64 == 0 && cols > 0 && cols % 128 == 0 && (forms == 1 || forms == 2))) {
+    st::set_error("transpose_bf16_bins_split: bad shape bins=%d rows=%d cols=%d forms=%d", bins, rows, cols, forms);
+    return ST_EINVAL;
+  }
+  const int half = cols / 2;
+  TransposeJobs js{};
+  js.n = 2 * forms;
+  js.tq = 2 * forms * rows;
+  js.pitch = (long)bins * js.tq;
+  for (int j = 0; j < forms; ++j)
+    for (int part = 0; part < 2; ++part) {
+      TransposeJob& jb = js.job[j * 2 + part];
+      const int from = j == 0 ? part : 1 - part;            // which half of the source row
+      jb.src = reinterpret_cast<const unsigned short*>(src) + from * half;
+      jb.dst = reinterpret_cast<unsigned short*>(dst) + (size_t)(j * 2 + part) * rows;
+      jb.zero_tail = nullptr;
+      jb.rows = rows;
+      jb.row0 = 0;
+      jb.step = 1;
+      jb.t_pitch = rows;
+      jb.c_pitch = cols;                                     // (the source row pitch; only `half` columns of it are this job's)
+      jb.c_rows = half;
+      jb.y_tiles = half / 64;
+      jb.flip = (j == 1 && part == 1) ? 0x8000 : 0;
+    }
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(rows / 64, js.n * (half / 64), bins), dim3(256), 0, s, js);
+  return st::check_launch("transpose_bf16_bins_split");
 }
 
 namespace {

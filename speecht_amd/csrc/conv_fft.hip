@@ -793,7 +793,8 @@ size_t st_conv1d_fft_planes_ws(const st_tensor3* x, const st_tensor3* y, int wid
   // [stream-K area (unused here, kept for a common layout) | fp32 product spectra: max(yf, xf, qf) | reduction-major bf16 copies
   //  of both spectra for the lag products, `planes` each]
   const size_t prod = std::max((size_t)p.bins * p.rows_pad * nf, (size_t)p.bins * ka * nf);
-  return (st::SK_WS_FLOATS + prod + 64) * sizeof(float) + planes * (ka + nf) * red * 2 + 512;
+  // (the input spectra twice when the lag products run in their split form: both operands of it, st::transpose_bf16_bins_split)
+  return (st::SK_WS_FLOATS + prod + 64) * sizeof(float) + planes * (2 * ka + nf) * red * 2 + 512;
 }
 
 int st_conv1d_nwc_fwd_fft_planes(const st_tensor3* x, const void* x_bf16, const void* gt_planes, const float* bias, int width,
@@ -883,10 +884,25 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
   const long red = (long)p.bins * p.rows_pad;
   const size_t prod = std::max((size_t)p.bins * p.rows_pad * nf, (size_t)p.bins * ka * nf);
   float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
-  unsigned short* st_planes = reinterpret_cast<unsigned short*>(qf + prod + 64);           // [planes][ka][red]
-  unsigned short* zt_planes = st_planes + (size_t)planes * ka * red;                       // [planes][nf][red]
+  unsigned short* st_planes = reinterpret_cast<unsigned short*>(qf + prod + 64);           // [planes][ka][red] (split: [half][4 red])
+  unsigned short* zt_planes = st_planes + (size_t)planes * 2 * ka * red;                   // [planes][nf][red] (split: [npo][2 red])
   const unsigned short* sfp = reinterpret_cast<const unsigned short*>(sf_planes);
   const unsigned short* zfp = reinterpret_cast<const unsigned short*>(zf_planes);
+  const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
+  if (split_lag_products(half)) {
+    // the split form of st_conv1d_nwc_bwd_filter_fft_f32: Re Q and Im Q as plain products over 2 * rows_pad (part, row) pairs,
+    // the rotated operand S' = [S_i | -S_r] formed by the transposing copy (a sign flip of bf16 is exact); batch 2 b + j reads
+    // the dz spectra of bin b
+    for (int pl = 0; pl < planes; ++pl) {
+      if (int e = st::transpose_bf16_bins_split(sfp + (size_t)pl * red * ka, st_planes + (size_t)pl * 2 * ka * red, p.bins, p.rows_pad, ka, 2, s)) return e;
+      if (int e = st::transpose_bf16_bins_split(zfp + (size_t)pl * red * nf, zt_planes + (size_t)pl * nf * red, p.bins, p.rows_pad, nf, 1, s)) return e;
+    }
+    if (int e = st::gemm_bf16_bins(planes, st_planes, (size_t)2 * ka * red, 4 * red, 2L * p.rows_pad, zt_planes, (size_t)nf * red, 2 * red,
+                                   2L * p.rows_pad, qf, npo, half, 2 * p.rows_pad, npo, 2 * p.bins, s, 1))
+      return e;
+    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+    return st::check_launch("conv fft planes bwd_filter");
+  }
   for (int pl = 0; pl < planes; ++pl) {
     if (int e = st::transpose_bf16_bins(sfp + (size_t)pl * red * ka, st_planes + (size_t)pl * ka * red, p.bins, p.rows_pad, ka, s)) return e;
     if (int e = st::transpose_bf16_bins(zfp + (size_t)pl * red * nf, zt_planes + (size_t)pl * nf * red, p.bins, p.rows_pad, nf, s)) return e;
@@ -895,7 +911,6 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
   if (int e = st::gemm_bf16_bins(planes, st_planes, (size_t)ka * red, red, p.rows_pad, zt_planes, (size_t)nf * red, red, p.rows_pad, qf, nf, ka,
                                  p.rows_pad, nf, p.bins, s))
     return e;
-  const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
   ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0);
   return st::check_launch("conv fft planes bwd_filter");
 }

@@ -56,8 +56,10 @@ int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long
 // conv_bf16.hip: the same per-bin products on the bf16 matrix pipe (planes = 1: bf16 operands; 3: the exact 3-way split of fp32
 // operands, six product terms -- fp32-accurate), and the reduction-major copies of spectra the lag products read
 int gemm_bf16_bins(int planes, const void* a_planes, size_t a_plane, long a_rows_apart, long a_bin, const void* bt_planes,
-                   size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s);
+                   size_t b_plane, long ldb, long b_bin, float* c, long ldc, int rows, int k, int n, int bins, hipStream_t s,
+                   int b_bin_shift = 0);
 int transpose_bf16_bins(const void* src, void* dst, int bins, int rows, int cols, hipStream_t s);
+int transpose_bf16_bins_split(const void* src, void* dst, int bins, int rows, int cols, int forms, hipStream_t s);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1,22 +1,28 @@
 #!/bin/bash
-# gpurun_out/ (scratch) -> profiles/ (tracked): the artefacts of scripts/gpu_round3_final.sh under their round-3 names
+# usage: copy_round_profiles.sh <round>: gpurun_out/ (scratch) -> profiles/ (tracked), the artefacts of scripts/gpu_round_final.sh
+# under their round names
 set -e
+N=${1:?round number}
 cd "$(dirname "$0")/.."
-R=gpurun_out/round3 F=gpurun_out/r3final
-cp $R/bench.json profiles/r3_bench.json
-cp $R/bench_under_rocprof.json profiles/r3_bench_under_rocprof.json
-cp $R/kernel_stats.csv profiles/r3_kernel_stats.csv
-cp $R/step_timeline.txt profiles/r3_step_timeline.txt
+R=gpurun_out/round$N F=gpurun_out/r${N}final P=profiles/r${N}
+cp $R/bench.json ${P}_bench.json
+cp $R/bench_under_rocprof.json ${P}_bench_under_rocprof.json
+cp $R/bench_steps_only_under_rocprof.json ${P}_bench_steps_only_under_rocprof.json
+cp $R/kernel_stats.csv ${P}_kernel_stats.csv
+cp $R/kernel_stats_steps_only.csv ${P}_kernel_stats_steps_only.csv
+cp $R/step_timeline.txt ${P}_step_timeline.txt
 cp $R/traffic.json profiles/traffic.json
 cp $R/mfma_util.json profiles/mfma_util.json
-cp $F/kernel_stats_bf16_mode.csv profiles/r3_bf16_mode_kernel_stats.csv
-cp $F/decode_config5.json profiles/r3_decode_config5.json
-cp $F/inference_config3_fp32.json profiles/r3_inference_config3_fp32.json
-cp $F/inference_config3_bf16.json profiles/r3_inference_config3_bf16.json
-cp $F/pmc_shapes_bf16.txt profiles/r3_pmc_shapes_bf16.txt
-cp $F/pmc_shapes_fp32.txt profiles/r3_pmc_shapes_fp32.txt
-cp $F/pytest_gpu.log profiles/r3_pytest_gpu.log
-cp $F/ubench_gemm_issue.txt profiles/r3_ubench_gemm_issue.txt
+for MODE in bf16 bf16x6; do
+  cp $F/kernel_stats_${MODE}_mode.csv ${P}_${MODE}_mode_kernel_stats.csv
+  cp $F/step_timeline_${MODE}_mode.txt ${P}_${MODE}_mode_step_timeline.txt
+done
+cp $F/decode_config5.json ${P}_decode_config5.json
+cp $F/inference_config3_fp32.json ${P}_inference_config3_fp32.json
+cp $F/inference_config3_bf16.json ${P}_inference_config3_bf16.json
+cp $F/pmc_shapes_bf16.txt ${P}_pmc_shapes_bf16.txt
+cp $F/pmc_shapes_fp32.txt ${P}_pmc_shapes_fp32.txt
+cp $F/pytest_gpu.log ${P}_pytest_gpu.log
 python - <<'PY'
 import json
 from speecht_amd import build

@@ -1,23 +1,27 @@
 #!/bin/bash
-# the artefacts profiles/ holds for the round: default bench line, kernel stats + step timeline of the fp32 step, PMC
-# traffic and matrix-pipe utilisation of the gemm kernels, the other configs' benches
+# usage: gpu_round_final.sh <round>: everything profiles/ holds for a round, from one build -- GPU suite, default bench + rocprof
+# stats + PMC passes (scripts/gpu_profile_round.sh), configs[2] / configs[4] benches, bf16- and bf16x6-mode kernel stats and
+# timelines, per-shape PMC.  Outputs under gpurun_out/round<round>/ and gpurun_out/r<round>final/; scripts/copy_round_profiles.sh
+# <round> puts them into profiles/ under their round names.
+R=${1:?round number}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-bash scripts/gpu_prof.sh final_prof python bench.py --no-alt --no-cpu-baseline | head -40 > gpurun_out/final/kernel_top.txt
-python scripts/step_timeline.py $(find gpurun_out/final_prof -name '*kernel_trace.csv' | head -1) > gpurun_out/final/step_timeline.txt
-cp $(find gpurun_out/final_prof -name '*kernel_stats.csv' | head -1) gpurun_out/final/kernel_stats.csv
-grep '^{' gpurun_out/final_prof/stdout.log > gpurun_out/final/bench_under_rocprof.json
-bash scripts/gpu_traffic.sh > gpurun_out/final/traffic.log 2>&1
-bash scripts/gpu_mfma_util.sh > gpurun_out/final/mfma.log 2>&1
-cp gpurun_out/traffic/traffic.json gpurun_out/mfma/mfma_util.json gpurun_out/final/ 2>/dev/null
-python scripts/bench_inference.py > gpurun_out/final/inference_fp32.json 2> gpurun_out/final/inference_fp32.err
-python scripts/bench_inference.py --conv-mode bf16 > gpurun_out/final/inference_bf16.json 2> gpurun_out/final/inference_bf16.err
-python scripts/bench_decode.py > gpurun_out/final/decode_config5.json 2> gpurun_out/final/decode.err
-bash scripts/gpu_prof.sh final_prof_x6 python bench.py --no-alt --no-cpu-baseline --conv-mode bf16x6 | head -30 > gpurun_out/final/kernel_top_bf16x6.txt
-cp $(find gpurun_out/final_prof_x6 -name '*kernel_stats.csv' | head -1) gpurun_out/final/kernel_stats_bf16x6.csv
-rm -rf gpurun_out/final_prof/*kernel_trace.csv gpurun_out/final_prof_x6/*kernel_trace.csv
-python -c "
-import json; d=json.loads([l for l in open('gpurun_out/final/bench.json') if l.startswith('{')][-1])
-print(d['ms_per_step'], d['ms_per_step_median'], d['value'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline'].get('all_matrix_launches'), d['cpu_baseline']['value'], d.get('alt_bf16x6',{}).get('ms_per_step'), d.get('alt_bf16',{}).get('ms_per_step'))"
-tail -2 gpurun_out/final/traffic.log | cut -c1-600; tail -30 gpurun_out/final/mfma.log | head -40
+F=gpurun_out/r${R}final
+mkdir -p $F
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $F/pytest_gpu.log
+cat $F/pytest_gpu.log
+bash scripts/gpu_profile_round.sh $R 2>&1 | tail -6
+timeout 600 python scripts/bench_inference.py > $F/inference_config3_fp32.json 2>/dev/null
+timeout 600 python scripts/bench_inference.py --conv-mode bf16 > $F/inference_config3_bf16.json 2>/dev/null
+timeout 300 python scripts/bench_decode.py > $F/decode_config5.json 2>/dev/null
+cut -c1-300 $F/inference_config3_fp32.json; cut -c1-700 $F/decode_config5.json
+for MODE in bf16 bf16x6; do
+  bash scripts/gpu_prof.sh r${R}_prof_$MODE python bench.py --steps-only --steps 20 --warmup 5 --conv-mode $MODE | head -14 > $F/kernel_top_$MODE.txt
+  cp $(find gpurun_out/r${R}_prof_$MODE -name '*kernel_stats.csv' | head -1) $F/kernel_stats_${MODE}_mode.csv
+  python scripts/step_timeline.py $(find gpurun_out/r${R}_prof_$MODE -name '*kernel_trace.csv' | head -1) > $F/step_timeline_${MODE}_mode.txt 2>/dev/null
+  grep '^{' gpurun_out/r${R}_prof_$MODE/stdout.log > $F/bench_steps_only_${MODE}_under_rocprof.json
+  rm -rf gpurun_out/r${R}_prof_$MODE
+done
+bash scripts/gpu_pmc_shapes.sh r${R}_bf16 --conv-mode bf16 > $F/pmc_shapes_bf16.txt 2>&1
+bash scripts/gpu_pmc_shapes.sh r${R}_fp32 > $F/pmc_shapes_fp32.txt 2>&1
+find gpurun_out -name '*.csv' -size +4M -delete
+du -sh gpurun_out | tail -1

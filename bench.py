@@ -791,15 +791,10 @@ def main():
                              'equivalent rate, not a hardware rate (the hardware rate is roofline.achieved)')
                             if (eng.fft and eng.fft_conv) else None,
     }
-    # (rank 0 alone runs these profiled steps: without the exchange when there are other ranks)
-    step_fn = lambda: train_step(eng, feed, reducer if world == 1 else None, lr, global_batch)
-    out['roofline'], step_hw = measure_dominant_kernel(eng, args.batch, step_fn, ms)
-    if step_hw:
-      out.update(step_hw)
-    if out['roofline'] and eng.conv_mode != 'bf16':
-      attach_pmc_profiles(out['roofline'])
-    if world == 1:
-      out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
+    # The side measurements come BEFORE the roofline passes: those launch through hipExtLaunchKernel with start / stop events,
+    # which switches the process's HSA queues into profiling mode for good -- every later dispatch carries a completion
+    # signal.  The 7 ms fp32 step does not notice; steps of many short launches do (measured round 4, scripts/exp/
+    # alt_timing_probe.py: bf16 2.66 -> 2.86 ms, bf16x6 6.46 -> 7.11 ms when timed after those passes).
     if world == 1 and reducer is None and eng.conv_mode == 'fp32':
       out['comm_probe_world1'] = comm_probe_world1(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
@@ -840,6 +835,15 @@ def main():
                     'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
         del alt
         torch.cuda.empty_cache()
+    # (rank 0 alone runs these profiled steps: without the exchange when there are other ranks)
+    step_fn = lambda: train_step(eng, feed, reducer if world == 1 else None, lr, global_batch)
+    out['roofline'], step_hw = measure_dominant_kernel(eng, args.batch, step_fn, ms)
+    if step_hw:
+      out.update(step_hw)
+    if out['roofline'] and eng.conv_mode != 'bf16':
+      attach_pmc_profiles(out['roofline'])
+    if world == 1:
+      out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
     if world == 1 and not args.no_cpu_baseline:
       # two CPU restatements of the reference path on this box's host cores; the faster one is `cpu_baseline`
       out['cpu_baseline'] = cpu_baseline_torch(args.mels, frames, args.batch)

@@ -76,7 +76,8 @@ class RcclCommunicator:
     handle = ctypes.c_void_p()
     with torch.cuda.device(self.device):        # RCCL binds the communicator to the current device
       _lib.call('st_comm_init', uid, n, self.rank, self.world, ctypes.byref(handle))
-      self.stream = torch.cuda.Stream(self.device)
+      from .engine import role_stream
+      self.stream = role_stream(self.device, 'collective')
     self._handle = handle
     self._joined = None
 

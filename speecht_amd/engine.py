@@ -174,6 +174,44 @@ def decoder_stream_pair(device):
 
 
 _DECODER_STREAMS = {}
+_ROLE_STREAMS = {}
+
+
+def role_stream(device, role):
+  """The process-wide stream of a role ('h2d', 'upload', 'side', 'side2', 'collective') on a device.
+
+  Which HARDWARE queue a HIP stream lands on is decided when it is first used, round-robin over the runtime's four queues,
+  and two streams on one queue do not overlap: the queue serialises them.  With a stream per engine the same engine ran
+  its step at different speeds depending on how many streams the process had used before it was built (measured round 4:
+  the bf16x6 step 6.4 ms in a process of its own, 7.0 ms as the bench's side measurement behind an fp32 engine and a
+  collective stream; the bf16 step 2.66 / 2.86 ms; GPU_MAX_HW_QUEUES=8 instead: fp32 step 7.0 -> 9.2 ms).  So the streams
+  of all roles are created -- and used once, in a fixed order -- when the first of them is asked for, every engine of the
+  process shares them (ordering between engines is by the events each engine records anyway), and the role -> queue map is
+  the same in every process: compute stream q0, h2d q1, side q2, side2 q3, upload q0, collective q1 -- the two side streams
+  on queues of their own (with side2 on the compute stream's queue, as creation order had it before: bf16 step 2.68 instead
+  of 2.57 ms, fp32 and bf16x6 within 0.5 %; ST_STREAM_ORDER lists the roles in another order, '-' skips a queue)."""
+  key = str(device)
+  pool = _ROLE_STREAMS.get(key)
+  if pool is None:
+    pool = {}
+    with torch.cuda.device(device):
+      torch.zeros(1, device=device)                       # the compute (current) stream has its queue first
+      keep = [torch.cuda.Stream(device) for _ in range(int(os.environ.get('ST_STREAM_ROTATE', '0')))]   # (experiments)
+      order = os.environ.get('ST_STREAM_ORDER', 'h2d,side,side2,upload,collective').split(',')
+      for r in keep + order:
+        st = r if not isinstance(r, str) else torch.cuda.Stream(device)
+        with torch.cuda.stream(st):
+          torch.zeros(1, device=device)
+        if isinstance(r, str) and r != '-':                 # ('-': a queue slot left to nobody)
+          pool[r] = st
+        elif isinstance(r, str):
+          keep.append(st)
+      pool['_keep'] = keep
+      torch.cuda.synchronize(device)
+    _ROLE_STREAMS[key] = pool
+  if role not in pool:                                   # (a role the order left out)
+    pool[role] = torch.cuda.Stream(device)
+  return pool[role]
 
 
 class _StagedHostBatch:
@@ -221,6 +259,7 @@ class Wav2LetterEngine:
     self.device = torch.device(device)
     if self.device.type != 'cuda':
       raise _lib.SpeechtHipError('Wav2LetterEngine needs a GPU device (no CPU path exists)')
+    role_stream(self.device, 'side')               # the role -> hardware-queue map is fixed before anything else makes streams
     self.layers = [LayerSpec(*l) for l in layers]
     self.num_classes = self.layers[-1].cout
     self._stream = stream
@@ -828,7 +867,7 @@ class Wav2LetterEngine:
     handle for ``load_batch``; the copy of batch k+1 overlaps the kernels of batch k.  A staging buffer is
     re-used only after the compute stream has consumed it (event recorded by ``load_batch``)."""
     if not hasattr(self, '_h2d'):
-      self._h2d = dict(stream=torch.cuda.Stream(self.device), slots=[None, None], turn=0)
+      self._h2d = dict(stream=role_stream(self.device, 'h2d'), slots=[None, None], turn=0)
     h = self._h2d
     x = torch.as_tensor(x_host)
     if x.dtype != torch.float32:
@@ -883,7 +922,7 @@ class Wav2LetterEngine:
     # there (`_wait_uploads`); on the compute stream three such copies cost the start of every step ~40 us
     main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     if not hasattr(self, '_up_stream'):
-      self._up_stream, self._uploads = torch.cuda.Stream(self.device), []
+      self._up_stream, self._uploads = role_stream(self.device, 'upload'), []
     with torch.cuda.stream(self._up_stream):
       dev = torch.empty(n, dtype=torch.int32, device=self.device)
       dev.copy_(slot[0][:n], non_blocking=True)
@@ -1012,9 +1051,9 @@ class Wav2LetterEngine:
     chains of the backward pass next to each other."""
     main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     if getattr(self, '_side', None) is None:
-      self._side = torch.cuda.Stream(self.device)
+      self._side = role_stream(self.device, 'side')
     if second and getattr(self, '_side2', None) is None:
-      self._side2 = torch.cuda.Stream(self.device)
+      self._side2 = role_stream(self.device, 'side2')
     stream = self._side2 if second else self._side
     fork = torch.cuda.Event()
     fork.record(main)

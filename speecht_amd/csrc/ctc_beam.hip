@@ -270,23 +270,22 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     // Fast path (threshold + rank): a cheap lower bound of the W-th largest candidate; only candidates at or above it
     // ("survivors", a few dozen) can be selected; they are compacted into LDS and every survivor finds its rank by counting
     // the survivors ahead of it (keys are unique: score, then smaller candidate index).  All of it is wave-parallel; the
-    // sequential rounds below remain as the fallback for more than 128 survivors and for beams wider than 16.
+    // sequential rounds below remain as the fallback for more than 128 survivors.
     int n_new = 0;
     bool selected = false;
-    if (CPL <= 16 && W <= 16) {
+    {
       // A lower bound of the W-th largest candidate that costs ten instructions: the lanes form 64 / 4 = 16 quads, every quad
-      // maximum is a candidate, so at least 16 candidates are >= the SMALLEST quad maximum (wider beams than 16 take the
-      // sequential path below).  It is looser than the W-th largest lane maximum of round 2 (flat posteriors: ~48 survivors
-      // instead of ~20) but that bound cost a ranking of the 64 lanes -- 3 800 of the frame's 13 300 cycles as 64 v_readlane
-      // steps, 1 700 as a 32-step radix select on ballots, more again as 16 four-key LDS reads -- and the survivors are
-      // ranked by counting anyway.
-      unsigned thr = kOrdNegInf + 1u;                     // a quad without a live candidate: every live candidate survives
-      if (W <= 16) {
-        unsigned g = best_ord;
-        g = max(g, (unsigned)dpp_i32<0xB1, 0xf, false>((int)g, (int)g));      // quad_perm [1, 0, 3, 2]
-        g = max(g, (unsigned)dpp_i32<0x4E, 0xf, false>((int)g, (int)g));      // quad_perm [2, 3, 0, 1]
-        thr = max(wave_min_u32(g), kOrdNegInf + 1u);
-      }
+      // maximum is a candidate, so at least 16 candidates are >= the SMALLEST quad maximum; for beams of 17 - 32 the 32 lane
+      // pairs take the quads' place, for 33 - 64 the lanes themselves (round 4: those widths took the sequential path).  It
+      // is looser than the W-th largest lane maximum of round 2 (flat posteriors: ~48 survivors instead of ~20 at beam 16)
+      // but that bound cost a ranking of the 64 lanes -- 3 800 of the frame's 13 300 cycles as 64 v_readlane steps, 1 700 as
+      // a 32-step radix select on ballots, more again as 16 four-key LDS reads -- and the survivors are ranked by counting
+      // anyway; more than 128 survivors fall through to the sequential rounds.
+      unsigned g = best_ord;
+      if (W <= 32) g = max(g, (unsigned)dpp_i32<0xB1, 0xf, false>((int)g, (int)g));        // quad_perm [1, 0, 3, 2]: pairs
+      if (W <= 16) g = max(g, (unsigned)dpp_i32<0x4E, 0xf, false>((int)g, (int)g));        // quad_perm [2, 3, 0, 1]: quads
+      // (a group without a live candidate: every live candidate survives)
+      const unsigned thr = max(wave_min_u32(g), kOrdNegInf + 1u);
       // compaction of the survivors into LDS: a lane's survivors sit behind those of the lanes below it (one wave prefix
       // sum instead of a ballot per candidate row; the keys carry the candidate index, so the order does not matter)
       int mine_n = 0;

@@ -239,7 +239,7 @@ def test_greedy_decode_bit_identical(dev):
     np.testing.assert_allclose(score, ref_score, rtol=1e-5)
 
 
-@pytest.mark.parametrize('beam', [1, 4, 16, 64])
+@pytest.mark.parametrize('beam', [1, 4, 16, 24, 40, 64])
 def test_beam_search_matches_oracle(dev, beam):
   """st_ctc_beam_search_decode vs the float64 prefix beam search of the oracle: identical label
   sequences, log-probabilities within 1e-4 relative (fp32 log-sum-exp over up to 401 frames)."""

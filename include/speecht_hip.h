@@ -162,6 +162,15 @@ size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width);
 int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
                               const st_tensor3* y, const float* tables, float* sf, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The same for a CHAIN of frequency-domain layers (round 4): sf_ready != 0 -- `sf` already holds this layer's input spectra (the
+ * previous layer's call wrote them); next_tables / next_sf / next_width / next_pad_left -- the next layer of the chain: when the
+ * shapes allow (at most 8 blocks of 64 frames per utterance, batch x blocks a multiple of 128, the next layer's window reaching at
+ * most 4 frames into either neighbour block: the model's 7-tap layers at utterances of up to 10.2 s) the inverse transform hands its
+ * frames to the next layer's forward transform in registers and writes next_sf; *next_sf_written says whether it did. */
+int st_conv1d_nwc_fwd_fft_chain_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
+                                    const st_tensor3* y, const float* tables, float* sf, int sf_ready, const float* next_tables,
+                                    float* next_sf, int next_width, int next_pad_left, int* next_sf_written, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream);
 /* dbias[o] = sum_{b,t} dz[b,t,o] read off bin 0 of the spectra zf (npad floats written, pads zero): the bias gradient of a
  * frequency-domain layer without another pass over dz */

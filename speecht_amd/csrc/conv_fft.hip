@@ -40,7 +40,19 @@ constexpr int T_IY = T_FZ + KP * KP;         // inverse at m = t'               
 constexpr int T_IX = T_IY + V * KP;          // inverse at m = t' + pl, t' + V + pl, t' - V + pl   [3][V][KP]
 constexpr int T_TW = T_IX + 3 * V * KP;      // (cos, sin)(2 pi j / N), j < N            [128][2]
 constexpr int T_FW = T_TW + 256;             // (cos, sin)(2 pi k w / N), k < bins, w < W: [HB][W][2] (filter kernels: one
-constexpr int T_END = T_FW + HB * 34 * 2;    // contiguous row per bin, read with wide scalar loads)
+constexpr int T_FP = T_FW + HB * 34 * 2;     // contiguous row per bin, read with wide scalar loads)
+// T_FP: the forward matrix T_FS with its columns in the order the inverse transform's accumulators hold frames, k-step
+// interleaved [FUSE_Q][KP][2] (idft_dft_rows_kernel): what the LAYER BELOW stages when it hands its frames over in registers
+constexpr int FUSE_BLOCKS = 8, FUSE_HALO = 4, FUSE_Q = 32 + FUSE_HALO;
+constexpr int T_END = T_FP + FUSE_Q * KP * 2;
+// window index of the frame lanes h supply in k-step q of the fused transform (-1: none): q < 32 pairs the frames of accumulator
+// register q & 15 of the 32-frame half q >> 4; k-step 32 + e pairs frame e of the left halo (h = 0) with frame e of the right one
+__host__ __device__ inline int fused_column(int q, int hh, int n, int pad_left) {
+  const int right = n - V - pad_left;
+  if (q < 32) return pad_left + 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh;
+  if (hh == 0) return (q - 32) < pad_left ? (q - 32) : -1;
+  return (q - 32) < right ? V + pad_left + (q - 32) : -1;
+}
 
 int npad_of(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)st::round_up(c, 128)); }
 // spectra of a tensor with channel pitch cp keep `half_of(cp)` columns for the real and for the imaginary parts: a
@@ -95,12 +107,20 @@ __global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
         sincospif(2.0f * (float)j * inv_n, &sn, &cs);
         val = (i - T_TW) % 2 ? sn : cs;
       }
-    } else {
+    } else if (i < T_FP) {
       const int e = (i - T_FW) / 2, k = e / width, w = e % width;
       if (k < bins) {
         float sn, cs;
         sincospif(2.0f * (float)((k * w) % n) * inv_n, &sn, &cs);
         val = (i - T_FW) % 2 ? sn : cs;
+      }
+    } else {
+      const int e = i - T_FP, q = e / (KP * 2), r = (e - q * (KP * 2)) >> 1, hh = e & 1;
+      const int k = r < HB ? r : r - HB, col = fused_column(q, hh, n, pad_left);
+      if (k < bins && col >= 0 && col < n) {
+        float sn, cs;
+        sincospif(2.0f * (float)((k * col) % n) * inv_n, &sn, &cs);
+        val = r < HB ? cs : -sn;
       }
     }
     t[i] = val;
@@ -373,6 +393,148 @@ __global__ __launch_bounds__(256, 2) void idft_rows_kernel(const float* __restri
   }
 }
 
+// ---- inverse DFT of layer i fused with the forward DFT of layer i + 1 (round 4) ---------------------------------------
+// The narrow layers' transforms are latency chains (one (block, 32 channels) item per wavefront, 14 + 19 us per layer
+// boundary with the chip mostly idle): here the frames an inverse transform has just produced -- bias and ReLU applied --
+// go into the NEXT layer's forward transform without leaving the registers.  A workgroup is one (utterance, 32 channels)
+// column of up to FUSE_BLOCKS blocks, a wavefront per block.  The inverse transform leaves lane (channel, h) with frames
+// {32 i + (r & 3) + 8 (r >> 2) + 4 h}: for every accumulator register r the pair (lanes h = 0, lanes h = 1) IS a valid
+// k-step of `v_mfma_f32_32x32x2_f32` for the next DFT once that DFT's matrix has its columns in the same order -- the
+// workgroup builds that column-permuted copy of the next layer's T_FS table in LDS.  The next block window also covers
+// pad_left frames of the block before and W - 1 - pad_left of the block after: those few frames go through LDS (one
+// barrier), as up to FUSE_HALO extra k-steps (left-neighbour frame on the h = 0 lanes, right-neighbour frame on h = 1).
+// Writes y (the backward pass needs it for the ReLU mask) and the next layer's input spectra (+ rotated copy) exactly as
+// idft_rows_kernel and dft_rows_kernel would; frames past y.frames and pad channels enter the transform as zeros.
+template <int HP>
+__global__ __launch_bounds__(64 * FUSE_BLOCKS, 1) void idft_dft_rows_kernel(
+    const float* __restrict__ in, const float* __restrict__ winv, int blocks, int rows_pad, int bins, int half_in, int nchunks, RowsOut y,
+    const float* __restrict__ bias, int relu, const float* __restrict__ wm_next, int n_next, int pl_next, int bins_next, int half_next,
+    float* __restrict__ out, long bin_stride, float* __restrict__ out2) {
+  constexpr int NST = 2 * HP / CH;
+  static_assert(2 * HP % CH == 0 && HP <= HB / 2, "pairs per term must fill whole stages");
+  __shared__ __attribute__((aligned(16))) float wl[V * KP];
+  __shared__ __attribute__((aligned(16))) float wf[FUSE_Q * KP * 2];          // [k-step][matrix row][h]
+  __shared__ float halo[FUSE_BLOCKS][2][FUSE_HALO][32];                       // [block][head | tail][frame][channel]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / nchunks, chunk = blockIdx.x - b * nchunks;
+  const int j = wave, row = b * blocks + j, c = chunk * 32 + l31;
+  const bool active = j < blocks;
+  const int right_next = n_next - V - pl_next;                               // frames of the next block inside the window
+  if (tid < 256) stage_matrix<V, 1>(wl, winv);
+  // the next layer's forward matrix with its columns in accumulator order (its table T_FP): a straight copy
+  {
+    constexpr int N4 = FUSE_Q * KP * 2 / 4;
+    for (int idx = tid; idx < N4; idx += 64 * FUSE_BLOCKS) reinterpret_cast<f32x4*>(wf)[idx] = reinterpret_cast<const f32x4*>(wm_next)[idx];
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const long plane = (long)rows_pad * 2 * half_in;
+  const bool cok = c < half_in;
+  const float* src = in + (long)(active ? row : 0) * 2 * half_in + min(c, half_in - 1);
+  auto load = [&](float (&bf)[CH], int st) {
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const int p = st * CH + s;
+      const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+      bf[s] = src[(long)min(bin, bins - 1) * plane + (p < HP ? 0 : half_in)];
+    }
+  };
+  float bfr[NST][CH];
+  if (active) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) load(bfr[st], st);                      // (in flight while the matrices are staged)
+  }
+  __syncthreads();
+  if (active) {
+    const float* afrag = wl + 2 * l31 + h;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int p = st * CH + s;
+        const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+        const unsigned keep = (cok && bin < bins) ? 0xffffffffu : 0u;
+        const float v = __uint_as_float(__float_as_uint(bfr[st][s]) & keep);
+        const int sidx = p < HP ? p : HB / 2 + (p - HP);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[(sidx * V) * 2], v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[(sidx * V + 32) * 2], v, acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // layer epilogue; what the next transform must see as zero (pad channels, frames past the end) becomes zero here
+    const float bv = (bias && c < y.channels) ? bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float val = c < y.channels ? acc[i][r] + bv : 0.f;
+        if (relu) val = fmaxf(val, 0.f);
+        val = t < y.frames ? val : 0.f;
+        asm volatile("" : "+v"(val));
+        acc[i][r] = val;
+      }
+    if (c < y.c_pitch) {
+      float* yp = y.base + (long)b * y.batch_stride + c;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (t < y.frames) yp[(long)t * y.c_pitch] = acc[i][r];
+        }
+    }
+    // frames 0 .. 3 of this block (registers 0 .. 3 of the h = 0 lanes) and 60 .. 63 (registers 12 .. 15 of half 1, h = 1 lanes)
+#pragma unroll
+    for (int e = 0; e < FUSE_HALO; ++e) {
+      if (h == 0) halo[j][0][e][l31] = acc[0][e];
+      else halo[j][1][e][l31] = acc[1][12 + e];
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  f32x16 sacc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+  const float* af2 = wf + 2 * l31 + h;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const float v = acc[q >> 4][q & 15];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[(q * KP + i * 32) * 2], v, sacc[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < FUSE_HALO; ++e) {
+    // left: frame 64 - pl + e of block j - 1 (tail slot 4 - pl + e); right: frame e of block j + 1
+    float v = 0.f;
+    if (h == 0) { if (j > 0 && e < pl_next) v = halo[j - 1][1][FUSE_HALO - pl_next + e][l31]; }
+    else { if (j + 1 < blocks && e < right_next) v = halo[j + 1][0][e][l31]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[((32 + e) * KP + i * 32) * 2], v, sacc[i], 0, 0, 0);
+  }
+  if (c < half_next) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half_next) + c;
+        if (bin < bins_next) {
+          const long o = (long)bin * bin_stride + (long)row * 2 * half_next;
+          out[o + col] = sacc[i][r];
+          if (out2) out2[o + (m < HB ? half_next : 0) + c] = m < HB ? -sacc[i][r] : sacc[i][r];
+        }
+      }
+  }
+}
+
 // ---- filters -> their spectra as a GEMM operand -------------------------------------------------------------
 // G[k][c][o] = sum_w F[w][c][o] e^{-2 pi i k w / N}.
 //  gfwd [bins][2 cph][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G); cph = spectra half width).  Back-prop to the input
@@ -577,6 +739,15 @@ void launch_filters_planes(int width, const dim3& grid, hipStream_t s, const flo
 
 bool planes_ok(int planes) { return planes == 1 || planes == 3; }
 
+// can layer i's inverse transform carry the next layer's forward transform (idft_dft_rows_kernel)?
+bool can_fuse_next(const Plan& p, const st_tensor3& y, int next_width, int next_pad_left) {
+  if (next_width < 2 || !width_ok(next_width) || next_pad_left < 0 || next_pad_left >= next_width) return false;
+  const int right = next_width - 1 - next_pad_left;
+  return p.blocks <= FUSE_BLOCKS && p.rows == p.rows_pad && next_pad_left <= FUSE_HALO && right <= FUSE_HALO &&
+         half_of(y.c_pitch) == y.c_pitch && y.c_pitch % 32 == 0 && st::tuning(st::TUNE_NO_FUSED_TRANSFORMS) == 0;
+}
+
+
 
 }  // namespace
 
@@ -689,12 +860,18 @@ size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
   return (st::SK_WS_FLOATS + std::max(yf, std::max(xf, qf)) + 64) * sizeof(float);
 }
 
-int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
-                              const st_tensor3* y, const float* tables, float* sf, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+// The forward call of a CHAIN of frequency-domain layers: `sf_ready` != 0 -- this layer's input spectra are in `sf` already (the
+// previous layer's call wrote them); next_* given -- when the shapes allow (can_fuse_next: at most 8 blocks per utterance, no pad
+// rows, a next window reaching at most 4 frames into either neighbour block) the inverse transform also produces the NEXT layer's
+// input spectra into `next_sf` and *next_sf_written becomes 1 (else 0: the next call transforms y itself).
+int st_conv1d_nwc_fwd_fft_chain_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
+                                    const st_tensor3* y, const float* tables, float* sf, int sf_ready, const float* next_tables,
+                                    float* next_sf, int next_width, int next_pad_left, int* next_sf_written, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(x) && tensor_ok(y) && gfwd && sf && workspace && tables && width_ok(width), "conv fft fwd: bad argument");
   ST_REQUIRE(x->batch == y->batch && x->frames == y->frames && pad_left >= 0 && pad_left < width, "conv fft fwd: stride-1 SAME layers only");
   ST_REQUIRE(npad_of(y->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, y, width), "conv fft fwd: workspace / shape");
+  if (next_sf_written) *next_sf_written = 0;
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, y->frames, y->batch);
   const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
@@ -702,14 +879,39 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
   float* yf = sk + st::SK_WS_FLOATS;
   const int half = half_of(x->c_pitch);
   const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin
-  launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half, sf, nullptr, 0, 0, nullptr, s, s_bin,
-             split_lag_products(half) ? sf + (long)p.rows_pad * ka : nullptr);
+  if (!sf_ready)
+    launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half, sf, nullptr, 0, 0, nullptr, s, s_bin,
+               split_lag_products(half) ? sf + (long)p.rows_pad * ka : nullptr);
   if (int e = st::gemm_nn_batched(sf, ka, s_bin, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka, nf, p.bins, s, sk))
     return e;
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames, nullptr};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
+  if (next_tables && next_sf && can_fuse_next(p, *y, next_width, next_pad_left)) {
+    const Plan pn = make_plan(next_width, y->frames, y->batch);
+    const int half_n = half_of(y->c_pitch), ka_n = 2 * half_n;
+    const long sn_bin = 2L * pn.rows_pad * ka_n;
+    float* rot = split_lag_products(half_n) ? next_sf + (long)pn.rows_pad * ka_n : nullptr;
+    st::trace("idft_dft_rows<%d> rows=%d chunks=%d bins=%d next_bins=%d", p.bins <= 36 ? 18 : 24, p.rows, nchunks, p.bins, pn.bins);
+    const dim3 grid(y->batch * nchunks), block(64 * FUSE_BLOCKS);
+    st::LaunchTimer timer(s);
+    if (p.bins <= 36)
+      st::launch_timed(timer, idft_dft_rows_kernel<18>, grid, block, s, yf, tables + T_IY, p.blocks, p.rows_pad, p.bins, npo, nchunks, out, bias, relu,
+                       next_tables + T_FP, pn.n, next_pad_left, pn.bins, half_n, next_sf, sn_bin, rot);
+    else
+      st::launch_timed(timer, idft_dft_rows_kernel<24>, grid, block, s, yf, tables + T_IY, p.blocks, p.rows_pad, p.bins, npo, nchunks, out, bias, relu,
+                       next_tables + T_FP, pn.n, next_pad_left, pn.bins, half_n, next_sf, sn_bin, rot);
+    if (next_sf_written) *next_sf_written = 1;
+    return st::check_launch("conv fft fwd (fused transforms)");
+  }
   launch_idft<1>(yf, tables + T_IY, p, npo, nchunks, out, bias, relu, nullptr, 0L, 0, s);
   return st::check_launch("conv fft fwd");
+}
+
+int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const float* bias, int width, int pad_left, int relu,
+                              const st_tensor3* y, const float* tables, float* sf, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return st_conv1d_nwc_fwd_fft_chain_f32(x, gfwd, bias, width, pad_left, relu, y, tables, sf, 0, nullptr, nullptr, 0, 0, nullptr, workspace,
+                                         workspace_bytes, stream);
 }
 
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {

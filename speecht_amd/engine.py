@@ -951,8 +951,11 @@ class Wav2LetterEngine:
       self._refresh_wplanes()
     if x6 and self._x6_fwd(0):
       call('st_exp_split3_bf16', self._ptr(self.X[0].buf), self.X[0].buf.numel(), self._ptr(self.Xp[0]), s)
+    sf_ready = False                 # the previous layer's call left this layer's input spectra behind
     for i, l in enumerate(self.layers):
       pf, pb = self._slice(self.params, i)
+      if not (i in self.fft and self.fft_conv):
+        sf_ready = False
       if x6 and self._x6_fwd(i):
         if i > 0 and not self._x6_fwd(i - 1):
           call('st_exp_split3_bf16', self._ptr(self.X[i].buf), self.X[i].buf.numel(), self._ptr(self.Xp[i]), s)
@@ -965,9 +968,18 @@ class Wav2LetterEngine:
           self._join_side_stream()
           self._refresh_fft_filters()
         self._wait_gfwd(i)                               # the filter spectra may still be on their way (side stream)
-        call('st_conv1d_nwc_fwd_fft_f32', f['xref'], self._ptr(f['gfwd']), self._ptr(pb), f['width'], f['pl'],
-             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), self._ptr(f['ws']),
-             f['ws'].numel() * 4, s)
+        # a chain of frequency-domain layers: where the shapes allow, this layer's inverse transform hands its frames to the
+        # next layer's forward transform in registers and leaves that layer's input spectra behind (`sf_ready` for its call)
+        nxt = self.fft.get(i + 1) if self.fft_conv else None
+        if nxt is not None and nxt['shift'] is not None:
+          nxt = None
+        written = ctypes.c_int(0)
+        call('st_conv1d_nwc_fwd_fft_chain_f32', f['xref'], self._ptr(f['gfwd']), self._ptr(pb), f['width'], f['pl'],
+             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), int(sf_ready),
+             self._ptr(nxt['tables']) if nxt else None, self._ptr(nxt['sf']) if nxt else None, nxt['width'] if nxt else 0,
+             nxt['pl'] if nxt else 0, ctypes.byref(written), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        sf_ready = written.value == 1
+        continue
       else:
         call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
              self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),

@@ -479,3 +479,55 @@ def test_one_tap_back_prop_reads_the_forward_filters_transposed(dev, B, T, cin, 
     assert float(whole[:, :, cin:].nan_to_num(nan=0.0).abs().max()) == 0.0 if dxt.c_pitch > cin else True
     outs.append(dxt.interior().clone())
   assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('B,T,taps', [(16, 500, (7, 7, 5)), (32, 250, (7, 3, 7)), (2, 4096 // 8, (7, 7, 7))])
+def test_inverse_transform_hands_its_frames_to_the_next_layers_forward_transform(dev, B, T, taps):
+  """st_conv1d_nwc_fwd_fft_chain_f32: in a chain of frequency-domain layers the inverse transform of layer i (bias, ReLU) feeds the
+  forward transform of layer i + 1 in registers (idft_dft_rows_kernel: the accumulator layout is a k-step order of the next DFT
+  once its matrix has the columns permuted; halo frames of the neighbour blocks through LDS) when the shapes allow -- at most 8
+  blocks per utterance, batch x blocks a multiple of 128, a next window reaching <= 4 frames into a neighbour.  Against the
+  separate kernels (st_set_tuning("no_fused_transforms", 1)): logits, every stored activation and every gradient (the filter
+  gradients read the handed-over spectra) to fp32 rounding; against the float64 oracle at the usual bound; ragged last blocks
+  (T not a multiple of 64), different taps per layer (other halos), pad channels."""
+  from speecht_amd.engine import Wav2LetterEngine
+  from speecht_amd._lib import launch_trace, set_tuning
+  from tests import workloads as WL
+  layers = [(5, 1, 40, 120, True), (taps[0], 1, 120, 128, True), (taps[1], 1, 128, 250, True), (taps[2], 1, 250, 128, True),
+            (1, 1, 128, 29, False)]                          # W-tap bottom layer, three frequency-domain layers, the 1-tap classifier
+  params = WL.xavier_params(layers, seed=9, bias_range=0.05, dtype=np.float32)
+  x, seq, labels = WL.make_batch([T] * (B - 1) + [T - 37], 40, seed=77)
+  runs = []
+  for off in (0, 1):
+    set_tuning('no_fused_transforms', off)
+    try:
+      eng = Wav2LetterEngine(layers, device=dev)
+      eng.fft_min_rows_narrow, eng.fft_min_width = 0, 2
+      eng.set_weights(params)
+      eng.load_batch(x.astype(np.float32), seq)
+      eng.set_labels(labels)
+      with launch_trace() as tr:
+        eng.forward()
+      eng.ctc_loss_grad(1.0 / B)
+      eng.backward()
+      torch.cuda.synchronize()
+      runs.append(([t.buf.clone() for t in eng.X], eng.grads.clone(), tr.lines, eng.get_grads(), eng.logits_time_major().cpu().numpy()))
+    finally:
+      set_tuning('no_fused_transforms', 0)
+  fused = [l for l in runs[0][2] if l.startswith('idft_dft_rows<')]
+  fits = (-(-T // 64)) <= 8 and (B * (-(-T // 64))) % 128 == 0
+  assert set(eng.fft) == {1, 2, 3}
+  assert len(fused) == (2 if fits else 0), '\n'.join(runs[0][2])             # layers 1 -> 2 and 2 -> 3
+  assert not any(l.startswith('idft_dft_rows<') for l in runs[1][2])
+  if fits:
+    assert sum(1 for l in runs[0][2] if l.startswith('dft_rows<')) == 1     # only the first layer transforms its input itself
+  for a, b in zip(runs[0][0], runs[1][0]):
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+  assert float((runs[0][1] - runs[1][1]).abs().max()) <= 5e-6 * float(runs[1][1].abs().max())
+  p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True)
+  assert np.max(np.abs(runs[0][4] - logits)) < 1e-4
+  loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)         # (the engine hands CTC sequence_lengths // 2, like the reference)
+  ref = O.wav2letter_backward(acts, p64, layers, g_logits / B)
+  for (gF, gb), (rF, rb) in zip(runs[0][3], ref):
+    assert np.max(np.abs(gF - rF)) <= 2e-4 * np.max(np.abs(rF)) and np.max(np.abs(gb - rb)) <= 2e-4 * max(np.max(np.abs(rb)), 1e-30)

@@ -178,6 +178,15 @@ int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf
 int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
                                    const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* The same for a CHAIN (round 4): below_tables / below_zf / below_width -- the frequency-domain layer below, whose output gradient
+ * dx is.  When the shapes allow (at most 8 blocks of 64 frames per utterance, batch x blocks a multiple of 128, at most 4 frames
+ * of a block's window in either neighbour block) ONE launch inverts every block at its whole window, overlap-adds through LDS,
+ * masks, stores dx and -- the frames still in registers -- writes the layer below's dz spectra to below_zf (*below_zf_written = 1:
+ * skip st_conv1d_fft_dz_spectra_f32 for that layer).  below_* may be NULL / 0: the window-form inverse alone. */
+int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
+                                         const st_tensor3* act, const st_tensor3* dx, const float* tables, const float* below_tables,
+                                         float* below_zf, int below_width, int* below_zf_written, void* workspace,
+                                         size_t workspace_bytes, void* stream);
 int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, const float* sf, const float* zf, int width,
                                      const float* tables, float* dpacked, void* workspace, size_t workspace_bytes,
                                      void* stream);

@@ -62,6 +62,8 @@ _SIGNATURES = {
                                           c_size_t, c_void_p]),
     'st_conv1d_nwc_fwd_fft_chain_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, c_int, _T3P, c_void_p, c_void_p, c_int, c_void_p,
                                                 c_void_p, c_int, c_int, POINTER(c_int), c_void_p, c_size_t, c_void_p]),
+    'st_conv1d_nwc_bwd_data_fft_chain_f32': (c_int, [_T3P, c_void_p, c_void_p, c_int, c_int, _T3P, _T3P, c_void_p, c_void_p, c_void_p, c_int,
+                                                     POINTER(c_int), c_void_p, c_size_t, c_void_p]),
     'st_conv1d_fft_filter_plane_elems': (c_size_t, [c_int, c_int, c_int]),
     'st_conv1d_fft_filters_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'st_conv1d_fft_planes_ws': (c_size_t, [_T3P, _T3P, c_int, c_int]),

@@ -44,7 +44,10 @@ constexpr int T_FP = T_FW + HB * 34 * 2;     // contiguous row per bin, read wit
 // T_FP: the forward matrix T_FS with its columns in the order the inverse transform's accumulators hold frames, k-step
 // interleaved [FUSE_Q][KP][2] (idft_dft_rows_kernel): what the LAYER BELOW stages when it hands its frames over in registers
 constexpr int FUSE_BLOCKS = 8, FUSE_HALO = 4, FUSE_Q = 32 + FUSE_HALO;
-constexpr int T_END = T_FP + FUSE_Q * KP * 2;
+constexpr int T_IW = T_FP + FUSE_Q * KP * 2; // inverse at the WHOLE window of a block [KP][KP]: rows 0..63 m = t' + pl (the block's own
+                                             // frames), 64 + e m = e (e < pl: lands in the block before), 68 + e m = V + pl + e (the block after)
+constexpr int T_ZP = T_IW + KP * KP;         // T_FZ with its columns in accumulator order, k-step interleaved [32][KP][2]
+constexpr int T_END = T_ZP + 32 * KP * 2;
 // window index of the frame lanes h supply in k-step q of the fused transform (-1: none): q < 32 pairs the frames of accumulator
 // register q & 15 of the 32-frame half q >> 4; k-step 32 + e pairs frame e of the left halo (h = 0) with frame e of the right one
 __host__ __device__ inline int fused_column(int q, int hh, int n, int pad_left) {
@@ -114,10 +117,31 @@ __global__ void tables_kernel(int n, int pad_left, float* __restrict__ t) {
         sincospif(2.0f * (float)((k * w) % n) * inv_n, &sn, &cs);
         val = (i - T_FW) % 2 ? sn : cs;
       }
-    } else {
+    } else if (i < T_IW) {
       const int e = i - T_FP, q = e / (KP * 2), r = (e - q * (KP * 2)) >> 1, hh = e & 1;
       const int k = r < HB ? r : r - HB, col = fused_column(q, hh, n, pad_left);
       if (k < bins && col >= 0 && col < n) {
+        float sn, cs;
+        sincospif(2.0f * (float)((k * col) % n) * inv_n, &sn, &cs);
+        val = r < HB ? cs : -sn;
+      }
+    } else if (i < T_ZP) {
+      const int e = i - T_IW, r = e / KP, col = e % KP;
+      const int k = col < HB ? col : col - HB;
+      int m = -1;
+      if (r < V) m = r + pad_left;
+      else if (r < V + 4) m = (r - V) < pad_left ? r - V : -1;
+      else if (r < V + 8) m = (r - V - 4) < width - 1 - pad_left ? V + pad_left + (r - V - 4) : -1;
+      if (k < bins && m >= 0 && m < n) {
+        const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;
+        float sn, cs;
+        sincospif(2.0f * (float)((k * m) % n) * inv_n, &sn, &cs);
+        val = col < HB ? wk * cs : -wk * sn;
+      }
+    } else {
+      const int e = i - T_ZP, q = e / (KP * 2), r = (e - q * (KP * 2)) >> 1, hh = e & 1;
+      const int k = r < HB ? r : r - HB, col = fused_column(q, hh, V, 0);      // frame t' of the zero-padded block
+      if (k < bins && col < V) {
         float sn, cs;
         sincospif(2.0f * (float)((k * col) % n) * inv_n, &sn, &cs);
         val = r < HB ? cs : -sn;
@@ -535,6 +559,142 @@ __global__ __launch_bounds__(64 * FUSE_BLOCKS, 1) void idft_dft_rows_kernel(
   }
 }
 
+// ---- back-prop: inverse DFT over the whole window + overlap-add through LDS + mask + the forward DFT of the layer below ---
+// idft_rows_kernel<3> gives every block three inverse terms: its own spectra and both neighbours', each neighbour for the
+// W - 1 frames it reaches into the block -- twice the matrix instructions and three times the loads of the forward inverse.
+// Here a workgroup is one (utterance, 32 channels) column of up to FUSE_BLOCKS blocks, a wavefront per block: the block's
+// spectra are inverted ONCE at all N points of its window (table T_IW: the 64 own frames and, in a third 32-row tile,
+// the few frames that spill into either neighbour), the spills change hands through LDS (one barrier; sum own + the block
+// before's + the block after's, a fixed order), the ReLU mask is applied, dx is stored, and the frames -- still in registers,
+// in accumulator order -- go straight into the zero-padded forward DFT that the layer below needs of its dz (table T_ZP of
+// THAT layer): its st_conv1d_fft_dz_spectra_f32 launch and the re-read of dx fall away.
+template <int HP>
+__global__ __launch_bounds__(64 * FUSE_BLOCKS, 1) void idft_ola_dft_rows_kernel(
+    const float* __restrict__ in, const float* __restrict__ winv, int blocks, int rows_pad, int bins, int half_in, int nchunks, RowsOut y,
+    int pad_left, int right, const float* __restrict__ mask, long mask_batch_stride, int mask_c_pitch,
+    const float* __restrict__ wz_below, int bins_below, int half_below, float* __restrict__ zf_below) {
+  constexpr int NST = 2 * HP / CH;
+  static_assert(2 * HP % CH == 0 && HP <= HB / 2, "pairs per term must fill whole stages");
+  __shared__ __attribute__((aligned(16))) float wl[KP * KP];
+  __shared__ __attribute__((aligned(16))) float wf[32 * KP * 2];
+  __shared__ float spill[FUSE_BLOCKS][2][FUSE_HALO][32];                      // [block][into the block before | after][frame][channel]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / nchunks, chunk = blockIdx.x - b * nchunks;
+  const int j = wave, row = b * blocks + j, c = chunk * 32 + l31;
+  const bool active = j < blocks;
+  const long plane = (long)rows_pad * 2 * half_in;
+  const bool cok = c < half_in;
+  const float* src = in + (long)(active ? row : 0) * 2 * half_in + min(c, half_in - 1);
+  auto load = [&](float (&bf)[CH], int st) {
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const int p = st * CH + s;
+      const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+      bf[s] = src[(long)min(bin, bins - 1) * plane + (p < HP ? 0 : half_in)];
+    }
+  };
+  float bfr[NST][CH];
+  float mk[2][16];
+  if (active) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) load(bfr[st], st);
+    if (mask) {
+      const float* mp = mask + (long)b * mask_batch_stride + min(c, mask_c_pitch - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          mk[i][r] = mp[(long)min(j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, y.frames - 1) * mask_c_pitch];
+    }
+  }
+  if (tid < 256) stage_matrix<KP, 1>(wl, winv);
+  if (wz_below) {
+    constexpr int N4 = 32 * KP * 2 / 4;
+    for (int idx = tid; idx < N4; idx += 64 * FUSE_BLOCKS) reinterpret_cast<f32x4*>(wf)[idx] = reinterpret_cast<const f32x4*>(wz_below)[idx];
+  }
+  __syncthreads();
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  if (active) {
+    const float* afrag = wl + 2 * l31 + h;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int p = st * CH + s;
+        const int bin = (p < HP ? 2 * p : 2 * (p - HP)) + h;
+        const unsigned keep = (cok && bin < bins) ? 0xffffffffu : 0u;
+        const float v = __uint_as_float(__float_as_uint(bfr[st][s]) & keep);
+        const int sidx = p < HP ? p : HB / 2 + (p - HP);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[(sidx * KP + i * 32) * 2], v, acc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // rows 64 .. 67 of the window (h = 0 lanes, registers 0 .. 3 of the third tile) belong to the block before, 68 .. 71 (h = 1) to the one after
+#pragma unroll
+    for (int e = 0; e < FUSE_HALO; ++e) spill[j][h][e][l31] = acc[2][e];
+  }
+  __syncthreads();
+  if (!active) return;
+  // overlap-add: frames 0 .. right - 1 get what the block before spilled forward, frames V - pl .. V - 1 what the block after spilled back
+#pragma unroll
+  for (int e = 0; e < FUSE_HALO; ++e) {
+    if (h == 0) { if (j > 0 && e < right) acc[0][e] += spill[j - 1][1][e][l31]; }
+    else { if (j + 1 < blocks && e >= FUSE_HALO - pad_left) acc[1][12 + e] += spill[j + 1][0][e - (FUSE_HALO - pad_left)][l31]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float val = c < y.channels ? acc[i][r] : 0.f;
+      if (mask) val = mk[i][r] > 0.f ? val : 0.f;
+      val = t < y.frames ? val : 0.f;
+      asm volatile("" : "+v"(val));
+      acc[i][r] = val;
+    }
+  if (c < y.c_pitch) {
+    float* yp = y.base + (long)b * y.batch_stride + c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = j * V + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (t < y.frames) yp[(long)t * y.c_pitch] = acc[i][r];
+      }
+  }
+  if (!wz_below) return;
+  f32x16 sacc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+  const float* af2 = wf + 2 * l31 + h;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const float v = acc[q >> 4][q & 15];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[(q * KP + i * 32) * 2], v, sacc[i], 0, 0, 0);
+  }
+  if (c < half_below) {
+    const long zplane = (long)rows_pad * 2 * half_below;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int bin = m < HB ? m : m - HB, col = (m < HB ? 0 : half_below) + c;
+        if (bin < bins_below) zf_below[(long)bin * zplane + (long)row * 2 * half_below + col] = sacc[i][r];
+      }
+  }
+}
+
 // ---- filters -> their spectra as a GEMM operand -------------------------------------------------------------
 // G[k][c][o] = sum_w F[w][c][o] e^{-2 pi i k w / N}.
 //  gfwd [bins][2 cph][2 npo]:  [[Gr, -Gi], [Gi, Gr]]      (Y = S conj(G); cph = spectra half width).  Back-prop to the input
@@ -930,14 +1090,21 @@ int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf
   return st::check_launch("conv fft bias grad");
 }
 
-int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
-                                   const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+// Back-prop to the input in a CHAIN of frequency-domain layers: below_tables / below_zf given (the layer below, whose output
+// gradient dx is) -- when the shapes allow (at most 8 blocks per utterance, no pad rows, spills of at most 4 frames into either
+// neighbour block, dx channels packing like the layer below's output) ONE launch inverts every block at its whole window,
+// overlap-adds through LDS, masks, stores dx and leaves the layer below's dz spectra in below_zf (*below_zf_written = 1: that
+// layer skips st_conv1d_fft_dz_spectra_f32).  Without them, or when the shapes do not fit: the three-term inverse of rounds 2-3.
+int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
+                                         const st_tensor3* act, const st_tensor3* dx, const float* tables, const float* below_tables,
+                                         float* below_zf, int below_width, int* below_zf_written, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tensor_ok(dx) && zf && gfwd && workspace && tables && width_ok(width), "conv fft bwd_data: bad argument");
   ST_REQUIRE(dz->batch == dx->batch && dz->frames == dx->frames && pad_left >= 0 && pad_left < width, "conv fft bwd_data: stride-1 layers only");
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(dx, dz, width), "conv fft bwd_data: workspace / shape");
   if (act) ST_REQUIRE(tensor_ok(act) && act->batch == dx->batch && act->frames == dx->frames && act->c_pitch >= dx->c_pitch,
                       "conv fft bwd_data: mask tensor mismatch");
+  if (below_zf_written) *below_zf_written = 0;
   hipStream_t s = st::as_stream(stream);
   const Plan p = make_plan(width, dz->frames, dz->batch);
   // X[bin] = Z[bin] (rows x 2 npo) * gfwd[bin]^T (2 npo x 2 cph): the forward spectra read as a transposed operand
@@ -949,9 +1116,38 @@ int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const 
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames, nullptr};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
-  launch_idft<3>(xf, tables + T_IX, p, cph, nchunks, out, nullptr, 0, act ? act->base + (long)act->halo * act->c_pitch : nullptr,
-                 act ? (long)act->t_pitch * act->c_pitch : 0L, act ? act->c_pitch : 0, s);
+  const float* mask = act ? act->base + (long)act->halo * act->c_pitch : nullptr;
+  const long mask_bs = act ? (long)act->t_pitch * act->c_pitch : 0L;
+  const int right = width - 1 - pad_left;
+  const bool window_form = p.blocks <= FUSE_BLOCKS && p.rows == p.rows_pad && pad_left <= FUSE_HALO && right <= FUSE_HALO &&
+                           st::tuning(st::TUNE_NO_FUSED_TRANSFORMS) == 0;
+  if (window_form) {
+    // the layer below's dz spectra ride along when its zf rows are laid out like this call's columns
+    const bool below = below_tables && below_zf && width_ok(below_width) && npad_of(dx->channels) % 128 == 0 &&
+                       npad_of(dx->channels) == cph && 32 * nchunks == cph;
+    const Plan pb = make_plan(below ? below_width : width, dx->frames, dx->batch);
+    st::trace("idft_ola_dft_rows<%d%s> rows=%d chunks=%d bins=%d", p.bins <= 36 ? 18 : 24, below ? ",dz-spectra" : "", p.rows, nchunks, p.bins);
+    const dim3 grid(dx->batch * nchunks), block(64 * FUSE_BLOCKS);
+    const float* wz = below ? below_tables + T_ZP : nullptr;
+    st::LaunchTimer timer(s);
+    if (p.bins <= 36)
+      st::launch_timed(timer, idft_ola_dft_rows_kernel<18>, grid, block, s, xf, tables + T_IW, p.blocks, p.rows_pad, p.bins, cph, nchunks, out,
+                       pad_left, right, mask, mask_bs, act ? act->c_pitch : 0, wz, pb.bins, cph, below ? below_zf : nullptr);
+    else
+      st::launch_timed(timer, idft_ola_dft_rows_kernel<24>, grid, block, s, xf, tables + T_IW, p.blocks, p.rows_pad, p.bins, cph, nchunks, out,
+                       pad_left, right, mask, mask_bs, act ? act->c_pitch : 0, wz, pb.bins, cph, below ? below_zf : nullptr);
+    if (below && below_zf_written) *below_zf_written = 1;
+    return st::check_launch("conv fft bwd_data (window form)");
+  }
+  launch_idft<3>(xf, tables + T_IX, p, cph, nchunks, out, nullptr, 0, mask, mask_bs, act ? act->c_pitch : 0, s);
   return st::check_launch("conv fft bwd_data");
+}
+
+int st_conv1d_nwc_bwd_data_fft_f32(const st_tensor3* dz, const float* zf, const float* gfwd, int width, int pad_left,
+                                   const st_tensor3* act, const st_tensor3* dx, const float* tables, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return st_conv1d_nwc_bwd_data_fft_chain_f32(dz, zf, gfwd, width, pad_left, act, dx, tables, nullptr, nullptr, 0, nullptr, workspace,
+                                              workspace_bytes, stream);
 }
 
 // ======== the same three operations with the per-bin products on the bf16 matrix pipe (conv_bf16.hip) ===================

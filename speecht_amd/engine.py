@@ -1195,6 +1195,7 @@ class Wav2LetterEngine:
         if top_pending != j:
           hook(j)
     bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
+    zf_ready = False             # layer i's dz spectra already written by the back-prop kernel of layer i + 1
     for i in reversed(range(len(self.layers))):
       l = self.layers[i]
       gf, gb = self._slice(self.grads, i)
@@ -1211,8 +1212,11 @@ class Wav2LetterEngine:
           call('st_bias_grad_f32', self.dZ[i].ref, self._ptr(gb), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       elif i in self.fft and self.fft_conv:
         f = self.fft[i]
-        # the spectra of dz serve the filter gradient here and back-prop to the input below
-        call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, f['width'], self._ptr(f['tables']), self._ptr(f['zf']), s)
+        # the spectra of dz serve the filter gradient here and back-prop to the input below (the layer above may have left
+        # them behind already: its back-prop kernel transformed the frames it had just produced, `zf_ready`)
+        if not zf_ready:
+          call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, f['width'], self._ptr(f['tables']), self._ptr(f['zf']), s)
+        zf_ready = False
         polyphase = f['shift'] is not None       # the gradient comes out in the shifted layout of the polyphase taps
 
         def filter_gradient(f=f, l=l, i=i, gf=gf, gb=gb, need_bias=need_bias, polyphase=polyphase, ws=f.get('ws2', f['ws'])):
@@ -1260,8 +1264,13 @@ class Wav2LetterEngine:
       elif i > 0 and i in self.fft and self.fft_conv:
         f = self.fft[i]
         act = self.X[i].ref if self.layers[i - 1].relu else None
-        call('st_conv1d_nwc_bwd_data_fft_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gfwd']), l.width,
-             self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        below = self.fft.get(i - 1)                # a frequency-domain layer below: its dz spectra can ride along
+        written = ctypes.c_int(0)
+        call('st_conv1d_nwc_bwd_data_fft_chain_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gfwd']), l.width,
+             self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(below['tables']) if below else None,
+             self._ptr(below['zf']) if below else None, below['width'] if below else 0, ctypes.byref(written), self._ptr(f['ws']),
+             f['ws'].numel() * 4, s)
+        zf_ready = written.value == 1
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1

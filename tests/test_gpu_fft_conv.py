@@ -485,7 +485,9 @@ def test_one_tap_back_prop_reads_the_forward_filters_transposed(dev, B, T, cin, 
 def test_inverse_transform_hands_its_frames_to_the_next_layers_forward_transform(dev, B, T, taps):
   """st_conv1d_nwc_fwd_fft_chain_f32: in a chain of frequency-domain layers the inverse transform of layer i (bias, ReLU) feeds the
   forward transform of layer i + 1 in registers (idft_dft_rows_kernel: the accumulator layout is a k-step order of the next DFT
-  once its matrix has the columns permuted; halo frames of the neighbour blocks through LDS) when the shapes allow -- at most 8
+  once its matrix has the columns permuted; halo frames of the neighbour blocks through LDS), and in back-prop ONE inverse
+  transform per block over its whole window replaces the three-term overlap-add (spills through LDS), masks and transforms
+  the frames again for the layer below (idft_ola_dft_rows_kernel) -- when the shapes allow -- at most 8
   blocks per utterance, batch x blocks a multiple of 128, a next window reaching <= 4 frames into a neighbour.  Against the
   separate kernels (st_set_tuning("no_fused_transforms", 1)): logits, every stored activation and every gradient (the filter
   gradients read the handed-over spectra) to fp32 rounding; against the float64 oracle at the usual bound; ragged last blocks
@@ -508,8 +510,8 @@ def test_inverse_transform_hands_its_frames_to_the_next_layers_forward_transform
       eng.set_labels(labels)
       with launch_trace() as tr:
         eng.forward()
-      eng.ctc_loss_grad(1.0 / B)
-      eng.backward()
+        eng.ctc_loss_grad(1.0 / B)
+        eng.backward()
       torch.cuda.synchronize()
       runs.append(([t.buf.clone() for t in eng.X], eng.grads.clone(), tr.lines, eng.get_grads(), eng.logits_time_major().cpu().numpy()))
     finally:
@@ -519,8 +521,15 @@ def test_inverse_transform_hands_its_frames_to_the_next_layers_forward_transform
   assert set(eng.fft) == {1, 2, 3}
   assert len(fused) == (2 if fits else 0), '\n'.join(runs[0][2])             # layers 1 -> 2 and 2 -> 3
   assert not any(l.startswith('idft_dft_rows<') for l in runs[1][2])
+  # back-prop: the window-form inverse with the overlap-add through LDS for all three layers, the dz spectra of the layer
+  # below riding along where that layer is a frequency-domain one (3 -> 2, 2 -> 1; layer 0 is a W-tap layer)
+  ola = [l for l in runs[0][2] if l.startswith('idft_ola_dft_rows<')]
+  assert len(ola) == (3 if fits else 0) and sum(1 for l in ola if ',dz-spectra>' in l) == (2 if fits else 0), '\n'.join(runs[0][2])
+  assert not any(l.startswith('idft_ola_dft_rows<') for l in runs[1][2])
   if fits:
-    assert sum(1 for l in runs[0][2] if l.startswith('dft_rows<')) == 1     # only the first layer transforms its input itself
+    # only the bottom layer of the chain transforms its input itself, only the top one its dz
+    assert sum(1 for l in runs[0][2] if l.startswith('dft_rows<')) == 2
+    assert sum(1 for l in runs[1][2] if l.startswith('dft_rows<')) == 6
   for a, b in zip(runs[0][0], runs[1][0]):
     assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
   assert float((runs[0][1] - runs[1][1]).abs().max()) <= 5e-6 * float(runs[1][1].abs().max())

@@ -1235,7 +1235,9 @@ class Wav2LetterEngine:
           # narrow layers' products (36 bins x 16 tiles) leave a quarter of the CU slots of their last round empty --
           # side by side they fill each other's gaps -- and the HBM-bound transforms of one chain run under the
           # matrix-pipe-bound products of the other (measured: 7.84 -> 7.43 ms per step).
-          self._on_side_stream(filter_gradient)
+          # (round 4: with back-prop's transforms fused the compute stream needs ~80 us per narrow layer, ONE side stream's
+          # chain -- 73 + 42 + 9 us, in order -- had become the pace of the backward pass: the chains take the two side streams in turn)
+          self._on_side_stream(filter_gradient, second=(i % 2 == 1 and os.environ.get('ST_WGRAD_TWO_SIDES', '1') != '0'))
           side_wgrad, deferred = True, i
         else:
           filter_gradient()

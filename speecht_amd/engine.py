@@ -196,7 +196,7 @@ def role_stream(device, role):
     pool = {}
     with torch.cuda.device(device):
       torch.zeros(1, device=device)                       # the compute (current) stream has its queue first
-      keep = [torch.cuda.Stream(device) for _ in range(int(os.environ.get('ST_STREAM_ROTATE', '0')))]   # (experiments)
+      keep = []
       order = os.environ.get('ST_STREAM_ORDER', 'h2d,side,side2,upload,collective').split(',')
       for r in keep + order:
         st = r if not isinstance(r, str) else torch.cuda.Stream(device)

@@ -742,6 +742,9 @@ class Wav2LetterEngine:
              self._ptr(f['tables']), self._ptr(gf), 1, self._ptr(f['ws']), f['ws'].numel() * 4, s)
         call('st_conv1d_fft_bias_grad_dc_f32', self._ptr(f['dc']), f['rows'], l.cout, l.n_pad, self._ptr(gb), s)
         if on_layer_done is not None and wanted(i):
+          if side:                       # (filter gradients of layers above still on the side streams: same bucket, see below)
+            self._join_side_stream()
+            side = False
           on_layer_done(i)
         relu_in = self.layers[i - 1].relu
         call('st_conv1d_nwc_bwd_data_fft_planes', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['g']), l.width, f['pl'],
@@ -761,6 +764,12 @@ class Wav2LetterEngine:
       else:
         filter_gradient()
         if on_layer_done is not None and wanted(i):
+          if side:
+            # the bucket this layer completes also holds layers whose filter gradients are still in flight on the side
+            # streams (bottom bucket L0..L3: L1-L3 run beside back-prop, L0 does not); the exchange is ordered behind the
+            # compute stream only
+            self._join_side_stream()
+            side = False
           on_layer_done(i)
       if i > 0:
         relu_in = self.layers[i - 1].relu
@@ -1253,6 +1262,12 @@ class Wav2LetterEngine:
         call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
              self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
       if on_layer_done is not None and deferred != i and wanted(i):
+        if side_wgrad:
+          # this layer's own gradient ran on the compute stream, but its bucket also holds the layers above whose filter
+          # gradients are still in flight on the side streams (the bottom bucket L0..L3: L1-L3 went there, L0 did not): the
+          # exchange is ordered behind the compute stream only, so the compute stream waits for them first
+          self._join_side_stream()
+          side_wgrad = False
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):
         act = self.X[i].ref if self.layers[i - 1].relu else None

@@ -127,6 +127,101 @@ def test_data_parallel_four_ranks_four_buckets_side_stream_gradients(tmp_path):
     assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o[-4000:])
 
 
+DP_DELAY_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ST_ROOT"])
+from tests import workloads as WL
+from speecht_amd.engine import Wav2LetterEngine
+from speecht_amd.data_parallel import GradientAllReducer, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = os.environ["ST_TEST_MODE"]
+dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks drive cuda:0
+layers = WL.w2l_layers(16, width=128, fc=256)
+params = WL.xavier_params(layers, seed=3, bias_range=0.05)
+x, seq, labels = WL.make_batch([200, 200, 161, 200, 133, 200, 97, 200], 16, seed=4)
+lo, hi = shard_range(len(labels), rank, world)
+
+def one_step(eng, red, slow):
+  # `slow`: every hand-over to a side stream is followed by a long spin on THAT stream before the work, so the filter gradients
+  # that run there finish long after the compute stream has enqueued the bucket's exchange -- unless the engine orders the two
+  if slow:
+    plain = eng._on_side_stream
+    def delayed(fn, second=False):
+      def spun():
+        with torch.cuda.stream(eng._stream):
+          torch.cuda._sleep(int(2e6))                    # 20 ms of the 100 MHz wall clock (1 ms if it counted shader cycles)
+        fn()
+      plain(spun, second=second)
+    eng._on_side_stream = delayed
+  try:
+    eng.load_batch(x[lo:hi], seq[lo:hi])
+    eng.set_labels(labels[lo:hi])
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / len(labels))
+    eng.backward(red.on_layer_done, red.hook_layers)       # hooks only where a bucket ends, as SpeechModel.step and bench.py call it
+    red.finish()
+    torch.cuda.synchronize()
+    g = eng.reduce_buffer.clone()
+    eng.apply_update(1e-3, 5.0)
+    torch.cuda.synchronize()
+  finally:
+    if slow:
+      del eng._on_side_stream
+  return g
+
+def engine():
+  e = Wav2LetterEngine(layers, device="cuda:0", conv_mode=mode)
+  e.set_weights(params)
+  return e
+
+a, b = engine(), engine()
+ra = GradientAllReducer(a.reduce_buffer, a.reduce_ranges)
+rb = GradientAllReducer(b.reduce_buffer, b.reduce_ranges)
+assert ra.hook_layers == {9, 8, 4, 0}, ra.hook_layers
+for k in range(2):
+  ga, gb = one_step(a, ra, slow=False), one_step(b, rb, slow=True)
+  assert torch.equal(ga, gb), ("reduced gradients depend on side-stream timing", k, float((ga - gb).abs().max()))
+  assert torch.equal(a.params, b.params)
+if mode == "fp32":
+  assert all("ws2" in a.fft[i] for i in range(1, 8))     # the narrow layers' filter gradients did run on the side streams
+else:
+  assert set(range(1, 8)) <= set(a._side_wgrad_bf16), a._side_wgrad_bf16
+mine = b.params.clone()
+gathered = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(gathered, mine)
+assert all(torch.equal(gathered[0], g) for g in gathered), "replicas diverged"
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_bucket_exchange_waits_for_side_stream_filter_gradients(tmp_path, mode):
+  """with hooks only at bucket-boundary layers, the bottom bucket (L0..L3) is handed over at L0,
+  whose own gradient runs on the compute stream while those of L1-L3 are still on the side streams.  Two ranks on cuda:0
+  (gloo): the same steps once as they come and once with every side-stream hand-over delayed by a long spin kernel must give
+  bit-identical reduced gradients and weights."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  script = tmp_path / 'dp_delay_worker.py'
+  script.write_text(DP_DELAY_WORKER)
+  env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29647' if mode == 'fp32' else '29649', WORLD_SIZE='2',
+             ST_FFT_MIN_ROWS='1', ST_FFT_MIN_ROWS_NARROW='1', ST_TEST_MODE=mode)
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT) for r in range(2)]
+  outs = []
+  for p in procs:
+    try:
+      outs.append(p.communicate(timeout=600)[0].decode())
+    except subprocess.TimeoutExpired:
+      for q in procs:
+        q.kill()
+      raise
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o[-4000:])
+
+
 def test_bench_rccl_transport_through_the_self_launch_path_at_world_one():
   """`python bench.py --gpus 1 --self-launch --force-allreduce --allreduce rccl`: torch.distributed.run starts the one
   rank, the library's communicator is created from the broadcast id, every bucket goes through st_allreduce_buckets_f32,

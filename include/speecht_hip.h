@@ -134,6 +134,14 @@ int st_gemm_nn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const f
  * workspace. */
 size_t st_gemm_nn_batched_ws_bytes(void);
 size_t st_gemm_nn_batched_ctrl_bytes(void);
+/* Lost hand-offs of the persistent launches since the library was loaded.  A reader whose bounded poll runs out (a producer
+ * workgroup that never published its partial tile) writes NaN into its tile -- never a sum with an unpublished partial -- and
+ * counts here.  st_streamk_lost_ptr: the device address of the 32-bit count; st_streamk_lost_count: a synchronous read (default
+ * stream); st_streamk_lost_fetch_async: for a caller that already copies status words back after a step (engine.fetch_losses). */
+int st_streamk_lost_ptr(void** device_word);
+int st_streamk_lost_count(unsigned* count);
+/* the count copied to `host_word` (pinned host memory) behind everything enqueued on `stream` so far */
+int st_streamk_lost_fetch_async(unsigned* host_word, void* stream);
 int st_gemm_nn_batched_ws_f32(const float* a, int64_t lda, int64_t a_batch, const float* b, int64_t b_batch, float* c,
                               int64_t ldc, int64_t c_batch, int m, int k, int n, int batches, void* workspace,
                               size_t workspace_bytes, void* stream);

@@ -43,6 +43,9 @@ _SIGNATURES = {
                                        c_int, c_int, c_void_p]),
     'st_gemm_nn_batched_ws_bytes': (c_size_t, []),
     'st_gemm_nn_batched_ctrl_bytes': (c_size_t, []),
+    'st_streamk_lost_ptr': (c_int, [POINTER(c_void_p)]),
+    'st_streamk_lost_count': (c_int, [POINTER(ctypes.c_uint32)]),
+    'st_streamk_lost_fetch_async': (c_int, [c_void_p, c_void_p]),
     'st_gemm_nn_batched_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_gemm_nn_batched_bt_ws_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -524,6 +524,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(NNParams p) {
 // Inner loop: the FAST stage of gemm_nn_kernel (whole k-tiles, LDS-DMA with source-side XOR swizzle, DMA slices between
 // MFMA quads); no row-offset tables (rows are plain multiples of lda).
 // ------------------------------------------------------------------------------------
+// Lost hand-offs since the library was loaded (module-scope, zero at load): a reader whose poll ran out counts here AND poisons its
+// tile with NaN instead of adding whatever the producer's slot holds; the host reads the word with the step's other status words
+// (st_streamk_lost_ptr / st_streamk_lost_count; engine.fetch_losses raises on a non-zero count).
+__device__ unsigned g_sk_lost = 0;
+
 struct BinsParams {
   const float* A; const float* B; float* C;
   long lda, ldb, ldc, a_batch, b_batch, c_batch;
@@ -532,6 +537,7 @@ struct BinsParams {
   unsigned* ctrl;                     // st::SK_CTRL_WORDS control words (flags, timeout count)
   float* partial;                     // [8 * wgs_per_xcd][BM * BN]
   unsigned epoch;                     // != 0
+  unsigned pub_epoch;                 // what producers publish: == epoch (the "streamk_test_drop" knob: another value -- every hand-off is lost)
 };
 
 // BT: B given transposed ([N][ldb], the reduction index contiguous) -- back-prop to the input reads the FORWARD filter spectra
@@ -548,6 +554,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
   typedef unsigned long long u64;
 
   __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ];
+  __shared__ int sk_lost;             // sticky: a hand-off to this workgroup timed out (its tiles are NaN from then on)
   float* const As = smem;
   float* const Bs = smem + 2 * A_SZ;
 
@@ -556,6 +563,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WNW, wn = wave % WNW;
+  if (tid == 0) sk_lost = 0;          // (read only behind the barrier that follows a poll)
 
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int slot = blockIdx.x;                               // this workgroup's partial tile and flag
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.ctrl + st::SK_FLAGS + slot, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(p.ctrl + st::SK_FLAGS + slot, p.pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
     // The piece holds the tile's start.  If it is not the whole tile, the rest are the FIRST pieces of the next runs of this
@@ -733,12 +741,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1u << 21)) {
             __hip_atomic_fetch_add(p.ctrl + st::SK_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&g_sk_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_lost = 1;
             break;
           }
         }
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // taken back: zero again for the next call
       }
       __syncthreads();
+      // an unpublished partial must not be consumed silently: the tile becomes NaN (and the count says why)
+      const float poison = sk_lost ? __uint_as_float(0x7fc00000u) : 0.f;
       const float* const theirs = p.partial + (long)src * (BM * BN);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -750,8 +762,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc[i][0][r] += __uint_as_float((unsigned)part[r]);
-          acc[i][1][r] += __uint_as_float((unsigned)(part[r] >> 32));
+          acc[i][0][r] += __uint_as_float((unsigned)part[r]) + poison;
+          acc[i][1][r] += __uint_as_float((unsigned)(part[r] >> 32)) + poison;
         }
       }
       covered += min(p.plan.upw, p.plan.nk - covered);
@@ -1294,6 +1306,7 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
       q.ctrl = reinterpret_cast<unsigned*>(sk_ws);
       q.partial = sk_ws + st::SK_CTRL_WORDS;
       q.epoch = epoch;
+      q.pub_epoch = st::tuning(st::TUNE_STREAMK_TEST_DROP) ? (epoch ^ 0x80000000u) : epoch;   // (test hook: producers that never arrive)
       st::trace("gemm_nn_bins<64,128,2,2%s> batched bins=%d M=%d Np=%d Kp=%d streamk wgs=%d upw=%d gflop=%.3f", b_transposed ? ",bt" : "",
                 batches, M, N, K, 8 * plan.wgs_per_xcd, plan.upw, 2e-9 * M * (double)N * K * batches);
       {
@@ -1378,6 +1391,36 @@ static int bwd_data_impl(const st_tensor3* dz, const float* packed_t, bool forwa
                          size_t workspace_bytes, void* stream);
 
 extern "C" {
+
+int st_streamk_lost_ptr(void** device_word) {
+  ST_REQUIRE(device_word, "st_streamk_lost_ptr: null argument");
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sk_lost)) != hipSuccess || !p) {
+    st::set_error("st_streamk_lost_ptr: hipGetSymbolAddress failed");
+    return ST_ELAUNCH;
+  }
+  *device_word = p;
+  return ST_OK;
+}
+
+int st_streamk_lost_fetch_async(unsigned* host_word, void* stream) {
+  ST_REQUIRE(host_word, "st_streamk_lost_fetch_async: null argument");
+  if (hipMemcpyFromSymbolAsync(host_word, HIP_SYMBOL(g_sk_lost), sizeof(unsigned), 0, hipMemcpyDeviceToHost, st::as_stream(stream)) !=
+      hipSuccess) {
+    st::set_error("st_streamk_lost_fetch_async: hipMemcpyFromSymbolAsync failed");
+    return ST_ELAUNCH;
+  }
+  return ST_OK;
+}
+
+int st_streamk_lost_count(unsigned* count) {
+  ST_REQUIRE(count, "st_streamk_lost_count: null argument");
+  if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_sk_lost), sizeof(unsigned), 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    st::set_error("st_streamk_lost_count: hipMemcpyFromSymbol failed");
+    return ST_ELAUNCH;
+  }
+  return ST_OK;
+}
 
 int st_packed_dims(int width, int cin_pitch, int cout, int* k_valid, int* k_pad, int* n_pad) {
   ST_REQUIRE(width > 0 && cin_pitch > 0 && cin_pitch % 16 == 0 && cout > 0, "st_packed_dims: bad shape");

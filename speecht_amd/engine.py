@@ -293,6 +293,10 @@ class Wav2LetterEngine:
     self._gfwd_fresh = False
     self.fft = {}
     self.fftb = {}
+    # lost stream-K hand-offs are counted per process by the library; this engine reports the ones after its creation
+    seen = ctypes.c_uint32(0)
+    call('st_streamk_lost_count', ctypes.byref(seen))
+    self._sk_lost = [torch.zeros(1, dtype=torch.int32, pin_memory=True), int(seen.value)]
 
   # ---- plumbing --------------------------------------------------------------------------
   @property
@@ -1452,12 +1456,14 @@ class Wav2LetterEngine:
                          torch.empty(16, dtype=torch.float32, pin_memory=True))
     loss_h, status_h, event, gate_h = self._loss_host
     stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    lost_h = self._streamk_lost_async(stream)
     with torch.cuda.stream(stream):
       loss_h[:2 * B].copy_(self.loss_pair, non_blocking=True)
       status_h[:B].copy_(self.ctc_status, non_blocking=True)
       gate_h[:1].copy_(self.gate, non_blocking=True)
       event.record(stream)
     event.synchronize()
+    self._check_streamk_lost(lost_h)
     st = status_h[:B].numpy()
     skipped = getattr(self, '_updates_in_flight', 0)
     self._updates_in_flight = 0
@@ -1476,6 +1482,22 @@ class Wav2LetterEngine:
     if precise:
       return pair[:B].astype(np.float64) + pair[B:].astype(np.float64)
     return pair[:B].copy()
+
+  def _streamk_lost_async(self, stream):
+    """The library's count of lost stream-K hand-offs (st_streamk_lost_ptr: a reader's bounded poll ran out and its tile became
+    NaN) on its way to pinned host memory behind everything enqueued on ``stream``; `_check_streamk_lost` reads it after the
+    caller's own synchronisation."""
+    host = self._sk_lost[0]
+    call('st_streamk_lost_fetch_async', ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
+    return host
+
+  def _check_streamk_lost(self, host):
+    seen = self._sk_lost[1]
+    now = int(host[0])
+    if now != seen:
+      self._sk_lost[1] = now
+      raise _lib.SpeechtHipError('{} hand-off(s) of the persistent per-bin products timed out (a producer workgroup never '
+                                 'published its partial tile); the tiles concerned were set to NaN'.format(now - seen))
 
   def losses_precise(self):
     """float64 losses (hi + lo) straight from the device buffers, no status check (tests, bench parity)."""

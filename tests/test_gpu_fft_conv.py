@@ -426,6 +426,58 @@ def test_batched_products_as_one_persistent_stream_k_launch(dev, bins, M, K, N, 
   assert float((plain.double() - ref).abs().max() / ref.abs().max()) < tol
 
 
+def test_a_lost_stream_k_producer_poisons_its_tile_and_is_counted(dev):
+  """a reader whose bounded poll runs out used to add whatever the producer's slot held and only bump a
+  word nobody read.  With the test hook that makes every producer publish a wrong epoch (`streamk_test_drop`): the tiles that
+  needed a hand-off come out NaN (never a silent sum with an unpublished partial), the others are right, the library's lost-count
+  rises (st_streamk_lost_count / _fetch_async, what engine.fetch_losses raises on), and the next launch -- knob off, same
+  scratch -- is correct again."""
+  from speecht_amd import _lib
+  from speecht_amd._lib import call, set_tuning
+  lib = _lib.load()
+  bins, M, K, N = 36, 256, 512, 512
+  rng = np.random.default_rng(5)
+  A = torch.as_tensor(rng.standard_normal((bins, M, K)), dtype=torch.float32).to(dev)
+  B = torch.as_tensor(rng.standard_normal((bins, K, N)) / np.sqrt(K), dtype=torch.float32).to(dev)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  ws_bytes = lib.st_gemm_nn_batched_ws_bytes()
+  ws = torch.zeros(ws_bytes // 4, dtype=torch.float32, device=dev)
+  ref = torch.matmul(A.double(), B.double())
+
+  def lost():
+    n = ctypes.c_uint32(0)
+    call('st_streamk_lost_count', ctypes.byref(n))
+    return n.value
+
+  before = lost()
+  C = torch.zeros((bins, M, N), dtype=torch.float32, device=dev)
+  set_tuning('streamk_test_drop', 1)
+  try:
+    call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C), N, M * N, M, K, N, bins, P(ws), ws_bytes, None)
+    torch.cuda.synchronize()
+  finally:
+    set_tuning('streamk_test_drop', 0)
+  dropped = lost() - before
+  assert dropped > 0
+  tiles = C.view(bins, M // 64, 64, N // 128, 128).permute(0, 1, 3, 2, 4).reshape(-1, 64 * 128)
+  nan_tiles = torch.isnan(tiles).all(dim=1)
+  mixed = torch.isnan(tiles).any(dim=1) & ~nan_tiles
+  assert int(mixed.sum()) == 0 and 0 < int(nan_tiles.sum()) < tiles.shape[0], (int(mixed.sum()), int(nan_tiles.sum()))
+  good = ~torch.isnan(C)
+  assert float((C.double() - ref)[good].abs().max() / ref.abs().max()) < 2e-6
+  # the pinned-word form the engine uses, ordered behind the stream's work
+  host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+  call('st_streamk_lost_fetch_async', ctypes.c_void_p(host.data_ptr()), None)
+  torch.cuda.synchronize()
+  assert int(host[0]) == before + dropped
+  # same scratch, producers publishing again: exact, and nothing new is counted
+  C2 = torch.zeros_like(C)
+  call('st_gemm_nn_batched_ws_f32', P(A), K, M * K, P(B), K * N, P(C2), N, M * N, M, K, N, bins, P(ws), ws_bytes, None)
+  torch.cuda.synchronize()
+  assert not torch.isnan(C2).any() and float((C2.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+  assert lost() == before + dropped
+
+
 @pytest.mark.parametrize('B,T,cin,cout,relu_below', [(3, 70, 2000, 2000, True), (2, 333, 2000, 29, True), (4, 40, 250, 2000, False),
                                                      (1, 5, 130, 64, True)])
 def test_one_tap_back_prop_reads_the_forward_filters_transposed(dev, B, T, cin, cout, relu_below):

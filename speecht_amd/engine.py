@@ -120,9 +120,14 @@ class _PendingBeamDecode:
 
   def __init__(self, slot, batch, t_out):
     self._slot, self._batch, self._t_out = slot, batch, t_out
+    self._generation = slot['generation']
 
   def result(self):
     s = self._slot
+    if s['generation'] != self._generation:
+      # the slots form a ring of (decoder streams + 1): this handle's pinned buffers and event now belong to a later batch
+      raise RuntimeError('beam-search handle read too late: {} further beam_search_decode_async call(s) re-used its slot; read a '
+                         'handle before issuing more than len(decode streams) further calls'.format(s['generation'] - self._generation))
     s['event'].synchronize()
     lens = s['lens_h'][:self._batch].numpy()
     ids = s['ids_h'][:self._batch * self._t_out].numpy().reshape(self._batch, self._t_out)
@@ -189,24 +194,17 @@ def role_stream(device, role):
   process shares them (ordering between engines is by the events each engine records anyway), and the role -> queue map is
   the same in every process: compute stream q0, h2d q1, side q2, side2 q3, upload q0, collective q1 -- the two side streams
   on queues of their own (with side2 on the compute stream's queue, as creation order had it before: bf16 step 2.68 instead
-  of 2.57 ms, fp32 and bf16x6 within 0.5 %; ST_STREAM_ORDER lists the roles in another order, '-' skips a queue)."""
+  of 2.57 ms, fp32 and bf16x6 within 0.5 %; DESIGN 4.8 item 5 has the orders that were measured)."""
   key = str(device)
   pool = _ROLE_STREAMS.get(key)
   if pool is None:
     pool = {}
     with torch.cuda.device(device):
       torch.zeros(1, device=device)                       # the compute (current) stream has its queue first
-      keep = []
-      order = os.environ.get('ST_STREAM_ORDER', 'h2d,side,side2,upload,collective').split(',')
-      for r in keep + order:
-        st = r if not isinstance(r, str) else torch.cuda.Stream(device)
-        with torch.cuda.stream(st):
+      for r in ('h2d', 'side', 'side2', 'upload', 'collective'):
+        pool[r] = torch.cuda.Stream(device)
+        with torch.cuda.stream(pool[r]):
           torch.zeros(1, device=device)
-        if isinstance(r, str) and r != '-':                 # ('-': a queue slot left to nobody)
-          pool[r] = st
-        elif isinstance(r, str):
-          keep.append(st)
-      pool['_keep'] = keep
       torch.cuda.synchronize(device)
     _ROLE_STREAMS[key] = pool
   if role not in pool:                                   # (a role the order left out)
@@ -1116,7 +1114,7 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16':
       if not self._wtplanes_fresh and hasattr(self, 'WTb'):
         self._on_side_stream(lambda: self._refresh_bf16_filters(True))
-    elif not self._packed_t_fresh and self._flip_layers():
+    elif not self._packed_t_ok() and self._flip_layers():
       self._on_side_stream(self._refresh_backward_operands)
     self._wait_uploads()
     call('st_ctc_loss_grad_hilo_f32', self.X[-1].ref, self._ptr(self.label_ids), self._ptr(self.label_offs),
@@ -1133,7 +1131,7 @@ class Wav2LetterEngine:
     (st_conv1d_1tap_bwd_data_bias_f32): one tap, whole 32-deep k-tiles over the output channels."""
     l = self.layers[i]
     return (self.conv_mode == 'fp32' and i > 0 and l.width == 1 and l.stride == 1 and l.cout_pitch % 32 == 0 and
-            l.n_pad >= l.cout_pitch and l.nt_pad % 128 == 0 and os.environ.get('ST_BWD_TRANSPOSED', '1') != '0')
+            l.n_pad >= l.cout_pitch and l.nt_pad % 128 == 0)
 
   def _flip_layers(self):
     """Layers whose back-prop to the input still needs the flipped / transposed copy of the weights: W-tap layers of
@@ -1159,7 +1157,13 @@ class Wav2LetterEngine:
       ev.record(stream)
       self._bwd_ready[i] = ev
     self._packed_t_fresh = True
+    self._packed_t_layers = frozenset(self._flip_layers())
     self._wtplanes_fresh = False
+
+  def _packed_t_ok(self):
+    """The flipped / transposed copies are current for every layer that needs one NOW: which layers do depends on state that
+    can change between steps (the shape's frequency-domain set, `fft_conv`), so a refresh remembers the set it rebuilt."""
+    return self._packed_t_fresh and frozenset(self._flip_layers()) <= getattr(self, '_packed_t_layers', frozenset())
 
   def _wait_bwd_operands(self, i=None):
     """The compute stream waits for the back-prop operands of layer i (None: of every layer) if they were rebuilt on the
@@ -1185,7 +1189,7 @@ class Wav2LetterEngine:
     if self.conv_mode == 'bf16':
       self._join_side_stream()
       return self._backward_bf16(on_layer_done, wanted)
-    if not self._packed_t_fresh:
+    if not self._packed_t_ok():
       self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad; nothing at the model's shapes)
     if self.fft and self.fft_conv and not self._gfwd_fresh:
       self._join_side_stream()                    # (weights written after the forward pass: back-prop reads the same spectra)
@@ -1250,7 +1254,7 @@ class Wav2LetterEngine:
           # matrix-pipe-bound products of the other (measured: 7.84 -> 7.43 ms per step).
           # (round 4: with back-prop's transforms fused the compute stream needs ~80 us per narrow layer, ONE side stream's
           # chain -- 73 + 42 + 9 us, in order -- had become the pace of the backward pass: the chains take the two side streams in turn)
-          self._on_side_stream(filter_gradient, second=(i % 2 == 1 and os.environ.get('ST_WGRAD_TWO_SIDES', '1') != '0'))
+          self._on_side_stream(filter_gradient, second=(i % 2 == 1))
           side_wgrad, deferred = True, i
         else:
           filter_gradient()
@@ -1422,9 +1426,10 @@ class Wav2LetterEngine:
                   ids=i32(B * T, device=self.device), out_lens=i32(B, device=self.device),
                   score=torch.empty(max(B, 1), dtype=torch.float32, device=self.device), ws=i32(need // 4 + 16, device=self.device),
                   ids_h=i32(B * T, pin_memory=True), lens_h=i32(B, pin_memory=True),
-                  score_h=torch.empty(max(B, 1), dtype=torch.float32, pin_memory=True), event=torch.cuda.Event())
+                  score_h=torch.empty(max(B, 1), dtype=torch.float32, pin_memory=True), event=torch.cuda.Event(), generation=0)
       slot['event'].record(decode_stream)
       self._beam_slots[which] = slot
+    slot['generation'] += 1                                       # handles of the batch that last used this slot are stale from here on
     self._wait_uploads()
     main.wait_event(slot['event'])                               # the search that last read this slot is through
     with torch.cuda.stream(main):

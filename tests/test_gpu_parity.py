@@ -583,6 +583,13 @@ def test_pipelined_beam_search_matches_the_serial_loop_and_the_oracle(dev):
   sync_ids, sync_lp = eng.beam_search_decode(8)
   async_ids, async_lp = eng.beam_search_decode_async(8).result()
   assert async_ids == sync_ids and np.array_equal(async_lp, sync_lp)
+  # a handle whose slot a later call re-used says so instead of returning that batch's transcripts (ring of streams + 1 = 2 slots)
+  stale = eng.beam_search_decode_async(8)
+  kept = eng.beam_search_decode_async(8)
+  eng.beam_search_decode_async(8)
+  with pytest.raises(RuntimeError, match='read too late'):
+    stale.result()
+  assert kept.result()[0] == sync_ids
   torch.cuda.synchronize()
   logits = eng.logits_time_major().cpu().numpy().astype(np.float64)
   ref_ids, ref_lp = O.ctc_beam_search_decode(logits, seq // 2, 8)

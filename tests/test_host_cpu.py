@@ -111,3 +111,19 @@ def test_bench_trace_line_parsing():
   assert bench.trace_key(tn) == bench.trace_key(tn.replace('ms=0.06100', 'ms=0.09'))
   assert bench.trace_field(nn, 'ms') == pytest.approx(0.54321) and bench.trace_field(nn, 'gflop') == pytest.approx(1059.5)
   assert bench.trace_field(bt, 'ms') is None and bench.trace_field(bt, 'bins') == 36.0
+
+
+def test_speecht_import_names_resolve_to_the_native_modules():
+  """The reference's callers import ``speecht.<module>`` (execution.py:20-23, evaluation.py:20-23): the alias package hands them
+  the speecht_amd modules themselves (same objects, not copies); what is out of scope raises ImportError."""
+  import importlib
+  import speecht
+  for name in ('vocabulary', 'preprocessing', 'speech_input', 'speech_model', 'evaluation', 'training', 'execution', 'exporting'):
+    assert importlib.import_module('speecht.' + name) is importlib.import_module('speecht_amd.' + name), name
+    assert getattr(speecht, name) is importlib.import_module('speecht_amd.' + name)
+  from speecht.speech_model import Wav2LetterModel, create_default_model      # noqa: F401
+  from speecht.speech_input import InputBatchLoader, SingleInputLoader       # noqa: F401
+  from speecht import vocabulary
+  assert vocabulary.sentence_to_ids("don't") == [3, 14, 13, 26, 19]
+  with pytest.raises(ImportError):
+    importlib.import_module('speecht.corpus')

@@ -291,13 +291,20 @@ int st_ctc_greedy_decode(const st_tensor3* logits, const int32_t* seq_lens, int 
 /* ---- LM-free CTC prefix beam search, top path (BASELINE config 5) -----
  * The reference only reaches a beam search through its KenLM TensorFlow fork
  * (speech_model.py:101-111: beam_width=100, merge_repeated=False, top_paths=1); this is the stock
- * tf.nn.ctc_beam_search_decoder recursion without a scorer.  blank = C-1, C <= 32, beam <= 64.
+ * tf.nn.ctc_beam_search_decoder recursion without a scorer.  blank = C-1, C <= 32, beam <= 128 (one wavefront per
+ * utterance; beams above 64 run a two-entries-per-lane instantiation with an exact W-th-largest selection bound).
  * ids [B][max_out] int32 (labels beyond max_out are dropped, out_lens still reports the true
- * length), log_prob [B] = ln p(top prefix) under the per-frame softmax. */
+ * length), log_prob [B] = ln p(top prefix) under the per-frame softmax.  The labels are the top prefix itself, i.e.
+ * merge_repeated=False as the reference asks (speech_model.py:110); collapsing repeats is a host-side option. */
 size_t st_ctc_beam_ws(int batch, int frames, int beam_width);
 int st_ctc_beam_search_decode(const st_tensor3* logits, const int32_t* seq_lens, int beam_width,
                               int32_t* ids, int max_out, int32_t* out_lens, float* log_prob,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* ... with the reference's input transform: input_transform = 1 searches on log10(softmax(logits) + 1e-8), what
+ * speech_model.py:102 hands the decoder (which normalises it per frame like any input); 0 = the logits themselves. */
+int st_ctc_beam_search_decode_ex(const st_tensor3* logits, const int32_t* seq_lens, int beam_width, int input_transform,
+                                 int32_t* ids, int max_out, int32_t* out_lens, float* log_prob,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K12-K13: clip_by_global_norm + AdamOptimizer(epsilon outside) (speech_model.py:77-82)
  * Flat fp32 buffers of n floats.  stats (device, 2 floats) receives {global_norm, scale}.

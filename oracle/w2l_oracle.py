@@ -505,7 +505,7 @@ def ctc_greedy_decode(logits_tm, seq_lens, merge_repeated=True):
   return out, score
 
 
-def ctc_beam_search_decode(logits_tm, seq_lens, beam_width=16):
+def ctc_beam_search_decode(logits_tm, seq_lens, beam_width=16, input_transform=None):
   """LM-free CTC prefix beam search, top path only (SURVEY 8(f) item 3 / BASELINE config 5).
 
   PARITY UNPINNED: the reference only ever calls a beam search through its KenLM TensorFlow fork
@@ -519,9 +519,19 @@ def ctc_beam_search_decode(logits_tm, seq_lens, beam_width=16):
   ``slot`` is the parent entry's rank in the previous frame and c == blank marks the stay candidate.
   Scores are natural-log probabilities under the per-frame softmax.
 
+  ``input_transform='log10_softmax'``: the search runs on ``tf.log(tf.nn.softmax(logits) + 1e-8) / math.log(10)``, what the
+  reference hands its decoder (speech_model.py:102); the decoder normalises that per frame like any other input.  The labels
+  returned are the top prefix itself (merge_repeated=False, speech_model.py:110).
+
   Returns (list of id lists, log_prob [B,1]).
   """
   logits_tm = np.asarray(logits_tm, dtype=np.float64)
+  if input_transform == 'log10_softmax':
+    z = logits_tm - logits_tm.max(axis=-1, keepdims=True)
+    sm = np.exp(z) / np.exp(z).sum(axis=-1, keepdims=True)
+    logits_tm = np.log(sm + 1e-8) / math.log(10)
+  elif input_transform not in (None, 'logits'):
+    raise ValueError(input_transform)
   T, B, C = logits_tm.shape
   blank, ninf = C - 1, -np.inf
   lse = np.logaddexp

@@ -104,6 +104,8 @@ _SIGNATURES = {
     'st_ctc_beam_ws': (c_size_t, [c_int, c_int, c_int]),
     'st_ctc_beam_search_decode': (c_int, [_T3P, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_size_t, c_void_p]),
+    'st_ctc_beam_search_decode_ex': (c_int, [_T3P, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_size_t, c_void_p]),
     'st_global_norm_ws': (c_size_t, [c_size_t]),
     'st_global_norm_clip_adam_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                              c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),

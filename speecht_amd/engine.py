@@ -135,6 +135,22 @@ class _PendingBeamDecode:
             s['score_h'][:self._batch].numpy().reshape(-1, 1).copy())
 
 
+def beam_input_transform(name):
+  """The `input_transform` code of st_ctc_beam_search_decode_ex: None / 'logits' -> 0, 'log10_softmax' -> 1 (the reference's
+  decoder input, tf.log(tf.nn.softmax(logits) + 1e-8) / log(10), speech_model.py:102)."""
+  if name in (None, 'logits', 0):
+    return 0
+  if name in ('log10_softmax', 1):
+    return 1
+  raise ValueError("input_transform must be None, 'logits' or 'log10_softmax', got {!r}".format(name))
+
+
+def merge_repeated_labels(seq):
+  """tf.nn.ctc_beam_search_decoder(merge_repeated=True) on an output prefix: consecutive equal labels collapse (TF's LabelSeq walk;
+  it also collapses genuine double letters, which is why the reference passes False, speech_model.py:110)."""
+  return [v for i, v in enumerate(seq) if i == 0 or v != seq[i - 1]]
+
+
 def decoder_streams(device, decoders=2):
   """(compute stream, [decoder streams]) for overlapping a one-wave-per-utterance decoder with the NEXT batches' forward passes.
 
@@ -1374,23 +1390,28 @@ class Wav2LetterEngine:
       slot[2].record(stream)
     return _PendingDecode(slot, B, self.t_out)
 
-  def beam_search_decode(self, beam_width=16):
+  def beam_search_decode(self, beam_width=16, input_transform=None, merge_repeated=False):
     """LM-free CTC prefix beam search, top path (stock tf.nn.ctc_beam_search_decoder semantics; the
     reference's own beam search needs its KenLM fork, speech_model.py:101-111)
-    -> (list of id lists, log_prob [B,1])."""
+    -> (list of id lists, log_prob [B,1]).  Beams up to 128 (the reference runs 100).  ``input_transform='log10_softmax'``
+    searches on log10(softmax(logits) + 1e-8), the reference's decoder input (speech_model.py:102); ``merge_repeated``
+    (reference: False, speech_model.py:110) collapses repeated labels of the returned prefix the way TF's decoder does."""
     lib = _lib.load()
     B = self.dec_lens.numel()
     need = lib.st_ctc_beam_ws(B, self.t_out, int(beam_width))
     ws = self._storage.view('beam_ws', need // 4 + 16, torch.int32)[0]
     self._wait_uploads()
-    call('st_ctc_beam_search_decode', self.X[-1].ref, self._ptr(self.ctc_lens), int(beam_width),
+    call('st_ctc_beam_search_decode_ex', self.X[-1].ref, self._ptr(self.ctc_lens), int(beam_width), beam_input_transform(input_transform),
          self._ptr(self.dec_ids), self.t_out, self._ptr(self.dec_lens), self._ptr(self.dec_score),
          self._ptr(ws), ws.numel() * 4, self.stream_ptr)
     lens = self.dec_lens.cpu().numpy()
     ids = self.dec_ids.view(-1, self.t_out).cpu().numpy()
-    return [ids[b, :lens[b]].tolist() for b in range(len(lens))], self.dec_score.cpu().numpy().reshape(-1, 1)
+    out = [ids[b, :lens[b]].tolist() for b in range(len(lens))]
+    if merge_repeated:
+      out = [merge_repeated_labels(seq) for seq in out]
+    return out, self.dec_score.cpu().numpy().reshape(-1, 1)
 
-  def beam_search_decode_async(self, beam_width=16, decode_stream=None):
+  def beam_search_decode_async(self, beam_width=16, decode_stream=None, input_transform=None):
     """``beam_search_decode`` without the host synchronisation and OFF the compute stream: the logits and lengths of this
     batch are copied into a decoder slot, the search runs on ``decode_stream`` (default: a stream of the engine's own;
     `decoder_streams` gives CU-masked ones -- a list of streams is used in turn, consecutive batches' searches then run side by
@@ -1439,7 +1460,8 @@ class Wav2LetterEngine:
       ready.record(main)
     desc = Tensor3(slot['logits'].data_ptr(), xl.batch, xl.frames, xl.channels, xl.halo, xl.t_pitch, xl.c_pitch)
     decode_stream.wait_event(ready)
-    call('st_ctc_beam_search_decode', ctypes.byref(desc), self._ptr(slot['lens']), int(beam_width), self._ptr(slot['ids']), T,
+    call('st_ctc_beam_search_decode_ex', ctypes.byref(desc), self._ptr(slot['lens']), int(beam_width), beam_input_transform(input_transform),
+         self._ptr(slot['ids']), T,
          self._ptr(slot['out_lens']), self._ptr(slot['score']), self._ptr(slot['ws']), slot['ws'].numel() * 4,
          ctypes.c_void_p(decode_stream.cuda_stream))
     with torch.cuda.stream(decode_stream):

@@ -282,13 +282,16 @@ class SpeechModel:
     self._training = self.labels is not None
 
   def add_decoding_ops(self, language_model=None, lm_weight=0.8, word_count_weight=0.0, valid_word_count_weight=2.3,
-                       beam_width=0):
+                       beam_width=0, beam_input=None):
     """Greedy CTC decoding (speech_model.py:112-115).  The LM beam search needs the reference's
     custom tensorflow-with-kenlm fork (speech_model.py:101-111) and is not part of this path.
-    ``beam_width`` > 0 (not a reference argument) selects the LM-free prefix beam search instead."""
+    ``beam_width`` > 0 (not a reference argument) selects the LM-free prefix beam search instead (up to 128; the reference's
+    operating point is 100 with merge_repeated=False on ``beam_input='log10_softmax'``, i.e. log10(softmax + 1e-8),
+    speech_model.py:102-110 -- without its KenLM scorer)."""
     if language_model:
       raise NotImplementedError('KenLM beam-search decoding depends on a TensorFlow fork that is not vendored')
     self.beam_width = int(beam_width or 0)
+    self.beam_input = beam_input
     self.lm_weight, self.word_count_weight = lm_weight, word_count_weight
     self.valid_word_count_weight = valid_word_count_weight
     self._decoding = True
@@ -377,7 +380,7 @@ class SpeechModel:
     if decode:
       if not self._decoding:
         raise RuntimeError('add_decoding_ops() was not called')
-      ids, _ = eng.beam_search_decode(self.beam_width) if self.beam_width else eng.greedy_decode()
+      ids, _ = eng.beam_search_decode(self.beam_width, getattr(self, 'beam_input', None)) if self.beam_width else eng.greedy_decode()
       idx = [[b, p] for b, seq in enumerate(ids) for p in range(len(seq))]
       out.append([SparseTensorValue(np.array(idx, dtype=np.int64).reshape(-1, 2),
                                     np.array([v for seq in ids for v in seq], dtype=np.int64),
@@ -465,7 +468,7 @@ def create_default_model(flags, input_size: int, speech_input: BaseInputLoader) 
                            lm_weight=getattr(flags, 'lm_weight', 0.8),
                            word_count_weight=getattr(flags, 'word_count_weight', 0.0),
                            valid_word_count_weight=getattr(flags, 'valid_word_count_weight', 2.3),
-                           beam_width=getattr(flags, 'beam_width', 0))
+                           beam_width=getattr(flags, 'beam_width', 0), beam_input=getattr(flags, 'beam_input', None))
   model.finalize(log_dir=flags.log_dir, run_name=flags.run_name, run_type=flags.run_type)
   model.checkpoint_format = 'tf' if getattr(flags, 'tf_checkpoints', False) else 'npz'
   return model

@@ -308,7 +308,78 @@ def test_beam_search_rejects_bad_arguments(dev):
   eng.ctc_lens = torch.as_tensor(np.array([9, 9], dtype=np.int32)).to(dev)
   from speecht_amd._lib import SpeechtHipError
   with pytest.raises(SpeechtHipError, match='beam width'):
-    eng.beam_search_decode(65)
+    eng.beam_search_decode(129)
+  with pytest.raises(ValueError, match='input_transform'):
+    eng.beam_search_decode(16, input_transform='softmax')
+
+
+def _beam_case(dev, logits, lens):
+  T, B, C = logits.shape
+  eng = make_engine([(1, 1, 16, C, False)], dev)
+  eng.load_batch(np.zeros((B, T, 16)), [T] * B)
+  eng.X[-1].interior().copy_(torch.as_tensor(np.transpose(logits, (1, 0, 2))))
+  eng.ctc_lens = torch.as_tensor(np.asarray(lens).astype(np.int32)).to(dev)
+  return eng
+
+
+@pytest.mark.parametrize('beam,B', [(65, 2), (100, 4), (128, 3)])
+def test_wide_beam_search_matches_oracle(dev, beam, B):
+  """Beams wider than the wavefront (the reference runs beam_width=100, speech_model.py:109): two beam entries per lane, the
+  classes on a pitch of 32 and the exact W-th largest score as the selection bound (ctc_beam_kernel<64, 128>) -- identical
+  label sequences and log-probabilities within 1e-4 of the float64 oracle search, on plain logits and on the reference's
+  decoder input log10(softmax + 1e-8); the launch trace says which instantiation ran."""
+  from speecht_amd._lib import launch_trace
+  rng = np.random.default_rng(400 + beam)
+  T, C = 121, 29
+  logits = (rng.standard_normal((T, B, C)) * 2.0).astype(np.float32)
+  logits[:, 0, 28] += 3.0                                # mostly blanks
+  if B > 2:
+    logits[:, 2, :] *= 0.1
+    logits[::2, 2, 11] += 9.0; logits[1::2, 2, 28] += 9.0  # l, blank, l, blank ... -> repeated labels
+  lens = np.array([121, 97, 120, 33][:B])
+  eng = _beam_case(dev, logits, lens)
+  for transform in (None, 'log10_softmax'):
+    with launch_trace() as tr:
+      ids, logp = eng.beam_search_decode(beam, input_transform=transform)
+    assert any(l.startswith('ctc_beam<wide> beam=%d transform=%d' % (beam, 1 if transform else 0)) for l in tr.lines), tr.lines
+    ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, beam, input_transform=transform)
+    assert ids == ref_ids, transform
+    np.testing.assert_allclose(logp, ref_logp, rtol=1e-4, atol=1e-4)
+  if B > 2:
+    assert ids[2] == [11] * 60                           # repeats separated by blanks survive; merge_repeated collapses them
+    merged, _ = eng.beam_search_decode(beam, input_transform='log10_softmax', merge_repeated=True)
+    assert merged[2] == [11] and all(a != b for seq in merged for a, b in zip(seq, seq[1:]))
+
+
+def test_wide_beam_search_massive_ties_take_the_sequential_rounds(dev):
+  """All-equal logits at beam 100: thousands of candidates tie exactly, more than the 256 survivors the wave-parallel selection
+  of the wide instantiation holds -- the sequential rounds order them by candidate index; deterministic and equal to the
+  oracle's probabilities."""
+  T, B, C = 24, 2, 29
+  logits = np.zeros((T, B, C), dtype=np.float32)
+  lens = np.array([24, 9])
+  eng = _beam_case(dev, logits, lens)
+  ids1, logp1 = eng.beam_search_decode(100)
+  ids2, logp2 = eng.beam_search_decode(100)
+  assert ids1 == ids2 and np.array_equal(logp1, logp2)
+  ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, 100)
+  np.testing.assert_allclose(logp1, ref_logp, rtol=1e-5)
+  assert ids1 == ref_ids
+
+
+def test_reference_operating_point_beam_100_on_long_form(dev):
+  """The reference's decoder call without its KenLM scorer (speech_model.py:101-111): beam_width=100, merge_repeated=False,
+  input log10(softmax(logits) + 1e-8), on a 30 s utterance (T' = 1501): label sequence identical to the float64 oracle search,
+  log-probability within 1e-5 relative (scores kept relative to the best entry with a double offset)."""
+  rng = np.random.default_rng(78)
+  T, B, C = 1501, 1, 29
+  logits = (rng.standard_normal((T, B, C)) * 3.0).astype(np.float32)
+  lens = np.array([1501])
+  eng = _beam_case(dev, logits, lens)
+  ids, logp = eng.beam_search_decode(100, input_transform='log10_softmax')
+  ref_ids, ref_logp = O.ctc_beam_search_decode(logits.astype(np.float64), lens, 100, input_transform='log10_softmax')
+  assert ids == ref_ids and len(ids[0]) > 1000
+  np.testing.assert_allclose(logp, ref_logp, rtol=1e-5)
 
 
 @pytest.mark.parametrize('n,clip', [(1000, 5.0), (1 << 20, 5.0), (4099, 0.01)])

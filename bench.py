@@ -66,6 +66,8 @@ class HostFeed:
 
 def train_step(eng, feed, reducer, lr, global_batch):
   feed.next()
+  if getattr(eng, '_step_graph_on', False) and reducer is None:
+    return eng.train_step_graph(1.0 / global_batch, lr)     # the same launch sequence, replayed from a HIP graph
   eng.forward()
   eng.ctc_loss_grad(1.0 / global_batch)
   eng.backward(reducer.on_layer_done if reducer else None, reducer.hook_layers if reducer else None)
@@ -581,6 +583,7 @@ def main():
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
                   help='gradient exchange transport: the library\'s own RCCL communicator behind the C ABI (st_allreduce_buckets_f32; '
                        'default for --gpus > 1, falls back to torch.distributed if it cannot be set up) or torch.distributed')
+  ap.add_argument('--graph', action='store_true', help='replay the step from a whole-step HIP graph (engine.train_step_graph; single rank)')
   ap.add_argument('--tune', action='append', default=[], help='name=value override of a library policy (st_set_tuning; experiments only)')
   args = ap.parse_args()
   for kv in args.tune:
@@ -625,6 +628,8 @@ def main():
     print('bench.py: PARITY FAILED against the oracle on the bench inputs, no result line is printed: ' + json.dumps(parity),
           file=sys.stderr)
     sys.exit(3)
+  if args.graph:
+    eng.enable_step_graph()
   feed = HostFeed(eng, x, seq_lens, labels)
   reducer, transport_note = None, None
   if world > 1 or args.force_allreduce:

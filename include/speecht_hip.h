@@ -325,6 +325,11 @@ int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float*
                                        float clip_norm, float lr_t, float beta1, float beta2, float eps,
                                        float* stats, const float* gate, void* workspace,
                                        size_t workspace_bytes, void* stream);
+/* ... with the bias-corrected rate read from DEVICE memory when lr_t_dev is not null (lr_t is then ignored): the form a launch
+ * replayed from a HIP graph needs -- the rate changes every step, the captured arguments do not (engine.train_step_graph). */
+int st_global_norm_clip_adam_gated_dev_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
+                                           float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps, float* stats,
+                                           const float* gate, void* workspace, size_t workspace_bytes, void* stream);
 /* norm only (stats[0] = ||g||, stats[1] = clip/max(norm,clip)); used for reporting */
 int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* stats,
                        void* workspace, size_t workspace_bytes, void* stream);
@@ -390,6 +395,16 @@ int st_conv1d_nwc_bwd_filter_bf16(const st_tensor3* x, const void* x_bf16, const
                                   const void* dz_bf16, int width, int stride, int pad_left,
                                   float* dpacked, float* dbias, void* workspace,
                                   size_t workspace_bytes, void* stream);
+/* The same for STRIDE-1 layers without the reduction-major copies: both planes are staged as they lie in HBM and transposed on
+ * their way from LDS into the matrix registers (ds_read_b64_tr_b16, csrc/wgrad_tr_bf16.hip).  Preconditions beyond the entry
+ * point above: stride 1, x->t_pitch == dz->t_pitch (always true for a 'SAME' layer laid out as the header describes), and both
+ * planes READABLE AND ZERO for st_conv1d_bwd_filter_tr_bf16_slack_rows() rows behind their last row.  _ws returns 0 for a
+ * geometry the entry point does not take. */
+int st_conv1d_bwd_filter_tr_bf16_slack_rows(void);
+size_t st_conv1d_bwd_filter_tr_bf16_ws(const st_tensor3* x, const st_tensor3* dz, int width, int stride, int pad_left);
+int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, const st_tensor3* dz, const void* dz_bf16,
+                                     int width, int stride, int pad_left, float* dpacked, float* dbias, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /* ---- gradient exchange (RCCL over xGMI) ---------------------------------
  * The reference is single-replica (training.py:46); data parallelism follows from

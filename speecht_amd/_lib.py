@@ -113,6 +113,9 @@ _SIGNATURES = {
     'st_global_norm_clip_adam_gated_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                                    c_void_p]),
+    'st_global_norm_clip_adam_gated_dev_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p,
+                                                       c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                       c_void_p]),
     'st_global_norm_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_melspec_plan_bytes': (c_size_t, []),
     'st_melspec_plan_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -135,6 +138,10 @@ _SIGNATURES = {
     'st_conv1d_bwd_filter_bf16_ws': (c_size_t, [_T3P, _T3P, c_int, c_int, c_int]),
     'st_conv1d_nwc_bwd_filter_bf16': (c_int, [_T3P, c_void_p, _T3P, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_size_t, c_void_p]),
+    'st_conv1d_bwd_filter_tr_bf16_slack_rows': (c_int, []),
+    'st_conv1d_bwd_filter_tr_bf16_ws': (c_size_t, [_T3P, _T3P, c_int, c_int, c_int]),
+    'st_conv1d_nwc_bwd_filter_tr_bf16': (c_int, [_T3P, c_void_p, _T3P, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                 c_void_p, c_size_t, c_void_p]),
     'st_comm_unique_id_bytes': (c_int, []),
     'st_comm_unique_id': (c_int, [c_void_p, c_size_t]),
     'st_comm_init': (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p)]),

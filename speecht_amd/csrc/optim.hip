@@ -59,10 +59,12 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                        const float* __restrict__ partial, float clip, float lr_t,
+                                                        const float* __restrict__ partial, float clip, float lr_t_value,
                                                         float b1, float b2, float eps, float* __restrict__ stats,
-                                                        const float* __restrict__ gate) {
+                                                        const float* __restrict__ gate, const float* __restrict__ lr_t_dev) {
   __shared__ float red[4];
+  // the bias-corrected rate changes every step: a launch replayed from a graph reads it from device memory
+  const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_value;
   const float gn = sqrtf(total_sumsq(partial, red));
   const float scale = clip / fmaxf(gn, clip);
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats) { stats[0] = gn; stats[1] = scale; }
@@ -135,6 +137,13 @@ int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, fl
 int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
                                        float lr_t, float beta1, float beta2, float eps, float* stats, const float* gate,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+  return st_global_norm_clip_adam_gated_dev_f32(params, grads, m, v, n, clip_norm, lr_t, nullptr, beta1, beta2, eps, stats, gate, workspace,
+                                                workspace_bytes, stream);
+}
+
+int st_global_norm_clip_adam_gated_dev_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
+                                           float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps, float* stats,
+                                           const float* gate, void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(params && grads && m && v && workspace && workspace_bytes >= st_global_norm_ws(n), "clip_adam: bad args");
   ST_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "clip_adam: buffers must be 16-byte aligned");
@@ -143,7 +152,7 @@ int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float*
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, partial);
   const int blocks = (int)std::max<size_t>(1, std::min<size_t>((n / 4 + 255) / 256, 2048));
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, partial, clip_norm,
-                     lr_t, beta1, beta2, eps, stats, gate);
+                     lr_t, beta1, beta2, eps, stats, gate, lr_t_dev);
   return st::check_launch("clip_adam");
 }
 

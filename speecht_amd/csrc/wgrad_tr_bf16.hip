@@ -1,0 +1,324 @@
+// Filter gradient of a stride-1 layer with bf16 activations, straight from the padded NWC planes (BASELINE config 4 arithmetic):
+//
+//   dF[w * cp + c][n] = sum_q X[q + w + xoff][c] * dZ[q][n]          (speech_model.py:78, gradient of tf.nn.conv1d wrt filters)
+//
+// q runs over the FLAT rows of the gradient tensor -- utterances one behind the other, halo rows included: they are zero, and for
+// a stride-1 'SAME' layer the input and the gradient tensor have the same frame pitch (T + W - 1), so one shift per tap maps a
+// gradient row to its input row for every utterance at once.  Both operands are reduction-MAJOR in memory (a row is one value of
+// the reduction index), but v_mfma_f32_32x32x16_bf16 wants eight consecutive reduction values per lane.  Rounds 1-4 therefore made
+// reduction-minor copies first (transpose_bf16_kernel: 13 launches and 0.38 ms of pure layout work per step).
+// gfx950 has the instruction for exactly this: ds_read_b64_tr_b16 reads, per 16-lane group, sixteen 8-byte pieces and hands lane
+// i the i-th 16-bit COLUMN of the 4 x 16 matrix they form (measured with scripts/ubench/tr16_probe.hip: result j of lane i is
+// element i % 4 of the piece lane 4 j + i / 4 addressed).  With lane 4 j + p pointing at channels [4 p, 4 p + 4) of row j, lane i
+// receives rows 0..3 of channel i -- four consecutive reduction values -- so the tiles are staged as they lie in HBM (LDS-DMA,
+// 256-byte rows) and transposed on their way into the registers: two reads per 32 x 16 fragment, no copy, no extra pass.
+//
+// Tile 128 (input channels of one tap) x 128 (output channels), four waves of 64 x 64, 32 reduction rows per stage in a ring of
+// four 16 KB stages (two workgroups per CU), counted vmcnt + one barrier per stage.  LDS image of a stage: [32 rows][16 chunks of
+// 16 bytes], physical chunk = chunk ^ (4 * (row & 3)) applied on the SOURCE side of the DMA: the four rows a transposing read
+// touches land in four different quarter-rows, so the 32 lanes of a half-wave cover all 64 banks exactly once.
+// The reduction is cut into `splits` contiguous runs of stages whose fp32 slabs wgrad_tr_finish_kernel sums in a fixed order
+// together with the bias gradient (column sums of dZ, colsum_bf16_partial_kernel): deterministic, no atomics.
+//
+// Contract with the caller (st_conv1d_nwc_bwd_filter_tr_bf16): both planes are READABLE and ZERO for 40 rows behind their last
+// row (the last stage and the last taps read past the end; what they read meets zero gradient rows).
+#include <algorithm>
+
+#include "st_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int TM = 128, TN = 128, TK = 32;         // tile: input channels x output channels x reduction rows per stage
+constexpr int ST = 4;                              // LDS ring depth
+constexpr int STAGE_ELEMS = TK * 128;              // bf16 elements of one operand's stage (32 rows x 256 bytes)
+constexpr int SLACK_ROWS = 40;
+
+struct TrParams {
+  const unsigned short* X;       // bf16 plane of the layer input, flat rows of x_cp elements
+  const unsigned short* Z;       // bf16 plane of the gradient wrt the layer output, flat rows of z_cp elements
+  float* out;                    // [splits][width * x_cp][n_pad]
+  long x_row0, z_row0;           // flat rows of tap 0 / of the gradient at reduction index 0
+  long slab_stride;
+  int x_cp, z_cp, n_pad, width;
+  int stages, stages_per_split, splits;
+  int mtiles_per_tap, tiles_m, tiles_n;
+};
+
+// ds_read_b64_tr_b16 as inline assembly, OFF = immediate byte offset.  (Through __builtin_amdgcn_ds_read_tr16_b64 the compiler sees
+// an LDS read that may alias the LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of the first read of every stage -- the
+// ring then holds one stage, not three.  Here the data dependence is stated by hand: `lds_wait` takes the eight results of a
+// k-step as in/out operands, so nothing that uses them can be scheduled in front of the wait.)
+typedef unsigned long long u64;
+template <int OFF>
+__device__ __forceinline__ u64 lds_read_tr16(unsigned addr) {
+  u64 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait(u64 (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               :
+               : "memory");
+}
+__device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(bf16x8, u64x2{lo, hi});
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ST * STAGE_ELEMS];
+  unsigned short* const As = smem;                              // [ST][32][128]
+  unsigned short* const Bs = smem + ST * STAGE_ELEMS;
+
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int split = blockIdx.x / tiles;
+  const int tile = blockIdx.x - split * tiles;
+  const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;   // row tiles fastest: neighbours share the gradient panel
+  const int w = tm / p.mtiles_per_tap, c0 = (tm - w * p.mtiles_per_tap) * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int kt_begin = split * p.stages_per_split;
+  const int nk = min(p.stages_per_split, p.stages - kt_begin);
+  if (nk <= 0) return;
+
+  // DMA: wave v stages rows [8 v, 8 v + 8) of both operands, two 1 KB pieces (4 rows x 256 bytes) each; lane i of a piece writes
+  // physical chunk i & 15 of row i >> 4 and fetches source chunk (i & 15) ^ (4 * (i >> 4))
+  const int prow = lane >> 4, pchunk = (lane & 15) ^ (4 * prow);
+  const unsigned short* asrc = p.X + (p.x_row0 + w + (long)kt_begin * TK + wave * 8 + prow) * p.x_cp + c0 + pchunk * 8;
+  const unsigned short* bsrc = p.Z + (p.z_row0 + (long)kt_begin * TK + wave * 8 + prow) * p.z_cp + n0 + pchunk * 8;
+  const long a_piece = 4L * p.x_cp, b_piece = 4L * p.z_cp, a_stage = (long)TK * p.x_cp, b_stage = (long)TK * p.z_cp;
+  auto issue = [&](int kt) {
+    const int buf = kt % ST;
+    const unsigned short* a = asrc + (long)kt * a_stage;
+    const unsigned short* b = bsrc + (long)kt * b_stage;
+    unsigned short* la = As + buf * STAGE_ELEMS + wave * 8 * 128;
+    unsigned short* lb = Bs + buf * STAGE_ELEMS + wave * 8 * 128;
+    __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)la, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(a + a_piece), (lptr_t)(la + 4 * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)b, (lptr_t)lb, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(b + b_piece), (lptr_t)(lb + 4 * 128), 16, 0, 0);
+  };
+
+  // fragment addresses (bytes inside a stage): 16-lane group g = lane >> 4 reads rows 8 (g >> 1) + 4 h + (l >> 2), l = lane & 15,
+  // channels base + 16 (g & 1) + 4 (l & 3) .. + 3: chunk = base / 8 + 2 (g & 1) + ((l & 3) >> 1), half-chunk l & 1
+  const int l16 = lane & 15, g = lane >> 4;
+  const int frow = 8 * (g >> 1) + (l16 >> 2);                    // + 4 h + 16 ks
+  const int fchunk = 2 * (g & 1) + ((l16 & 3) >> 1);            // + tile base chunk
+  const int fswz = 4 * (l16 >> 2);                               // (row & 3) of the rows this lane addresses
+  unsigned a_at[2], b_at[2];                                     // LDS byte addresses inside ring slot 0
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = ((wm * 64 + i * 32) >> 3) + fchunk, cb = ((wn * 64 + i * 32) >> 3) + fchunk;
+    a_at[i] = (unsigned)(size_t)As + (unsigned)(frow * 256 + ((ca ^ fswz) << 4) + (l16 & 1) * 8);
+    b_at[i] = (unsigned)(size_t)Bs + (unsigned)(frow * 256 + ((cb ^ fswz) << 4) + (l16 & 1) * 8);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int kt = 0; kt < ST - 1 && kt < nk; ++kt) issue(kt);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of stage kt have landed when at most the younger stages' (4 instructions each) are outstanding
+    // (a bare s_barrier: __syncthreads() is a fence too and would drain every DMA in flight -- vmcnt(0) -- each stage.  The
+    // fragment reads of stage kt - 1 are complete: the MFMAs that consumed them have been issued.)
+    if (kt + ST - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (ST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + ST - 1 < nk) issue(kt + ST - 1);                    // into the slot of stage kt - 1: everyone is past reading it
+    const unsigned so = (unsigned)((kt % ST) * STAGE_ELEMS * 2);
+    const unsigned a0 = a_at[0] + so, a1 = a_at[1] + so, b0 = b_at[0] + so, b1 = b_at[1] + so;
+    // k-step 0 (rows 0..15 of the stage: reads at +0 and +4 rows), then k-step 1 (+16, +20 rows); the second k-step's reads are
+    // issued before the first one's MFMAs and return under them
+    u64 r0[8] = {lds_read_tr16<0>(a0), lds_read_tr16<1024>(a0), lds_read_tr16<0>(a1), lds_read_tr16<1024>(a1),
+                 lds_read_tr16<0>(b0), lds_read_tr16<1024>(b0), lds_read_tr16<0>(b1), lds_read_tr16<1024>(b1)};
+    lds_wait(r0);
+    u64 r1[8] = {lds_read_tr16<4096>(a0), lds_read_tr16<5120>(a0), lds_read_tr16<4096>(a1), lds_read_tr16<5120>(a1),
+                 lds_read_tr16<4096>(b0), lds_read_tr16<5120>(b0), lds_read_tr16<4096>(b1), lds_read_tr16<5120>(b1)};
+    {
+      const bf16x8 fa0 = frag_of(r0[0], r0[1]), fa1 = frag_of(r0[2], r0[3]), fb0 = frag_of(r0[4], r0[5]), fb1 = frag_of(r0[6], r0[7]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+    lds_wait(r1);
+    {
+      const bf16x8 fa0 = frag_of(r1[0], r1[1]), fa1 = frag_of(r1[2], r1[3]), fb0 = frag_of(r1[4], r1[5]), fb1 = frag_of(r1[6], r1[7]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // out[split][w * cp + c][n]: accumulator r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+  float* const out = p.out + (long)split * p.slab_stride;
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        // (columns between the gradient's channel pitch and n_pad met the NEXT row's bytes: they are padding, exactly zero)
+        if (c < p.x_cp && n < p.n_pad) out[((long)w * p.x_cp + c) * p.n_pad + n] = n < p.z_cp ? acc[i][j][r] : 0.f;
+      }
+    }
+}
+
+// column sums of a bf16 plane [rows][cp] over row chunks: part[chunk][c] (fp32), 64 columns x 16 row lanes per workgroup
+__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short* __restrict__ z, long rows, int cp, int n_pad,
+                                                                  float* __restrict__ part) {
+  __shared__ float red[16][65];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cp) {
+    for (long r = r0 + rl; r < r1; r += 16) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(z + r * cp + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];        // fixed order
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < n_pad) part[(long)blockIdx.y * n_pad + cc] = cc < cp ? t : 0.f;
+  }
+}
+
+// dpacked = sum of the slabs (fixed order); dbias = sum of the column-sum partials
+__global__ __launch_bounds__(256) void wgrad_tr_finish_kernel(const float* __restrict__ slabs, int n_slabs, size_t n4,
+                                                              float* __restrict__ dpacked, const float* __restrict__ part, int chunks,
+                                                              int n_pad, float* __restrict__ dbias) {
+  if (slabs) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+      f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
+      for (int s = 1; s < n_slabs; ++s) a += reinterpret_cast<const f32x4*>(slabs + (size_t)s * n4 * 4)[i];
+      reinterpret_cast<f32x4*>(dpacked)[i] = a;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < n_pad; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < chunks; ++k) t += part[(long)k * n_pad + c];
+      dbias[c] = t;
+    }
+  }
+}
+
+int npad_of(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)st::round_up(cout, 128)); }
+
+struct TrPlan {
+  long z_row0, x_row0, rows;
+  int stages, splits, stages_per_split, n_pad, mtiles_per_tap, tiles_m, tiles_n, chunks;
+  size_t slab_bytes, part_bytes;
+};
+
+TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_left) {
+  TrPlan t{};
+  t.n_pad = npad_of(dz.channels);
+  t.z_row0 = dz.halo;                                                     // the first real gradient row
+  t.x_row0 = (long)dz.halo + (x.halo - pad_left) - dz.halo;               // its input row for tap 0
+  t.rows = (long)(dz.batch - 1) * dz.t_pitch + dz.frames;                 // up to the last real gradient row
+  t.stages = (int)((t.rows + TK - 1) / TK);
+  t.mtiles_per_tap = st::ceil_div(x.c_pitch, TM);
+  t.tiles_m = width * t.mtiles_per_tap;
+  t.tiles_n = st::ceil_div(t.n_pad, TN);
+  const long tiles = (long)t.tiles_m * t.tiles_n;
+  // two 64 KB workgroups per CU: about one round of 512 (tile, split) pairs, at least 8 stages per split
+  const int forced = st::tuning(st::TUNE_BF16_WGRAD_SPLITS);
+  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 480;
+  int splits = forced ? forced : (int)std::max(1L, std::min<long>(target / std::max(1L, tiles), t.stages / 8));
+  splits = std::max(1, std::min(splits, t.stages));
+  t.stages_per_split = st::ceil_div(t.stages, splits);
+  t.splits = st::ceil_div(t.stages, t.stages_per_split);
+  t.slab_bytes = t.splits > 1 ? st::round_up((size_t)t.splits * width * x.c_pitch * t.n_pad * 4, 256) : 0;
+  t.chunks = 32;
+  t.part_bytes = st::round_up((size_t)t.chunks * t.n_pad * 4, 256);
+  return t;
+}
+
+bool tr_eligible(const st_tensor3* x, const st_tensor3* dz, int width, int stride, int pad_left) {
+  return x && dz && stride == 1 && width >= 1 && x->t_pitch == dz->t_pitch && x->batch == dz->batch && x->frames == dz->frames &&
+         x->halo >= pad_left && x->c_pitch % 8 == 0 && dz->c_pitch % 8 == 0 && dz->c_pitch >= dz->channels &&
+         (long)(x->halo - pad_left) + width - 1 <= (long)x->t_pitch;
+}
+
+}  // namespace
+
+extern "C" {
+
+int st_conv1d_bwd_filter_tr_bf16_slack_rows(void) { return SLACK_ROWS; }
+
+size_t st_conv1d_bwd_filter_tr_bf16_ws(const st_tensor3* x, const st_tensor3* dz, int width, int stride, int pad_left) {
+  if (!tr_eligible(x, dz, width, stride, pad_left)) return 0;
+  const TrPlan t = tr_plan(*x, *dz, width, pad_left);
+  return t.slab_bytes + t.part_bytes + 256;
+}
+
+int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, const st_tensor3* dz, const void* dz_bf16, int width,
+                                     int stride, int pad_left, float* dpacked, float* dbias, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  ST_REQUIRE(x && dz && x_bf16 && dz_bf16 && dpacked && dbias, "conv bwd-filter tr bf16: null argument");
+  ST_REQUIRE(tr_eligible(x, dz, width, stride, pad_left),
+             "conv bwd-filter tr bf16: stride-1 layers whose input and gradient tensors share one frame pitch only");
+  const TrPlan t = tr_plan(*x, *dz, width, pad_left);
+  const size_t need = t.slab_bytes + t.part_bytes + 256;
+  if (!workspace || workspace_bytes < need) {
+    st::set_error("conv bwd-filter tr bf16: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    return ST_EWORKSPACE;
+  }
+  hipStream_t s = st::as_stream(stream);
+  float* slabs = reinterpret_cast<float*>(workspace);
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + t.slab_bytes);
+  TrParams p{};
+  p.X = reinterpret_cast<const unsigned short*>(x_bf16);
+  p.Z = reinterpret_cast<const unsigned short*>(dz_bf16);
+  p.out = t.splits > 1 ? slabs : dpacked;
+  p.x_row0 = t.x_row0; p.z_row0 = t.z_row0;
+  p.slab_stride = (long)width * x->c_pitch * t.n_pad;
+  p.x_cp = x->c_pitch; p.z_cp = dz->c_pitch; p.n_pad = t.n_pad; p.width = width;
+  p.stages = t.stages; p.stages_per_split = t.stages_per_split; p.splits = t.splits;
+  p.mtiles_per_tap = t.mtiles_per_tap; p.tiles_m = t.tiles_m; p.tiles_n = t.tiles_n;
+  st::trace("wgrad_tr_bf16<128,128,32> M=%d Np=%d rows=%ld stages=%d splits=%d gflop=%.3f", width * x->c_pitch, t.n_pad, t.rows, t.stages,
+            t.splits, 2e-9 * (double)t.stages * TK * t.tiles_m * TM * t.tiles_n * TN);
+  {
+    st::LaunchTimer timer(s);
+    st::launch_timed(timer, wgrad_tr_bf16_kernel, dim3((unsigned)(t.splits * t.tiles_m * t.tiles_n)), dim3(256), s, p);
+  }
+  if (int e = st::check_launch("wgrad_tr_bf16")) return e;
+  const long z_rows = (long)dz->batch * dz->t_pitch;
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 64), t.chunks), dim3(256), 0, s, p.Z, z_rows, dz->c_pitch,
+                     t.n_pad, part);
+  const size_t n4 = (size_t)width * x->c_pitch * t.n_pad / 4;
+  hipLaunchKernelGGL(wgrad_tr_finish_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048)), dim3(256), 0, s,
+                     t.splits > 1 ? slabs : (const float*)nullptr, t.splits, n4, dpacked, part, t.chunks, t.n_pad, dbias);
+  return st::check_launch("wgrad_tr_finish");
+}
+
+}  // extern "C"

@@ -645,11 +645,18 @@ class Wav2LetterEngine:
   # ---- bf16 activations (config 4) ------------------------------------------------------------------
   def _alloc_bf16(self):
     L = len(self.layers)
-    self.Xb = [self._planes('Xb%d' % i, self.X[i].buf.numel(), 1) for i in range(L)]
-    self.dZb = [self._planes('dZb%d' % i, self.dZ[i].buf.numel(), 1) for i in range(L)]
     lib = _lib.load()
-    ws = max(lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2])
-             for i, l in enumerate(self.layers))
+    # the filter gradients of the stride-1 layers read both planes as they lie (LDS transpose reads, csrc/wgrad_tr_bf16.hip) and
+    # run up to `slack` rows past the last one: zeros behind every plane
+    slack = lib.st_conv1d_bwd_filter_tr_bf16_slack_rows()
+    self.Xb = [self._planes('Xb%d' % i, self.X[i].buf.numel(), 1, slack * self.X[i].c_pitch) for i in range(L)]
+    self.dZb = [self._planes('dZb%d' % i, self.dZ[i].buf.numel(), 1, slack * self.dZ[i].c_pitch) for i in range(L)]
+    self._wgrad_tr = [os.environ.get('ST_BF16_WGRAD_TR', '1') != '0' and
+                      lib.st_conv1d_bwd_filter_tr_bf16_ws(self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2]) > 0
+                      for i, l in enumerate(self.layers)]
+    wgrad_ws = lambda i: (lib.st_conv1d_bwd_filter_tr_bf16_ws if self._wgrad_tr[i] else lib.st_conv1d_bwd_filter_bf16_ws)(
+        self.X[i].ref, self.dZ[i].ref, self.layers[i].width, self.layers[i].stride, self.geo[i][2])
+    ws = max(wgrad_ws(i) for i in range(L))
     ws = max([ws] + [lib.st_conv1d_bwd_data_bf16_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
                      for i, l in enumerate(self.layers) if i > 0])
     ws = max([ws] + [lib.st_conv1d_fwd_bf16_ws(self.X[i].ref, self.X[i + 1].ref, l.width)
@@ -658,8 +665,7 @@ class Wav2LetterEngine:
     # the narrow layers' filter gradients run beside back-prop to the input on the side stream: their own scratch
     # (the classification layer beside its back-prop, as in fp32: measured, no gain here -- 3.15 ms either way)
     self._side_wgrad_bf16 = [i for i, l in enumerate(self.layers) if self.side_filter_gradient and i > 0 and l.cout <= 512 and l.cin <= 512]
-    ws2 = max([0] + [lib.st_conv1d_bwd_filter_bf16_ws(self.X[i].ref, self.dZ[i].ref, self.layers[i].width, self.layers[i].stride,
-                                                      self.geo[i][2]) for i in self._side_wgrad_bf16])
+    ws2 = max([0] + [wgrad_ws(i) for i in self._side_wgrad_bf16])
     self.wgrad_ws_b2 = self._storage.view('wgrad_ws_b2', ws2 // 4 + 64)[0] if ws2 else None
     self.wgrad_ws_b3 = self._storage.view('wgrad_ws_b3', ws2 // 4 + 64)[0] if ws2 else None    # second side stream
     if not hasattr(self, 'Wb'):
@@ -772,8 +778,9 @@ class Wav2LetterEngine:
 
       def filter_gradient(i=i, l=l, gf=gf, gb=gb, ws=(self.wgrad_ws_b3 if (i % 2 == 1 and self.wgrad_ws_b3 is not None)
                                                          else self.wgrad_ws_b2) if beside else self.wgrad_ws_b):
-        call('st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref, self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]),
-             l.width, l.stride, self.geo[i][2], self._ptr(gf), self._ptr(gb), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+        call('st_conv1d_nwc_bwd_filter_tr_bf16' if self._wgrad_tr[i] else 'st_conv1d_nwc_bwd_filter_bf16', self.X[i].ref,
+             self._ptr(self.Xb[i]), self.dZ[i].ref, self._ptr(self.dZb[i]), l.width, l.stride, self.geo[i][2], self._ptr(gf),
+             self._ptr(gb), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
       if beside:
         # two side streams take the chains in turn (each needs only its own layer's tensors): with all seven on one
         # stream that stream, not back-prop to the input, set the length of the backward pass of the narrow layers
@@ -819,13 +826,15 @@ class Wav2LetterEngine:
     return (self.conv_mode == 'bf16x6' and i > 0 and l.stride == 1 and l.n_pad % 128 == 0 and tiles >= 192 and
             not self._in_fft(i))
 
-  def _planes(self, name, numel, n=3):
-    """n zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used)."""
-    buf, fresh = self._storage.view(name, n * numel, torch.bfloat16)
-    v = buf[:n * numel]
+  def _planes(self, name, numel, n=3, slack=0):
+    """n zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used).  ``slack``: that many further zero
+    elements stay allocated behind the (single) plane -- readable zeros for kernels that run past the last row
+    (st_conv1d_nwc_bwd_filter_tr_bf16); the returned view does not include them."""
+    buf, fresh = self._storage.view(name, n * numel + slack, torch.bfloat16)
+    v = buf[:n * numel + slack]
     if not fresh:
       v.zero_()
-    return v
+    return v[:n * numel]
 
   def _alloc_planes(self):
     self.Xp = {i: self._planes('Xp%d' % i, self.X[i].buf.numel()) for i in range(len(self.layers)) if self._x6_fwd(i)}
@@ -886,7 +895,7 @@ class Wav2LetterEngine:
       staged.consumed.record(self._stream if self._stream is not None else torch.cuda.current_stream(self.device))
     self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
     # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
-    self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32))
+    self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32), fixed='ctc_lens')
 
   def stage_host_batch(self, x_host):
     """Asynchronous H2D copy of a padded feature batch [B, T, C] (float32; a pinned torch tensor copies without
@@ -931,10 +940,13 @@ class Wav2LetterEngine:
       staged.taken = True
       staged.consumed.record(self._h2d['stream'])      # "consumed" right behind the copy on the copy stream
 
-  def _upload_i32(self, values):
+  def _upload_i32(self, values, fixed=None):
     """Small int32 host array -> device through a ring of pinned slots.  A hipMemcpyAsync from pageable memory
     only returns once the stream's earlier kernels have finished, which would stall the thread that enqueues
-    the next batch behind the previous batch's forward; from pinned memory the copy is a stream operation."""
+    the next batch behind the previous batch's forward; from pinned memory the copy is a stream operation.
+    ``fixed``: with whole-step graphs on (`enable_step_graph`) the array goes to a persistent device buffer of that name --
+    one per step parity, so that the upload of step k + 1 does not wait for step k's kernels -- whose address a captured
+    launch can hold."""
     if not hasattr(self, '_pin_ring'):
       self._pin_ring, self._pin_turn = [[None, None] for _ in range(8)], 0
     slot = self._pin_ring[self._pin_turn % len(self._pin_ring)]
@@ -951,7 +963,20 @@ class Wav2LetterEngine:
     if not hasattr(self, '_up_stream'):
       self._up_stream, self._uploads = role_stream(self.device, 'upload'), []
     with torch.cuda.stream(self._up_stream):
-      dev = torch.empty(n, dtype=torch.int32, device=self.device)
+      if fixed is not None and getattr(self, '_step_graph_on', False):
+        par = self._step_parity
+        dev = self._storage.view('%s_par%d' % (fixed, par), _round_up(max(n, 1), 4096), torch.int32)[0][:n]
+        if fixed in self._parity_written[par]:
+          # written before and not consumed by a graph step since (eager passes in between: evaluation, a decode): whatever is
+          # enqueued on the compute stream so far may still read the buffer
+          busy = torch.cuda.Event()
+          busy.record(main)
+          self._up_stream.wait_event(busy)
+        elif self._parity_consumed[par] is not None:
+          self._up_stream.wait_event(self._parity_consumed[par])      # the step that last read this parity's buffers is through
+        self._parity_written[par].add(fixed)
+      else:
+        dev = torch.empty(n, dtype=torch.int32, device=self.device)
       dev.copy_(slot[0][:n], non_blocking=True)
       if slot[1] is None:
         slot[1] = torch.cuda.Event()
@@ -1079,8 +1104,8 @@ class Wav2LetterEngine:
       offs[1:] = np.cumsum(lens)
       self.max_label_len = int(max(lens + [0]))
       ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
-    self.label_ids = self._upload_i32(ids)
-    self.label_offs = self._upload_i32(offs)
+    self.label_ids = self._upload_i32(ids, fixed='label_ids')
+    self.label_offs = self._upload_i32(offs, fixed='label_offs')
 
   def _on_side_stream(self, fn, second=False):
     """Run ``fn`` (which enqueues kernels through ``self.stream_ptr``) on the engine's side stream (``second``: on a
@@ -1339,11 +1364,23 @@ class Wav2LetterEngine:
     if top_pending is not None and hook is not None:
       hook(top_pending)
 
-  def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
-    """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""
+  def _adam_rate(self, lr, beta1, beta2):
+    """The bias-corrected rate of the NEXT update (tf.train.AdamOptimizer: lr * sqrt(1 - beta2^t) / (1 - beta1^t)); counts it."""
     self.step_count += 1
     t = self.step_count
-    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+  def _refresh_after_update(self):
+    """The operands the NEXT forward pass derives from the weights: filter spectra of the frequency-domain layers / the bf16 filter
+    copies -- the bottom layer's on the compute stream, the others on the side stream with an event each."""
+    if self.fft:
+      self._refresh_gfwd()
+    elif self.conv_mode == 'bf16' and hasattr(self, 'Wb'):
+      self._refresh_wb_after_update()
+
+  def apply_update(self, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
+    """clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-3) (speech_model.py:77-82)."""
+    lr_t = self._adam_rate(lr, beta1, beta2)
     # gated on the device: a step whose batch CTC rejected (on any rank) leaves params / m / v untouched
     call('st_global_norm_clip_adam_gated_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
          self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), float(lr_t), beta1, beta2, eps,
@@ -1351,10 +1388,107 @@ class Wav2LetterEngine:
          self.stream_ptr)
     self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
     self.mark_weights_changed()
-    if self.fft:
-      self._refresh_gfwd()          # the forward filter spectra of the frequency-domain layers for the next pass
-    elif self.conv_mode == 'bf16' and hasattr(self, 'Wb'):
-      self._refresh_wb_after_update()              # the bf16 copies the next forward pass reads
+    self._refresh_after_update()
+
+  # ---- the whole training step from a HIP graph ------------------------------------------------------------------
+  def enable_step_graph(self, on=True):
+    """From the next `load_batch` on, lengths and labels are uploaded into persistent per-parity device buffers so that
+    `train_step_graph` can replay captured launches that hold their addresses."""
+    self._step_graph_on = bool(on)
+    if not hasattr(self, '_step_parity'):
+      self._step_parity, self._parity_consumed, self._parity_written = 0, [None, None], [set(), set()]
+      self._step_graphs, self._step_graph_seen = {}, set()
+      self._rate_host = torch.zeros(16, dtype=torch.float32, pin_memory=True)
+      self._rate_turn = 0
+
+  def _step_body(self, grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev):
+    """The launch sequence of one training step in the order a captured graph holds it: the operands derived from the weights
+    FIRST (what `apply_update` does at its end for the next step: inside a graph nothing may outlive the capture, and at the
+    head of the step the rebuild still overlaps the first layers), forward, CTC, backward, clip + Adam with the rate read from
+    device memory; every side stream joined at the end."""
+    self.mark_weights_changed()
+    self._refresh_after_update()
+    self.forward()
+    self.ctc_loss_grad(grad_scale)
+    self.backward()
+    call('st_global_norm_clip_adam_gated_dev_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
+         self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), 0.0, self._ptr(rate_dev), beta1, beta2, eps,
+         self._ptr(self.stats), self._ptr(self.gate), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
+    self._join_side_stream()
+    for name in ('_gfwd_ready', '_wb_ready', '_bwd_ready'):      # events of this sequence: consumed inside it
+      d = getattr(self, name, None)
+      if d:
+        d.clear()
+
+  def train_step_graph(self, grad_scale, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
+    """forward + ctc_loss_grad + backward + apply_update of the batch `load_batch` / `set_labels` staged, as ONE graph launch.
+
+    The step's ~100 kernel launches and ~40 cross-stream events are captured once per (shape, label-length class, parity) -- the
+    second time a key shows up; the first time runs the same sequence eagerly -- and replayed afterwards: the launch sequence,
+    its side-stream forks and joins included, is identical, so the result is bit-identical to the eager step
+    (tests/test_gpu_api.py).  What changes from step to step lives in device memory the captured launches point at: the input
+    batch (X[0]), lengths and labels (per-parity buffers, `enable_step_graph`), the Adam rate (a device scalar per parity,
+    uploaded with them).  Single-process training only: the data-parallel exchange stays on the eager path."""
+    if not getattr(self, '_step_graph_on', False):
+      raise RuntimeError('train_step_graph: call enable_step_graph() before load_batch / set_labels')
+    lib = _lib.load()
+    B, T = self.X[-1].batch, self.X[-1].frames
+    kpl_len = next((k * 32 - 1 for k in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16) if k * 64 >= 2 * self.max_label_len + 1), None)
+    if kpl_len is None:
+      raise ValueError('label of length {} is too long for the CTC kernel (max 511)'.format(self.max_label_len))
+    par = self._step_parity
+    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    # the rate of this update: pinned slot -> this parity's device scalar, with the step's other uploads
+    lr_t = self._adam_rate(lr, beta1, beta2)
+    self._rate_turn = (self._rate_turn + 1) % 16
+    self._rate_host[self._rate_turn] = lr_t
+    rate_dev = self._storage.view('adam_rate_par%d' % par, 4)[0]
+    with torch.cuda.stream(self._up_stream):
+      if self._parity_consumed[par] is not None:
+        self._up_stream.wait_event(self._parity_consumed[par])
+      rate_dev[:1].copy_(self._rate_host[self._rate_turn:self._rate_turn + 1], non_blocking=True)
+      ev = torch.cuda.Event()
+      ev.record(self._up_stream)
+      self._uploads.append(ev)
+    need = lib.st_ctc_ws(B, T, kpl_len)
+    if self.ctc_ws is None or self.ctc_ws.numel() * 4 < need:
+      self.ctc_ws = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
+    key = (self._shape, self._storage.generation, kpl_len, par, float(grad_scale), float(max_grad_norm), beta1, beta2, eps,
+           self.fft_conv, self.ctc_ws.data_ptr())
+    # everything enqueued outside the graph that it depends on: uploads, side-stream work of an eager step before this one
+    self._wait_uploads()
+    self._join_side_stream()
+    saved_len, self.max_label_len = self.max_label_len, kpl_len      # (the CTC launch depends on the length class only)
+    try:
+      graph = self._step_graphs.get(key)
+      if getattr(self, '_rejected_labels', None):
+        graph = None                                                  # (deferred label errors: the eager sequence marks them)
+        self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
+      elif graph is None and key not in self._step_graph_seen:
+        self._step_graph_seen = {k for k in self._step_graph_seen if k[1] == self._storage.generation} | {key}
+        self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
+      else:
+        if graph is None:
+          self._step_graphs = {k: g for k, g in self._step_graphs.items() if k[1] == self._storage.generation}
+          torch.cuda.synchronize(self.device)
+          graph = torch.cuda.CUDAGraph()
+          own_stream, self._stream = self._stream, None
+          try:
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+              self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
+          finally:
+            self._stream = own_stream
+          self._step_graphs[key] = graph
+        graph.replay()
+    finally:
+      self.max_label_len = saved_len
+    self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
+    self.mark_weights_changed()                  # an eager pass after this one rebuilds its operands itself
+    done = torch.cuda.Event()
+    done.record(main)
+    self._parity_consumed[par] = done
+    self._parity_written[par].clear()
+    self._step_parity = par ^ 1
 
   def greedy_decode(self, merge_repeated=True):
     """tf.nn.ctc_greedy_decoder (speech_model.py:113-115) -> (list of id lists, neg_sum_logits [B,1])."""

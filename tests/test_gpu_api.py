@@ -248,6 +248,69 @@ def test_forward_graph_replays_bit_exactly(dev, mode):
   assert torch.equal(eng.logits_time_major(), eager)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16x6'])
+def test_whole_step_graph_replay_is_bit_identical_to_the_eager_step(dev, mode):
+  """engine.train_step_graph: forward + CTC + backward + clip / Adam of a step as ONE captured HIP graph.  Two
+  engines from the same weights walk the same six steps over two alternating batches (same shape, different features, lengths and
+  labels -- one label set long enough to change the CTC kernel's states-per-lane class, i.e. a second graph key): one through the
+  eager sequence, one through train_step_graph (first sight of a key runs eagerly, the second captures, later ones replay; both
+  parities).  Weights, Adam moments and per-utterance losses must be bit-identical after every step; an eager step after the
+  graph steps continues bit-identically too (derived operands are rebuilt)."""
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(16, width=128, fc=256)
+  params = WL.xavier_params(layers, seed=5, bias_range=0.05)
+  batches = []
+  for k, frames in enumerate(([200, 161, 200, 133], [97, 200, 200, 180])):
+    x, seq, labels = WL.make_batch(frames, 16, seed=10 + k)
+    batches.append((x, seq, labels))
+  long_labels = [list(np.random.default_rng(3).integers(0, 28, 40)) for _ in range(4)]      # 2 * 40 + 1 > 64: another class
+  batches.append((batches[0][0], batches[0][1], long_labels))
+
+  def make():
+    e = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
+    e.fft_min_rows = e.fft_min_rows_narrow = 1               # every layer that can takes the frequency-domain path
+    e.set_weights(params)
+    return e
+
+  eager, graph = make(), make()
+  graph.enable_step_graph()
+  order = [0, 1, 0, 1, 0, 1, 2, 2, 2, 0, 1]
+  for step, k in enumerate(order):
+    x, seq, labels = batches[k]
+    for e in (eager, graph):
+      e.load_batch(x, seq)
+      e.set_labels(labels)
+    eager.forward()
+    eager.ctc_loss_grad(0.25)
+    eager.backward()
+    eager.apply_update(1e-3)
+    graph.train_step_graph(0.25, 1e-3)
+    la, lb = eager.fetch_losses(precise=True), graph.fetch_losses(precise=True)
+    assert np.array_equal(la, lb), (step, la, lb)
+    assert torch.equal(eager.params, graph.params) and torch.equal(eager.adam_m, graph.adam_m) and \
+        torch.equal(eager.adam_v, graph.adam_v), step
+    assert eager.step_count == graph.step_count == step + 1
+  assert len(graph._step_graphs) >= 3                        # both parities of the short-label class, and the long-label class
+  if mode == 'fp32':
+    assert len(graph.fft) == 9
+  # an eager step on the graph engine afterwards (evaluation, a caller that mixes the two): still in lock-step
+  x, seq, labels = batches[1]
+  for e in (eager, graph):
+    e.load_batch(x, seq)
+    e.set_labels(labels)
+    e.forward()
+    e.ctc_loss_grad(0.25)
+    e.backward()
+    e.apply_update(1e-3)
+  torch.cuda.synchronize()
+  assert torch.equal(eager.params, graph.params)
+  graph.load_batch(*batches[0][:2]); graph.set_labels(batches[0][2]); graph.train_step_graph(0.25, 1e-3)
+  eager.load_batch(*batches[0][:2]); eager.set_labels(batches[0][2])
+  eager.forward(); eager.ctc_loss_grad(0.25); eager.backward(); eager.apply_update(1e-3)
+  torch.cuda.synchronize()
+  assert torch.equal(eager.params, graph.params)
+
+
 DP_GPU_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist

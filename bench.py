@@ -116,7 +116,10 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
   import ctypes
   from speecht_amd._lib import call, launch_trace
   if eng.conv_mode == 'bf16':
-    return measure_dominant_kernel_bf16(eng, batch, conv_flops(eng, batch), 10), None
+    block = roofline_bf16_in_step(eng, step_fn, step_ms)
+    if block is not None:
+      block['isolated_forward_wide_layers'] = measure_dominant_kernel_bf16(eng, batch, conv_flops(eng, batch), 10)
+    return block, None
   flops = conv_flops(eng, batch)
   s, P = eng.stream_ptr, eng._ptr
   ws, wsb = P(eng.wgrad_ws), eng.wgrad_ws.numel() * 4
@@ -318,6 +321,210 @@ def measure_dominant_kernel_bf16(eng, batch, flops, reps):
               achieved=round(achieved, 1), peak=2500.0, unit='TFLOP/s', frac=round(achieved / 2500.0, 4), traffic=None,
               avg_launch_ms=round(ms / len(wide), 4), launches_per_step=len(wide),
               algorithmic_gflop_per_launch=round(fl / len(wide) / 1e9, 2))
+
+
+def roofline_bf16_in_step(eng, step_fn, ms_per_step, steps=4):
+  """`roofline` block of the bf16-activation step (configs[3] arithmetic), measured INSIDE real steps: every launch of the bf16
+  matrix kernels (W-tap / per-bin GEMMs `gemm_nn_bf16<..>`, transposing-read filter gradients `wgrad_tr_bf16<..>`) carries
+  start / stop events from its own dispatch (the library's timed launch trace), grouped by kernel symbol; the symbol with the
+  largest share of the step is the block, the others go to `by_kernel`.  FLOPs are the EXECUTED ones of each launch (its trace
+  line: tile padding included), so `achieved` is a hardware rate against the dense bf16 MFMA peak (2.5 PFLOP/s nominal; the
+  board sustains ~1.8 on random operands).  The HBM view beside it: algorithmic bytes of the step (SURVEY 8(d) with
+  2-byte activations) over the step time against 8 TB/s, and -- when profiles/traffic_bf16.json was collected for these sources
+  -- the fabric bytes the TCC counters saw."""
+  from speecht_amd._lib import launch_trace
+  from speecht_amd.build import source_digest
+  torch.cuda.synchronize()
+  with launch_trace(timed=True, only='bf16<') as tr:
+    for _ in range(steps):
+      step_fn()
+    torch.cuda.synchronize()
+  groups = {}
+  for line in tr.lines:
+    ms, gf = trace_field(line, 'ms'), trace_field(line, 'gflop')
+    if ms is None or ms < 0 or gf is None:
+      continue
+    g = groups.setdefault(line.split()[0], dict(ms=0.0, gflop=0.0, n=0))
+    g['ms'] += ms; g['gflop'] += gf; g['n'] += 1
+  if not groups:
+    return None
+  def block(sym):
+    g = groups[sym]
+    ach = g['gflop'] / g['ms']                       # GFLOP / ms = TFLOP/s
+    return dict(kernel=sym, launches_per_step=round(g['n'] / steps, 2), avg_launch_ms=round(g['ms'] / g['n'], 4),
+                ms_per_step=round(g['ms'] / steps, 4), executed_gflop_per_launch=round(g['gflop'] / g['n'], 3),
+                achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4))
+  dom = max(groups, key=lambda k: groups[k]['ms'])
+  out = dict(bound='mfma', **block(dom))
+  out['by_kernel'] = [block(k) for k in sorted(groups, key=lambda k: -groups[k]['ms']) if k != dom]
+  total_ms = sum(g['ms'] for g in groups.values()) / steps
+  total_gf = sum(g['gflop'] for g in groups.values()) / steps
+  out['matrix_launches'] = dict(ms_per_step=round(total_ms, 3), executed_gflop_per_step=round(total_gf, 1),
+                                achieved=round(total_gf / total_ms, 1), frac=round(total_gf / total_ms / 2500.0, 4),
+                                note='summed launch times of all traced bf16 matrix launches; launches on different streams overlap')
+  out['step_executed_gflop_traced'] = round(total_gf, 1)
+  out['step_hw_frac'] = round(total_gf / ms_per_step / 2500.0, 4)
+  # HBM side: activations (X 1..10, dZ 0..10) at 2 bytes, weights / gradients / Adam state at 4 (SURVEY 8(d): 3 392.6 MB in fp32,
+  # of which activations 1 757 MB)
+  B = eng.X[0].batch
+  act = sum(2.0 * B * t_out * l.cout for l, (_, t_out, _, _) in zip(eng.layers, eng.geo))       # one write of every layer output
+  alg_bytes = 4.0 * B * eng.geo[0][0] * eng.layers[0].cin + 3.0 * act + 2.0 * act + 4.0 * 8 * eng.n_flat
+  out['hbm'] = dict(algorithmic_bytes_per_step=round(alg_bytes), achieved_gbs=round(alg_bytes / ms_per_step / 1e6, 1), peak_gbs=PEAK_HBM_GBS,
+                    frac=round(alg_bytes / ms_per_step / 1e6 / PEAK_HBM_GBS, 4),
+                    note='algorithmic bytes: fp32 input, every activation written once and read by forward, back-prop mask and filter '
+                         'gradient (2 bytes), every activation gradient written once and read twice, weights / gradient / Adam moments '
+                         '(4 bytes: read p g m v, write p m v, norm pass); over the step time, against 8 TB/s')
+  path = os.path.join(ROOT, 'profiles', 'traffic_bf16.json')
+  out['traffic'] = None
+  if os.path.exists(path):
+    data = json.load(open(path))
+    if data.get('source_digest') == source_digest():
+      out['traffic'] = data.get('step_bytes')
+      out['traffic_over_algorithmic'] = round(data['step_bytes'] / alg_bytes, 2) if data.get('step_bytes') else None
+      out['traffic_gbs'] = round(data['step_bytes'] / ms_per_step / 1e6, 1) if data.get('step_bytes') else None
+      out['traffic_source'] = 'profiles/traffic_bf16.json: FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps-only --conv-mode bf16`, fabric bytes of one step'
+    else:
+      out['traffic_stale'] = 'profiles/traffic_bf16.json was collected for other sources (%s)' % str(data.get('source_digest'))[:12]
+  return out
+
+
+def comm_model(eng, feed, lr, global_batch, step_ms, world=8, reps=5):
+  """MODEL, not a measurement (every test box has one GPU): when, inside the backward pass, each of the four
+  gradient buckets is complete (events recorded where the data-parallel hook would hand the bucket to RCCL: engine.backward with
+  the bucket-boundary hooks, side streams joined as in a real exchange), and what an 8-rank all-reduce of that bucket would add
+  to the step for an ASSUMED bus bandwidth: buckets go out in order on one collective stream, a ring / tree moves
+  2 (N - 1) / N x bytes at `busbw`, the transfer that is not over when back-prop ends is exposed.  Nothing is claimed about the
+  slowdown the transfers cause the kernels they run beside."""
+  from speecht_amd.data_parallel import default_buckets
+  ranges = eng.reduce_ranges
+  buckets = default_buckets([e - s for s, e in ranges], ranges)
+  hook_layers = {lo for lo, _, _ in buckets}
+  samples = []
+  for _ in range(reps):
+    ready = {}
+    def hook(i):
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+      ready[i] = ev
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    feed.next()
+    eng.forward()
+    eng.ctc_loss_grad(1.0 / global_batch)
+    e0.record()
+    eng.backward(hook, hook_layers)
+    e1.record()
+    eng.apply_update(lr)
+    torch.cuda.synchronize()
+    samples.append((e0.elapsed_time(e1), {i: e0.elapsed_time(ev) for i, ev in ready.items()}))
+  bwd_ms = float(np.median([s[0] for s in samples]))
+  per_bucket = []
+  for lo, s, e in buckets:
+    t = float(np.median([smp[1][lo] for smp in samples]))
+    per_bucket.append(dict(first_layer=lo, mb=round((e - s) * 4 / 1e6, 2), ready_ms_after_backward_starts=round(t, 3),
+                           ms_of_backward_left=round(bwd_ms - t, 3)))
+  model = {}
+  for busbw in (100.0, 200.0, 300.0):
+    clock = 0.0
+    for b in per_bucket:
+      clock = max(clock, b['ready_ms_after_backward_starts']) + 2.0 * (world - 1) / world * b['mb'] / busbw     # MB / (GB/s) = ms
+    exposed = max(0.0, clock - bwd_ms)
+    model['busbw_%d_GBs' % int(busbw)] = dict(exposed_ms=round(exposed, 3), step_ms=round(step_ms + exposed, 3),
+                                             utterances_per_s_8gpu=round(world * global_batch / (step_ms + exposed) * 1e3, 1),
+                                             scaling_vs_8x=round(step_ms / (step_ms + exposed), 4))
+  return dict(kind='MODEL from single-GPU event times, not a measurement', world_assumed=world, backward_ms=round(bwd_ms, 3),
+              buckets=per_bucket, assumed=model,
+              note='exposed = what the in-order all-reduces of the four buckets (2 (N - 1) / N x bytes / busbw each, started when the bucket '
+                   'is ready) still have to do when back-prop ends; the measured compute step is `step_ms` of this mode.  xGMI: 7 links x '
+                   '~153 GB/s per GPU; RCCL on 8 MI300-class GPUs reaches 200-300 GB/s bus bandwidth on large messages, less on 7-16 MB ones')
+
+
+def config2_rate(dev, layers, budget_s=0.6):
+  """BASELINE configs[2] in the line: inference only, 256 utterances of 2-15 s (seeded), batch 64, bucketed by length and pipelined
+  (inference.transcribe: host padding, H2D of every batch and read-back of the transcripts included), greedy decode; the shortest
+  utterance's logits and greedy ids are checked against the float64 oracle."""
+  from oracle import w2l_oracle as O          # checker only
+  from speecht_amd import inference
+  rng = np.random.default_rng(3)
+  samples = rng.integers(32000, 240001, 256)
+  frames = 1 + samples // 160
+  feats = [rng.standard_normal((int(t), 80)).astype(np.float32) for t in frames]
+  params = WL.xavier_params(layers, seed=42, bias_range=0.05, dtype=np.float32)
+  eng = Wav2LetterEngine(layers, device=dev)
+  eng.set_weights(params)
+  ids, _ = inference.transcribe(eng, feats, 64, True, True)                    # warm-up
+  torch.cuda.synchronize()
+  t0, passes = time.perf_counter(), 0
+  while time.perf_counter() - t0 < budget_s:
+    ids, _ = inference.transcribe(eng, feats, 64, True, True)
+    passes += 1
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  # oracle check on the shortest utterance, alone in its batch (same batch composition on both sides)
+  k = int(np.argmin(frames))
+  one = feats[k]
+  eng.load_batch(one[None], [one.shape[0]])
+  eng.forward()
+  dec, _ = eng.greedy_decode()
+  torch.cuda.synchronize()
+  p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
+  ref = O.wav2letter_forward(one[None].astype(np.float64), p64, layers)
+  ref_dec, _ = O.ctc_greedy_decode(ref, np.array([one.shape[0] // 2]))
+  err = float(np.max(np.abs(eng.logits_time_major().cpu().numpy() - ref)))
+  buckets = inference.make_buckets(frames, 64)
+  del eng
+  torch.cuda.empty_cache()
+  return dict(workload='configs[2]: inference, 256 utterances of 2-15 s (seeded), batch 64, length-bucketed + pipelined, greedy decode',
+              utterances_per_s=round(passes * len(feats) / dt, 1), passes=passes, seconds=round(dt, 3),
+              padding_overhead=round(inference.padding_overhead(frames, buckets), 4),
+              audio_seconds_per_s=round(passes * float(samples.sum()) / 16000.0 / dt, 0),
+              oracle_check=dict(utterance_frames=int(one.shape[0]), max_logit_err=err, greedy_ids_equal=bool(dec == ref_dec),
+                                passed=bool(err < 1e-4 and dec == ref_dec)))
+
+
+def config4_rate(dev, layers, batches=12, beam=16):
+  """BASELINE configs[4] on one GPU's shard in the line: 16 utterances of 30 s (T' = 1501) resident, forward pass + LM-free prefix
+  beam search (beam 16), the search of batch k on CU-masked decoder streams under the forward passes of the next batches
+  (engine.beam_search_decode_async); the beam ids of utterance 0 are checked against the oracle search on the device's own logits."""
+  from oracle import w2l_oracle as O          # checker only
+  from speecht_amd import engine as E
+  frames = 3001
+  params = WL.xavier_params(layers, seed=42, bias_range=0.05, dtype=np.float32)
+  eng = Wav2LetterEngine(layers, device=dev)
+  eng.set_weights(params)
+  x, seq_lens, _ = WL.make_batch([frames] * 16, 80, seed=7)
+  eng.load_batch(x, seq_lens)
+  eng.forward()
+  std = float(eng.X[-1].interior().std())        # a random-init network's rows are nearly flat: scale the output layer to std 3
+  w = eng.get_weights()
+  w[-1] = (w[-1][0] * (3.0 / max(std, 1e-6)), w[-1][1] * (3.0 / max(std, 1e-6)))
+  eng.set_weights(w)
+  eng.load_batch(x, seq_lens)
+  cs, ds = E.decoder_streams(dev, 2)
+  def run(n):
+    pending, last = [], None
+    for _ in range(n):
+      with torch.cuda.stream(cs):
+        eng.forward()
+        pending.append(eng.beam_search_decode_async(beam, ds))
+      if len(pending) > 2:
+        last = pending.pop(0).result()
+    for h in pending:
+      last = h.result()
+    return last
+  run(3)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  got, _ = run(batches)
+  dt = time.perf_counter() - t0
+  torch.cuda.synchronize()
+  logits = eng.logits_time_major()[:, :1, :].cpu().numpy().astype(np.float64)
+  ref_ids, _ = O.ctc_beam_search_decode(logits, np.array([frames // 2]), beam)
+  del eng
+  torch.cuda.empty_cache()
+  return dict(workload="configs[4] shard: 16 x 30 s resident (T' = 1501), forward + prefix beam search (beam %d), searches overlapped "
+                       'with the next forward passes on CU-masked decoder streams' % beam,
+              utterances_per_s=round(batches * 16 / dt, 1), ms_per_batch=round(dt / batches * 1e3, 3), batches=batches,
+              oracle_check=dict(utterance=0, decoded_len=len(got[0]), beam_ids_equal=bool(got[0] == ref_ids[0]), passed=bool(got[0] == ref_ids[0])))
 
 
 def measure_mel(dev, batch, seconds, n_mels, reps=5):
@@ -802,6 +1009,8 @@ def main():
     # alt_timing_probe.py: bf16 2.66 -> 2.86 ms, bf16x6 6.46 -> 7.11 ms when timed after those passes).
     if world == 1 and reducer is None and eng.conv_mode == 'fp32':
       out['comm_probe_world1'] = comm_probe_world1(eng, feed, lr, global_batch, args.steps, ahead)
+    if world == 1 and reducer is None and not args.no_alt:
+      out['comm_model_8gpu'] = comm_model(eng, feed, lr, global_batch, ms)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
       # Side measurements on the same box and inputs, NOT the headline:
       #  * bf16x6 (experimental): fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on the bf16
@@ -838,6 +1047,10 @@ def main():
         out[key] = {'value': round(args.batch / alt_ms * 1e3, 2), 'unit': 'utterances/s', 'ms_per_step': round(alt_ms, 3),
                     'step_tflops_algorithmic': round(step_gflop / alt_ms, 2),
                     'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
+        if mode == 'bf16':
+          # the comm model first (plain events), the roofline pass last: its timed launches switch the queues to profiling mode
+          out[key]['comm_model_8gpu'] = comm_model(alt, alt_feed, lr, global_batch, alt_ms)
+          out[key]['roofline'] = roofline_bf16_in_step(alt, lambda: train_step(alt, alt_feed, None, lr, global_batch), alt_ms)
         del alt
         torch.cuda.empty_cache()
     # (rank 0 alone runs these profiled steps: without the exchange when there are other ranks)
@@ -849,6 +1062,10 @@ def main():
       attach_pmc_profiles(out['roofline'])
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
+    if world == 1 and not args.no_alt and args.mels == 80:
+      # the other single-GPU configurations of BASELINE.json, a few seconds each, each with an oracle check of its own
+      out['configs2_inference'] = config2_rate(dev, layers)
+      out['configs4_decode'] = config4_rate(dev, layers)
     if world == 1 and not args.no_cpu_baseline:
       # two CPU restatements of the reference path on this box's host cores; the faster one is `cpu_baseline`
       out['cpu_baseline'] = cpu_baseline_torch(args.mels, frames, args.batch)

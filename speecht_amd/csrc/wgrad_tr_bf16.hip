@@ -183,50 +183,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
     }
 }
 
-// column sums of a bf16 plane [rows][cp] over row chunks: part[chunk][c] (fp32), 64 columns x 16 row lanes per workgroup
+// column sums of a bf16 plane [rows][cp] over row chunks: part[chunk][c] (fp32).  A workgroup covers 256 columns -- 32 threads x 8
+// columns = one 512-byte piece of a row -- with 8 row lanes, four rows in flight per lane
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short* __restrict__ z, long rows, int cp, int n_pad,
                                                                   float* __restrict__ part) {
-  __shared__ float red[16][65];
-  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 64 + cq * 4;
+  __shared__ float red[8][257];
+  const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + cq * 8;
   const long per = (rows + gridDim.y - 1) / gridDim.y;
   const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < cp) {
-    for (long r = r0 + rl; r < r1; r += 16) {
-      const bf16x4 v = *reinterpret_cast<const bf16x4*>(z + r * cp + c);
+    long r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {
+      bf16x8 v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += (float)v[e];
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const bf16x8*>(z + (r + 8 * k) * cp + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[k][e];
+    }
+    for (; r < r1; r += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(z + r * cp + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
+  for (int e = 0; e < 8; ++e) red[rl][cq * 8 + e] = s[e];
   __syncthreads();
-  if (threadIdx.x < 64) {
-    float t = 0.f;
+  float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];        // fixed order
-    const int cc = blockIdx.x * 64 + threadIdx.x;
-    if (cc < n_pad) part[(long)blockIdx.y * n_pad + cc] = cc < cp ? t : 0.f;
-  }
+  for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];          // fixed order
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < n_pad) part[(long)blockIdx.y * n_pad + cc] = cc < cp ? t : 0.f;
 }
 
-// dpacked = sum of the slabs (fixed order); dbias = sum of the column-sum partials
+// dpacked = sum of the slabs (fixed order); dbias = sum of the column-sum partials (the first ceil(n_pad / 256) workgroups)
 __global__ __launch_bounds__(256) void wgrad_tr_finish_kernel(const float* __restrict__ slabs, int n_slabs, size_t n4,
                                                               float* __restrict__ dpacked, const float* __restrict__ part, int chunks,
                                                               int n_pad, float* __restrict__ dbias) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < n_pad) {
+    float t = 0.f;
+    for (int k = 0; k < chunks; ++k) t += part[(long)k * n_pad + c];
+    dbias[c] = t;
+  }
   if (slabs) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
       f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
       for (int s = 1; s < n_slabs; ++s) a += reinterpret_cast<const f32x4*>(slabs + (size_t)s * n4 * 4)[i];
       reinterpret_cast<f32x4*>(dpacked)[i] = a;
-    }
-  }
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < n_pad; c += 256) {
-      float t = 0.f;
-      for (int k = 0; k < chunks; ++k) t += part[(long)k * n_pad + c];
-      dbias[c] = t;
     }
   }
 }
@@ -250,15 +258,16 @@ TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_lef
   t.tiles_m = width * t.mtiles_per_tap;
   t.tiles_n = st::ceil_div(t.n_pad, TN);
   const long tiles = (long)t.tiles_m * t.tiles_n;
-  // two 64 KB workgroups per CU: about one round of 512 (tile, split) pairs, at least 8 stages per split
+  // two 64 KB workgroups per CU: one round of 512 (tile, split) pairs (the 2000 x 2000 layer: 256 tiles in two halves -- alone on
+  // its CU a workgroup is latency-bound, 0.32 us per stage for 0.11 us of MFMAs), at least 8 stages per split
   const int forced = st::tuning(st::TUNE_BF16_WGRAD_SPLITS);
-  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 480;
+  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 512;
   int splits = forced ? forced : (int)std::max(1L, std::min<long>(target / std::max(1L, tiles), t.stages / 8));
   splits = std::max(1, std::min(splits, t.stages));
   t.stages_per_split = st::ceil_div(t.stages, splits);
   t.splits = st::ceil_div(t.stages, t.stages_per_split);
   t.slab_bytes = t.splits > 1 ? st::round_up((size_t)t.splits * width * x.c_pitch * t.n_pad * 4, 256) : 0;
-  t.chunks = 32;
+  t.chunks = 64;
   t.part_bytes = st::round_up((size_t)t.chunks * t.n_pad * 4, 256);
   return t;
 }
@@ -313,10 +322,12 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
   }
   if (int e = st::check_launch("wgrad_tr_bf16")) return e;
   const long z_rows = (long)dz->batch * dz->t_pitch;
-  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 64), t.chunks), dim3(256), 0, s, p.Z, z_rows, dz->c_pitch,
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 256), t.chunks), dim3(256), 0, s, p.Z, z_rows, dz->c_pitch,
                      t.n_pad, part);
   const size_t n4 = (size_t)width * x->c_pitch * t.n_pad / 4;
-  hipLaunchKernelGGL(wgrad_tr_finish_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048)), dim3(256), 0, s,
+  const unsigned bias_blocks = (unsigned)st::ceil_div(t.n_pad, 256);
+  const unsigned sum_blocks = t.splits > 1 ? (unsigned)std::min<size_t>((n4 + 255) / 256, 2048) : 0u;
+  hipLaunchKernelGGL(wgrad_tr_finish_kernel, dim3(std::max(bias_blocks, sum_blocks)), dim3(256), 0, s,
                      t.splits > 1 ? slabs : (const float*)nullptr, t.splits, n4, dpacked, part, t.chunks, t.n_pad, dbias);
   return st::check_launch("wgrad_tr_finish");
 }

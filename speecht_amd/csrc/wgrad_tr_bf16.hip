@@ -258,11 +258,15 @@ TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_lef
   t.tiles_m = width * t.mtiles_per_tap;
   t.tiles_n = st::ceil_div(t.n_pad, TN);
   const long tiles = (long)t.tiles_m * t.tiles_n;
-  // two 64 KB workgroups per CU: one round of 512 (tile, split) pairs (the 2000 x 2000 layer: 256 tiles in two halves -- alone on
-  // its CU a workgroup is latency-bound, 0.32 us per stage for 0.11 us of MFMAs), at least 8 stages per split
+  // Splits (measured round 5 on the config-2 shapes, bf16 step): every split adds a slab to write and sum -- the 250-channel
+  // layers' 28 tiles in 9 runs of 57 stages (256 pairs) and in 18 (512 pairs) give the same step, 2.49 ms; 768 pairs 2.58, 1 024
+  // 2.62 -- but a workgroup alone on its CU is latency-bound (the 2000 x 2000 layer's 256 tiles unsplit: 0.32 us per stage for 0.11
+  // us of MFMAs, 163 us; in two halves, two workgroups per CU, 146 us): about 256 pairs, and two halves when the tile grid
+  // alone gives about one workgroup per CU and the reduction is long; at least 8 stages per split.
   const int forced = st::tuning(st::TUNE_BF16_WGRAD_SPLITS);
-  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 512;
+  const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 256;
   int splits = forced ? forced : (int)std::max(1L, std::min<long>(target / std::max(1L, tiles), t.stages / 8));
+  if (!forced && splits == 1 && tiles >= 128 && tiles <= 320 && t.stages >= 64) splits = 2;
   splits = std::max(1, std::min(splits, t.stages));
   t.stages_per_split = st::ceil_div(t.stages, splits);
   t.splits = st::ceil_div(t.stages, t.stages_per_split);

@@ -1400,6 +1400,11 @@ class Wav2LetterEngine:
       self._step_graphs, self._step_graph_seen = {}, set()
       self._rate_host = torch.zeros(16, dtype=torch.float32, pin_memory=True)
       self._rate_turn = 0
+      # the device scalars of the Adam rate exist (and are zero-filled) before any stream copies into them: created lazily, the
+      # fill kernel on a busy compute stream ran AFTER the copy on the idle upload stream and wiped the step's rate
+      for par in (0, 1):
+        self._storage.view('adam_rate_par%d' % par, 4)
+      torch.cuda.synchronize(self.device)
 
   def _step_body(self, grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev):
     """The launch sequence of one training step in the order a captured graph holds it: the operands derived from the weights

@@ -433,7 +433,7 @@ def comm_model(eng, feed, lr, global_batch, step_ms, world=8, reps=5):
                                              scaling_vs_8x=round(step_ms / (step_ms + exposed), 4))
   return dict(kind='MODEL from single-GPU event times, not a measurement', world_assumed=world, backward_ms=round(bwd_ms, 3),
               buckets=per_bucket, assumed=model,
-              note='exposed = what the in-order all-reduces of the four buckets (2 (N - 1) / N x bytes / busbw each, started when the bucket '
+              note='exposed = what the in-order all-reduces of the buckets (2 (N - 1) / N x bytes / busbw each, started when the bucket '
                    'is ready) still have to do when back-prop ends; the measured compute step is `step_ms` of this mode.  xGMI: 7 links x '
                    '~153 GB/s per GPU; RCCL on 8 MI300-class GPUs reaches 200-300 GB/s bus bandwidth on large messages, less on 7-16 MB ones')
 
@@ -721,7 +721,7 @@ class c_stdout_to_stderr:
 
 
 def comm_probe_world1(eng, feed, lr, global_batch, steps, ahead):
-  """What the data-parallel plumbing costs a step on ONE GPU: the same steps with the four-bucket exchange forced through the
+  """What the data-parallel plumbing costs a step on ONE GPU: the same steps with the bucketed exchange forced through the
   library's RCCL communicator at world size 1 (per-layer hooks, the collective stream, its events, ncclAllReduce launches
   beside back-prop) against the plain steps.  It cannot show what the transfers of N > 1 cost the GEMMs (a 1-rank all-reduce
   moves nothing over xGMI); it bounds everything else."""

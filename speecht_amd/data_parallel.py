@@ -7,7 +7,7 @@ global-norm clip -- all replicas then apply the identical clip + Adam update and
 
 One process per GPU; ``torch.distributed`` (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests) is
 used purely as the collective transport.  Buckets are contiguous slices of the flat gradient buffer
-in the order back-prop finishes them (L10+L9, L8, L7..L0), launched asynchronously so that the
+in the order back-prop finishes them (L10+L9, L8, L7..L4, L3..L1, L0), launched asynchronously so that the
 xGMI transfer overlaps the remaining back-prop kernels.
 """
 import ctypes
@@ -39,10 +39,16 @@ def default_buckets(layer_sizes, layer_offsets):
   groups.append((big, big))
   if big >= 4:
     # the layers below the big one finish last: the exchange of the final bucket is the part of the communication that
-    # no kernel hides, so they go in two halves and only the lower one is left over at the end of back-prop
+    # no kernel hides, so they go in three pieces -- the upper half, the lower half without the bottom layer, and the bottom
+    # layer alone (3.8 MB of the model's 96: what is left over when back-prop ends; round 4 left 9.4 MB, and a 2.5 ms bf16 step
+    # has no slack for it -- bench.py's comm_model_8gpu prices the tail per assumed bus bandwidth)
     mid = big // 2
     groups.append((mid, big - 1))
-    groups.append((0, mid - 1))
+    if mid > 1:
+      groups.append((1, mid - 1))
+      groups.append((0, 0))
+    else:
+      groups.append((0, mid - 1))
   elif big > 0:
     groups.append((0, big - 1))
   return [(lo, layer_offsets[lo][0], layer_offsets[hi][1]) for lo, hi in groups]

@@ -173,14 +173,14 @@ def test_shard_range_and_buckets():
     shard_range(10, 0, 4)
   offs = [(0, 10), (10, 20), (20, 120), (120, 140), (140, 145)]
   assert default_buckets([e - s for s, e in offs], offs) == [(3, 120, 145), (2, 20, 120), (0, 0, 20)]
-  # the Wav2Letter shape: the big layer is the ninth; the eight layers below it go in two halves, the lower one last
+  # the Wav2Letter shape: the big layer is the ninth; the eight layers below it go in three pieces, the bottom layer alone last
   sizes = [10, 4, 4, 4, 4, 4, 4, 4, 100, 30, 1]
   offs, o = [], 0
   for n in sizes:
     offs.append((o, o + n))
     o += n
   assert default_buckets(sizes, offs) == [(9, offs[9][0], offs[10][1]), (8, offs[8][0], offs[8][1]), (4, offs[4][0], offs[7][1]),
-                                          (0, 0, offs[3][1])]
+                                          (1, offs[1][0], offs[3][1]), (0, 0, offs[0][1])]
 
 
 DP_WORKER = r'''
@@ -193,7 +193,7 @@ from speecht_amd.data_parallel import GradientAllReducer, shard_range, all_reduc
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 if os.environ.get("ST_FULL_DEPTH"):
-  layers = WL.w2l_layers(6, width=8, fc=16)                      # eleven layers: the four-bucket schedule of the real model
+  layers = WL.w2l_layers(6, width=8, fc=16)                      # eleven layers: the five-bucket schedule of the real model
   frames = [80, 66, 56, 80, 71, 80, 49, 80]                      # global batch 8
 else:
   layers = [(7, 2, 6, 8, True), (5, 1, 8, 8, True), (1, 1, 8, 29, False)]
@@ -215,7 +215,7 @@ ranges = [(int(offs[i]), int(offs[i + 1])) for i in range(len(sizes))]
 flat = torch.tensor(local)
 red = GradientAllReducer(flat, ranges)
 if os.environ.get("ST_FULL_DEPTH"):
-  assert [b[0] for b in red.buckets] == [9, 8, 4, 0], red.buckets   # L9+L10 | L8 | L4..L7 | L0..L3, in back-prop order
+  assert [b[0] for b in red.buckets] == [9, 8, 4, 1, 0], red.buckets   # L9+L10 | L8 | L4..L7 | L1..L3 | L0, in back-prop order
   assert red.buckets[0][2] == ranges[-1][1] and red.buckets[-1][1] == 0
   assert sum(e - s for _, s, e in red.buckets) == flat.numel()      # the buckets tile the flat gradient exactly
 for i in reversed(range(len(layers))):
@@ -238,7 +238,7 @@ print("rank", rank, "ok")
 def test_data_parallel_allreduce_equals_single_rank_gloo(tmp_path, world, full_depth):
   """world_size 2 and 4 on CPU (gloo): bucketed SUM all-reduce of per-rank gradients scaled by
   1/global_batch == gradient of the concatenated batch; replicas end bit-identical.  The world-4 case runs the
-  eleven-layer model, i.e. the four buckets of the real schedule (L9+L10, L8, L4..L7, L0..L3)."""
+  eleven-layer model, i.e. the five buckets of the real schedule (L9+L10, L8, L4..L7, L1..L3, L0)."""
   script = tmp_path / 'dp_worker.py'
   script.write_text(DP_WORKER)
   env = dict(os.environ, ST_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29611 + world), WORLD_SIZE=str(world))

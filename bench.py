@@ -1049,6 +1049,7 @@ def main():
                     'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
         if mode == 'bf16':
           # the comm model first (plain events), the roofline pass last: its timed launches switch the queues to profiling mode
+          out[key]['comm_probe_world1'] = comm_probe_world1(alt, alt_feed, lr, global_batch, args.steps, ahead)
           out[key]['comm_model_8gpu'] = comm_model(alt, alt_feed, lr, global_batch, alt_ms)
           out[key]['roofline'] = roofline_bf16_in_step(alt, lambda: train_step(alt, alt_feed, None, lr, global_batch), alt_ms)
         del alt
@@ -1062,6 +1063,8 @@ def main():
       attach_pmc_profiles(out['roofline'])
     if world == 1:
       out['mel_features'] = measure_mel(dev, args.batch, args.seconds, args.mels)
+      if not args.no_alt:
+        out['mel_features_batch512'] = measure_mel(dev, 512, args.seconds, args.mels)    # (a preprocessing job's batch: launch costs amortised)
     if world == 1 and not args.no_alt and args.mels == 80:
       # the other single-GPU configurations of BASELINE.json, a few seconds each, each with an oracle check of its own
       out['configs2_inference'] = config2_rate(dev, layers)

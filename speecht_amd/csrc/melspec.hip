@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
                                                           const long* __restrict__ sample_off,
                                                           const Plan* __restrict__ plan, int n_mels, int hop,
                                                           const long* __restrict__ frame_off,
-                                                          float* __restrict__ logpow, float* __restrict__ wmax) {
+                                                          float* __restrict__ logpow, float* __restrict__ wmax,
+                                                          double* __restrict__ wstat) {
+  // wstat (nullable; the power-spectrogram path): per wave slot {min, sum, sum of squares} of the log2 values it wrote -- with
+  // the maximum they give the utterance's mean / variance in closed form whenever power_to_db's 80 dB floor touches no element
+  // (normalize(), preprocessing.py:29-33), so the statistics pass over the matrix only runs for utterances it does touch
   using melfft::cf;
   __shared__ cf zbuf[4][melfft::LDS_COMPLEX];
   __shared__ float pw[4][2][NBINS + PLAN_PIECE - 1];       // + read-ahead pad (zero weights meet zero values there)
@@ -141,8 +145,15 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p_begin = (blockIdx.x * 4 + wave) * PAIRS_PER_WAVE;
   float* my_max = wmax + (long)u * (gridDim.x * 4) + blockIdx.x * 4 + wave;
+  double* my_stat = wstat ? wstat + ((long)u * (gridDim.x * 4) + blockIdx.x * 4 + wave) * 3 : nullptr;
+  auto idle_slot = [&]() {
+    if (lane == 0) {
+      *my_max = LOG2_AMIN;
+      if (my_stat) { my_stat[0] = 1e30; my_stat[1] = 0.0; my_stat[2] = 0.0; }
+    }
+  };
   if (blockIdx.x * 4 * PAIRS_PER_WAVE >= pairs) {          // whole workgroup past the end of a short utterance
-    if (lane == 0) *my_max = LOG2_AMIN;
+    idle_slot();
     return;
   }
   for (int i = tid; i < 8 * 64; i += 256) {
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
   }
   __syncthreads();                                         // the only workgroup barrier
   if (p_begin >= pairs) {
-    if (lane == 0) *my_max = LOG2_AMIN;
+    idle_slot();
     return;
   }
   const float* y = audio + s0;
@@ -166,7 +177,8 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
   for (int j = 0; j < MAX_OUT_PER_LANE; ++j) oinfo[j] = lane + 64 * j < 2 * n_mels ? plan->oinfo[lane + 64 * j] : 0;
   cf* zb = zbuf[wave];
   float* part = reinterpret_cast<float*>(zb);              // piece sums: the FFT buffer is idle during the projection
-  float vmax = LOG2_AMIN;
+  float vmax = LOG2_AMIN, vmin = 1e30f;
+  double sum1 = 0.0, sum2 = 0.0;
   const int p_end = min(pairs, p_begin + PAIRS_PER_WAVE);
   // raw samples of a frame pair: frame 2p -> xa, frame 2p + 1 -> xb; centre=True: padded index t*hop + k  <->  sample
   // t*hop + k - NFFT/2, reflected at the ends.  Loaded one pair ahead so that the HBM/L2 latency hides behind the
@@ -279,6 +291,9 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
         if (i < valid) {
           dst[i] = l2;
           vmax = fmaxf(vmax, l2);
+          vmin = fminf(vmin, l2);
+          sum1 += (double)l2;
+          sum2 += (double)l2 * (double)l2;
         }
       }
     }
@@ -286,6 +301,15 @@ __global__ __launch_bounds__(256, 4) void mel_pair_kernel(const float* __restric
   }
   vmax = st::wave_max(vmax);
   if (lane == 0) *my_max = vmax;
+  if (my_stat) {
+    vmin = -st::wave_max(-vmin);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                       // fixed-shape tree: deterministic
+      sum1 += __shfl_xor(sum1, o, 64);
+      sum2 += __shfl_xor(sum2, o, 64);
+    }
+    if (lane == 0) { my_stat[0] = (double)vmin; my_stat[1] = sum1; my_stat[2] = sum2; }
+  }
 }
 
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
@@ -313,6 +337,29 @@ __device__ __forceinline__ float utterance_max(const float* __restrict__ wmax, i
   return m;
 }
 
+// {min, sum, sum of squares} of the utterance's log2 values from the per-wave slots (fixed order); every thread gets them
+__device__ __forceinline__ void utterance_stats(const double* __restrict__ wstat, int u, int slots, double* red3, double* mn, double* s1,
+                                                double* s2) {
+  double a = 1e30, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < slots; i += blockDim.x) {
+    const double* w = wstat + ((long)u * slots + i) * 3;
+    a = fmin(a, w[0]); b += w[1]; c += w[2];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a = fmin(a, __shfl_xor(a, o, 64));
+    b += __shfl_xor(b, o, 64);
+    c += __shfl_xor(c, o, 64);
+  }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red3[wave * 3] = a; red3[wave * 3 + 1] = b; red3[wave * 3 + 2] = c; }
+  __syncthreads();
+  a = red3[0]; b = red3[1]; c = red3[2];
+  for (int i = 1; i < nw; ++i) { a = fmin(a, red3[i * 3]); b += red3[i * 3 + 1]; c += red3[i * 3 + 2]; }
+  __syncthreads();
+  *mn = a; *s1 = b; *s2 = c;
+}
+
 // power_to_db(ref = max, amin 1e-10, top_db 80) from log2 values: 10 log10(x) = DB_PER_LOG2 * log2(x); the maximum of
 // the dB matrix is 0 by construction, so the floor is -80
 __device__ __forceinline__ float to_db(float l2, float l2_max) { return fmaxf(DB_PER_LOG2 * (l2 - l2_max), -80.f); }
@@ -321,14 +368,22 @@ __global__ __launch_bounds__(256) void mel_stats_kernel(const float* __restrict_
                                                         const long* __restrict__ sample_off,
                                                         const long* __restrict__ frame_off, int n_mels, int hop,
                                                         const float* __restrict__ wmax, int slots,
-                                                        double* __restrict__ partial) {
+                                                        const double* __restrict__ wstat, double* __restrict__ partial) {
   __shared__ double red[4];
+  __shared__ double red3[12];
   __shared__ float redf[4];
   const int u = blockIdx.y;
   const int n = (int)(sample_off[u + 1] - sample_off[u]);
   const long count = (long)(1 + n / hop) * n_mels;
   const float* src = logpow + frame_off[u] * (long)n_mels;
   const float l2_max = utterance_max(wmax, u, slots, redf);
+  {
+    // the smallest element stays above the floor -> so does every element (to_db is monotone): mel_finish_kernel takes the closed
+    // form from the per-wave sums and this pass has nothing to do (block-uniform exit)
+    double mn, s1, s2;
+    utterance_stats(wstat, u, slots, red3, &mn, &s1, &s2);
+    if (DB_PER_LOG2 * ((float)mn - l2_max) >= -80.f) return;
+  }
   const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
   const long lo = blockIdx.x * per, hi = min(count, lo + per);
   double s = 0.0, ss = 0.0;
@@ -368,15 +423,27 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict
                                                          const long* __restrict__ sample_off,
                                                          const long* __restrict__ frame_off, int n_mels, int hop,
                                                          const float* __restrict__ wmax, int slots,
-                                                         const double* __restrict__ partial,
+                                                         const double* __restrict__ wstat, const double* __restrict__ partial,
                                                          float* __restrict__ out) {
   __shared__ float redf[4];
+  __shared__ double red3[12];
   __shared__ double tot[2];
   const int u = blockIdx.y;
   const int n = (int)(sample_off[u + 1] - sample_off[u]);
   const long count = (long)(1 + n / hop) * n_mels;
   static_assert(STAT_CHUNKS == 64, "one partial per lane of the first wave");
-  if (threadIdx.x < 64) {                          // same fixed-shape tree in every block: deterministic
+  const float l2_max_early = utterance_max(wmax, u, slots, redf);
+  double mn, w1, w2;
+  utterance_stats(wstat, u, slots, red3, &mn, &w1, &w2);
+  const bool unfloored = DB_PER_LOG2 * ((float)mn - l2_max_early) >= -80.f;      // (the test mel_stats_kernel exits on)
+  if (unfloored) {
+    // d = c (l - M) for every element: sum d = c (S1 - N M), sum d^2 = c^2 (S2 - 2 M S1 + N M^2), in double
+    if (threadIdx.x == 0) {
+      const double c = (double)DB_PER_LOG2, M = (double)l2_max_early, N = (double)count;
+      tot[0] = c * (w1 - N * M);
+      tot[1] = c * c * (w2 - 2.0 * M * w1 + N * M * M);
+    }
+  } else if (threadIdx.x < 64) {                   // same fixed-shape tree in every block: deterministic
     double s = partial[((long)u * STAT_CHUNKS + threadIdx.x) * 2];
     double ss = partial[((long)u * STAT_CHUNKS + threadIdx.x) * 2 + 1];
 #pragma unroll
@@ -394,7 +461,7 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict
   const float meanf = (float)mean;
   const float* src = logpow + frame_off[u] * (long)n_mels;
   float* dst = out + frame_off[u] * (long)n_mels;
-  const float l2_max = utterance_max(wmax, u, slots, redf);
+  const float l2_max = l2_max_early;
   const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
   const long lo = blockIdx.x * per, hi = min(count, lo + per);
   if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)(lo * 4)) & 15) == 0) {
@@ -539,10 +606,10 @@ size_t slot_bytes_bound(int n_utts, int64_t total_frames) {
 
 // log2 mel power of every frame + per-wave maxima
 int launch_frames(const float* audio, const long* soff, int n_utts, int64_t max_samples, const Plan* plan, int n_mels,
-                  int hop, const long* foff, float* logpow, float* wmax, hipStream_t s) {
+                  int hop, const long* foff, float* logpow, float* wmax, hipStream_t s, double* wstat = nullptr) {
   const int max_frames = (int)(1 + max_samples / hop);
   hipLaunchKernelGGL(mel_pair_kernel, dim3(wave_slots(max_frames) / 4, n_utts), dim3(256), 0, s, audio, soff, plan, n_mels,
-                     hop, foff, logpow, wmax);
+                     hop, foff, logpow, wmax, wstat);
   return st::check_launch("mel_frames");
 }
 
@@ -563,8 +630,9 @@ int st_melspec_plan_f32(const float* mel_basis, int n_mels, int n_fft, void* pla
 
 size_t st_melspec_ws(int n_utts, int64_t total_frames, int n_mels) {
   if (n_utts <= 0 || total_frames <= 0 || n_mels <= 0) return 0;
+  // log2 mel powers | per-wave maxima | statistics partials | per-wave {min, sum, sum of squares} (3 doubles per slot) | plan
   return pow_bytes(total_frames, n_mels) + slot_bytes_bound(n_utts, total_frames) +
-         (size_t)n_utts * STAT_CHUNKS * 2 * sizeof(double) + st_melspec_plan_bytes() + 256;
+         (size_t)n_utts * STAT_CHUNKS * 2 * sizeof(double) + 6 * slot_bytes_bound(n_utts, total_frames) + st_melspec_plan_bytes() + 256;
 }
 
 int st_melspec_planned_f32(const float* audio, const int64_t* sample_offsets, int n_utts, int64_t max_samples,
@@ -584,16 +652,18 @@ int st_melspec_planned_f32(const float* audio, const int64_t* sample_offsets, in
   float* wmax = reinterpret_cast<float*>(w);
   w += slot_bytes(n_utts, max_samples, hop);
   double* partial = reinterpret_cast<double*>(w);
+  w += (size_t)n_utts * STAT_CHUNKS * 2 * sizeof(double);
+  double* wstat = reinterpret_cast<double*>(w);
   const long* soff = reinterpret_cast<const long*>(sample_offsets);
   const long* foff = reinterpret_cast<const long*>(frame_offsets);
   const int slots = wave_slots((int)(1 + max_samples / hop));
   if (int e = launch_frames(audio, soff, n_utts, max_samples, reinterpret_cast<const Plan*>(plan), n_mels, hop, foff, logpow,
-                            wmax, s))
+                            wmax, s, wstat))
     return e;
   hipLaunchKernelGGL(mel_stats_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, logpow, soff, foff, n_mels, hop, wmax,
-                     slots, partial);
+                     slots, wstat, partial);
   hipLaunchKernelGGL(mel_finish_kernel, dim3(STAT_CHUNKS, n_utts), dim3(256), 0, s, logpow, soff, foff, n_mels, hop, wmax,
-                     slots, partial, out);
+                     slots, wstat, partial, out);
   return st::check_launch("melspec");
 }
 

@@ -484,11 +484,15 @@ def test_melspec_vs_oracle(dev, golden_dir, n_mels, sr):
   z-normalised dB values (std 1), tolerance 1e-3 absolute (fp32 FFT + log10 vs float64)."""
   import os
   from speecht_amd.preprocessing import calc_power_spectrogram, calc_power_spectrogram_batch
+  # noise clips (no element reaches power_to_db's 80 dB floor: mean / std come in closed form from the sums the FFT kernel
+  # kept, the statistics pass exits at once), a pure tone and a clip that ends in digital silence (most elements ON the floor:
+  # the statistics pass runs) -- both branches of mel_stats_kernel / mel_finish_kernel in one batch
   audio = [O.synthetic_audio(7, 16000 + 77), O.synthetic_audio(8, 32000), O.synthetic_audio(9, 5003),
-           np.sin(2 * np.pi * 440.0 * np.arange(12345) / sr).astype(np.float32)]
+           np.sin(2 * np.pi * 440.0 * np.arange(12345) / sr).astype(np.float32),
+           np.concatenate([O.synthetic_audio(10, 8000), np.zeros(8000, np.float32)])]
+  dyn = [O.calc_power_spectrogram(a, sr, n_mels=n_mels) for a in audio]
   feats = calc_power_spectrogram_batch(audio, sr, n_mels=n_mels)
-  for a, f in zip(audio, feats):
-    ref = O.calc_power_spectrogram(a, sr, n_mels=n_mels)
+  for a, f, ref in zip(audio, feats, dyn):
     assert f.shape == ref.shape == (1 + len(a) // 160, n_mels)
     assert np.max(np.abs(f - ref)) < 1e-3
   single = calc_power_spectrogram(audio[0], sr, n_mels=n_mels)

@@ -337,27 +337,28 @@ __device__ __forceinline__ float utterance_max(const float* __restrict__ wmax, i
   return m;
 }
 
-// {min, sum, sum of squares} of the utterance's log2 values from the per-wave slots (fixed order); every thread gets them
-__device__ __forceinline__ void utterance_stats(const double* __restrict__ wstat, int u, int slots, double* red3, double* mn, double* s1,
-                                                double* s2) {
+// {max, min, sum, sum of squares} of the utterance's log2 values from the per-wave slots: every WAVE walks all slots in the same
+// fixed order (identical values in every wave of every workgroup), no LDS, no barrier -- the 64 workgroups an utterance has in
+// mel_stats_kernel / mel_finish_kernel each pay this once, and for the statistics pass it is all an unfloored utterance costs
+// (with block-wide reductions behind barriers it was 2 us per workgroup: 73 us of nothing at batch 512)
+__device__ __forceinline__ void utterance_stats(const float* __restrict__ wmax, const double* __restrict__ wstat, int u, int slots,
+                                                float* mx, double* mn, double* s1, double* s2) {
+  const int lane = threadIdx.x & 63;
+  float m = LOG2_AMIN;
   double a = 1e30, b = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < slots; i += blockDim.x) {
+  for (int i = lane; i < slots; i += 64) {
     const double* w = wstat + ((long)u * slots + i) * 3;
+    m = fmaxf(m, wmax[(long)u * slots + i]);
     a = fmin(a, w[0]); b += w[1]; c += w[2];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
     a = fmin(a, __shfl_xor(a, o, 64));
     b += __shfl_xor(b, o, 64);
     c += __shfl_xor(c, o, 64);
   }
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red3[wave * 3] = a; red3[wave * 3 + 1] = b; red3[wave * 3 + 2] = c; }
-  __syncthreads();
-  a = red3[0]; b = red3[1]; c = red3[2];
-  for (int i = 1; i < nw; ++i) { a = fmin(a, red3[i * 3]); b += red3[i * 3 + 1]; c += red3[i * 3 + 2]; }
-  __syncthreads();
-  *mn = a; *s1 = b; *s2 = c;
+  *mx = m; *mn = a; *s1 = b; *s2 = c;
 }
 
 // power_to_db(ref = max, amin 1e-10, top_db 80) from log2 values: 10 log10(x) = DB_PER_LOG2 * log2(x); the maximum of
@@ -370,18 +371,16 @@ __global__ __launch_bounds__(256) void mel_stats_kernel(const float* __restrict_
                                                         const float* __restrict__ wmax, int slots,
                                                         const double* __restrict__ wstat, double* __restrict__ partial) {
   __shared__ double red[4];
-  __shared__ double red3[12];
-  __shared__ float redf[4];
   const int u = blockIdx.y;
   const int n = (int)(sample_off[u + 1] - sample_off[u]);
   const long count = (long)(1 + n / hop) * n_mels;
   const float* src = logpow + frame_off[u] * (long)n_mels;
-  const float l2_max = utterance_max(wmax, u, slots, redf);
+  float l2_max;
   {
     // the smallest element stays above the floor -> so does every element (to_db is monotone): mel_finish_kernel takes the closed
-    // form from the per-wave sums and this pass has nothing to do (block-uniform exit)
+    // form from the per-wave sums and this pass has nothing to do (the same value in every wave: a uniform exit)
     double mn, s1, s2;
-    utterance_stats(wstat, u, slots, red3, &mn, &s1, &s2);
+    utterance_stats(wmax, wstat, u, slots, &l2_max, &mn, &s1, &s2);
     if (DB_PER_LOG2 * ((float)mn - l2_max) >= -80.f) return;
   }
   const long per = (count + STAT_CHUNKS - 1) / STAT_CHUNKS;
@@ -425,16 +424,14 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict
                                                          const float* __restrict__ wmax, int slots,
                                                          const double* __restrict__ wstat, const double* __restrict__ partial,
                                                          float* __restrict__ out) {
-  __shared__ float redf[4];
-  __shared__ double red3[12];
   __shared__ double tot[2];
   const int u = blockIdx.y;
   const int n = (int)(sample_off[u + 1] - sample_off[u]);
   const long count = (long)(1 + n / hop) * n_mels;
   static_assert(STAT_CHUNKS == 64, "one partial per lane of the first wave");
-  const float l2_max_early = utterance_max(wmax, u, slots, redf);
+  float l2_max_early;
   double mn, w1, w2;
-  utterance_stats(wstat, u, slots, red3, &mn, &w1, &w2);
+  utterance_stats(wmax, wstat, u, slots, &l2_max_early, &mn, &w1, &w2);
   const bool unfloored = DB_PER_LOG2 * ((float)mn - l2_max_early) >= -80.f;      // (the test mel_stats_kernel exits on)
   if (unfloored) {
     // d = c (l - M) for every element: sum d = c (S1 - N M), sum d^2 = c^2 (S2 - 2 M S1 + N M^2), in double

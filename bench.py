@@ -388,6 +388,40 @@ def roofline_bf16_in_step(eng, step_fn, ms_per_step, steps=4):
   return out
 
 
+def host_cost_and_graph(eng, feed, lr, global_batch, steps, ahead):
+  """What the host side of a step costs and what a whole-step HIP graph changes: the same steps timed three
+  ways on this engine -- `host_enqueue_ms` is the CPU time inside the calls that enqueue one step (Python + ctypes; the pacing
+  wait that keeps two steps in flight is NOT in it), `ms_per_step` the wall clock per step -- once through the eager launch
+  sequence and once through engine.train_step_graph (one graph launch per step; capture happens in the warm-up)."""
+  res = {}
+  for name, graph in (('eager', False), ('graph', True)):
+    eng.enable_step_graph(graph)
+    for _ in range(6):                                        # (graph: first sight of both parities, capture, replay)
+      train_step(eng, feed, None, lr, global_batch)
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event() for _ in range(steps)]
+    host = 0.0
+    t0 = time.perf_counter()
+    for k in range(steps):
+      if ahead and k >= ahead:
+        marks[k - ahead].synchronize()
+      h0 = time.perf_counter()
+      train_step(eng, feed, None, lr, global_batch)
+      host += time.perf_counter() - h0
+      marks[k].record()
+    torch.cuda.synchronize()
+    res[name] = dict(ms_per_step=round((time.perf_counter() - t0) / steps * 1e3, 3), host_enqueue_ms=round(host / steps * 1e3, 3))
+  eng.enable_step_graph(False)
+  for _ in range(2):                                          # back on the eager path: derived operands rebuilt, uploads unfixed
+    train_step(eng, feed, None, lr, global_batch)
+  torch.cuda.synchronize()
+  res['graphs_captured'] = len(getattr(eng, '_step_graphs', {}))
+  res['note'] = ('graph = forward + CTC + backward + clip / Adam replayed as ONE hipGraphLaunch (bit-identical to the eager step, '
+                 'tests/test_gpu_api.py); the host enqueues an eager step in about a millisecond while the GPU needs 2.5 - 7, two steps '
+                 'ahead: the eager sequence is not host-bound, and the graph replays its multi-stream launch sequence no faster')
+  return res
+
+
 def comm_model(eng, feed, lr, global_batch, step_ms, world=8, reps=5):
   """MODEL, not a measurement (every test box has one GPU): when, inside the backward pass, each of the four
   gradient buckets is complete (events recorded where the data-parallel hook would hand the bucket to RCCL: engine.backward with
@@ -1011,6 +1045,7 @@ def main():
       out['comm_probe_world1'] = comm_probe_world1(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and reducer is None and not args.no_alt:
       out['comm_model_8gpu'] = comm_model(eng, feed, lr, global_batch, ms)
+      out['whole_step_graph'] = host_cost_and_graph(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
       # Side measurements on the same box and inputs, NOT the headline:
       #  * bf16x6 (experimental): fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on the bf16
@@ -1049,6 +1084,7 @@ def main():
                     'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
         if mode == 'bf16':
           # the comm model first (plain events), the roofline pass last: its timed launches switch the queues to profiling mode
+          out[key]['whole_step_graph'] = host_cost_and_graph(alt, alt_feed, lr, global_batch, args.steps, ahead)
           out[key]['comm_probe_world1'] = comm_probe_world1(alt, alt_feed, lr, global_batch, args.steps, ahead)
           out[key]['comm_model_8gpu'] = comm_model(alt, alt_feed, lr, global_batch, alt_ms)
           out[key]['roofline'] = roofline_bf16_in_step(alt, lambda: train_step(alt, alt_feed, None, lr, global_batch), alt_ms)

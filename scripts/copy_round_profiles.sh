@@ -23,11 +23,17 @@ cp $F/inference_config3_bf16.json ${P}_inference_config3_bf16.json
 cp $F/pmc_shapes_bf16.txt ${P}_pmc_shapes_bf16.txt
 cp $F/pmc_shapes_fp32.txt ${P}_pmc_shapes_fp32.txt
 cp $F/pytest_gpu.log ${P}_pytest_gpu.log
+cp $F/traffic_bf16.json profiles/traffic_bf16.json
+cp $F/mel_traffic_b32.json ${P}_mel_traffic_b32.json
+cp $F/mel_traffic_b512.json ${P}_mel_traffic_b512.json
+cp $F/mel_timing.txt ${P}_mel_timing.txt
+for M in fp32 bf16; do cp $F/host_cost_$M.json ${P}_host_cost_$M.json; cp $F/api_train_$M.json ${P}_api_train_$M.json; done
+cp $F/forced_build.txt ${P}_forced_build.txt
 python - <<'PY'
 import json
 from speecht_amd import build
 d = build.source_digest()
-for f in ('profiles/traffic.json', 'profiles/mfma_util.json'):
+for f in ('profiles/traffic.json', 'profiles/mfma_util.json', 'profiles/traffic_bf16.json'):
   got = json.load(open(f)).get('source_digest')
   print(f, 'digest', got[:12], 'matches sources' if got == d else 'STALE against ' + d[:12])
 PY

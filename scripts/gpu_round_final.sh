@@ -7,9 +7,18 @@ R=${1:?round number}
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/r${R}final
 mkdir -p $F
+# gfx950 compilation on the box itself, once per round (the shipped .so is otherwise reused when the source digest matches)
+python -c "from speecht_amd.build import build_library; build_library(force=True, verbose=False)" 2>&1 | tail -3; echo "forced build rc=$?" | tee $F/forced_build.txt
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $F/pytest_gpu.log
 cat $F/pytest_gpu.log
+# (the bench line quotes profiles/traffic_bf16.json for its alt_bf16.roofline: collected BEFORE the default bench run below)
+bash scripts/gpu_traffic_bf16.sh 2>&1 | tail -2
+cp gpurun_out/traffic_bf16/traffic_bf16.json $F/
 bash scripts/gpu_profile_round.sh $R 2>&1 | tail -6
+for B in 32 512; do bash scripts/gpu_mel_traffic.sh $B > /dev/null 2>&1; cp gpurun_out/mel_traffic_b$B/mel_traffic.json $F/mel_traffic_b$B.json; cp gpurun_out/mel_traffic_b$B/timing_under_rocprof.txt $F/mel_timing_under_rocprof_b$B.txt; done
+for B in 32 512; do python scripts/bench_mel.py 80 $B 2>/dev/null | tail -1; done > $F/mel_timing.txt; cat $F/mel_timing.txt
+for M in fp32 bf16; do timeout 300 python scripts/bench_host_cost.py --conv-mode $M 2>/dev/null | grep '^{' > $F/host_cost_$M.json; timeout 300 python scripts/bench_api_train.py --conv-mode $M 2>/dev/null | grep '^{' > $F/api_train_$M.json; done
+cat $F/host_cost_bf16.json $F/api_train_bf16.json
 timeout 600 python scripts/bench_inference.py > $F/inference_config3_fp32.json 2>/dev/null
 timeout 600 python scripts/bench_inference.py --conv-mode bf16 > $F/inference_config3_bf16.json 2>/dev/null
 timeout 300 python scripts/bench_decode.py > $F/decode_config5.json 2>/dev/null

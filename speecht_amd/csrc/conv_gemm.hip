@@ -553,17 +553,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
   typedef typename FVec<NT>::type bvec;
   typedef unsigned long long u64;
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ];
-  __shared__ int sk_lost;             // sticky: a hand-off to this workgroup timed out (its tiles are NaN from then on)
+  // (ONE LDS object: with a second __shared__ variable the LDS lowering tags every access with alias scopes, the waitcnt pass
+  // then sees fragment reads that may alias the LDS-DMA in flight and drains it -- s_waitcnt vmcnt(0) in the stage loop, 54 -> 77 us
+  // per launch, measured round 5.  The sticky flag lives in four floats behind the stages.)
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ + 4];
   float* const As = smem;
   float* const Bs = smem + 2 * A_SZ;
+  volatile int* const sk_lost_p = reinterpret_cast<volatile int*>(smem + 2 * A_SZ + 2 * B_SZ);   // sticky: a hand-off timed out
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WNW, wn = wave % WNW;
-  if (tid == 0) sk_lost = 0;          // (read only behind the barrier that follows a poll)
+  if (tid == 0) *sk_lost_p = 0;       // (read only behind the barrier that follows a poll)
 
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int slot = blockIdx.x;                               // this workgroup's partial tile and flag
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
           if (++spins > (1u << 21)) {
             __hip_atomic_fetch_add(p.ctrl + st::SK_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&g_sk_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_lost = 1;
+            *sk_lost_p = 1;
             break;
           }
         }
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
       }
       __syncthreads();
       // an unpublished partial must not be consumed silently: the tile becomes NaN (and the count says why)
-      const float poison = sk_lost ? __uint_as_float(0x7fc00000u) : 0.f;
+      const float poison = *sk_lost_p ? __uint_as_float(0x7fc00000u) : 0.f;
       const float* const theirs = p.partial + (long)src * (BM * BN);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {

@@ -24,6 +24,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--steps', type=int, default=40)
   ap.add_argument('--conv-mode', default=None)
+  ap.add_argument('--graph', action='store_true', help='model.step_graph = True: the training step as one HIP-graph launch')
   args = ap.parse_args()
   if args.conv_mode:
     os.environ['ST_CONV_MODE'] = args.conv_mode
@@ -37,6 +38,7 @@ def main():
 
   loader = speech_input.InputBatchLoader(80, 32, generator)
   model = speech_model.create_default_model(Flags(), 80, loader)
+  model.step_graph = bool(args.graph)
   with speech_model.Session('cuda:0') as sess:
     model.init_session(sess)
     coord = speech_input.Coordinator()
@@ -51,7 +53,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     coord.request_stop()
   print(json.dumps({'workload': 'SpeechModel.step through InputBatchLoader, batch 32 x 10 s, 80-mel',
-                    'conv_mode': model.engine.conv_mode, 'ms_per_step': round(dt * 1e3, 3),
+                    'conv_mode': model.engine.conv_mode, 'step_graph': bool(args.graph), 'ms_per_step': round(dt * 1e3, 3),
                     'utterances_per_s': round(32 / dt, 1)}))
   sys.stdout.flush()
   os._exit(0)

@@ -259,6 +259,7 @@ class SpeechModel:
     self._reducer = None
     self._world = 1
     self._rank = 0
+    self.step_graph = os.environ.get('ST_STEP_GRAPH', '0') == '1'      # training steps as one HIP-graph launch (see `step`)
 
   # ---- graph-building protocol ---------------------------------------------------------------
   def _convolution(self, value, filter_width, stride, input_channels, out_channels, apply_non_linearity=True):
@@ -352,15 +353,27 @@ class SpeechModel:
       labels = feed_dict.get(self.labels, labels) if self.labels is not None else labels
     if (loss or update) and labels is None:
       raise ValueError('loss/update requested but the input loader provides no labels')
+    # opt-in (`model.step_graph = True` / ST_STEP_GRAPH=1): a training step of a single process as ONE HIP-graph launch
+    # (engine.train_step_graph: bit-identical to the sequence below).  It pays where the host is the limit -- this method reads the
+    # loss back every step, so the enqueue cost of the ~100 launches is not hidden behind the GPU as in a loop that runs ahead:
+    # bf16 activations 3.16 -> see DESIGN 4.9 -- and costs a capture per (batch shape, label-length class), so it is off by default
+    # for corpora whose padded batch length changes every step.
+    use_graph = bool(getattr(self, 'step_graph', False)) and update and self._training and self._world == 1 and labels is not None
+    if use_graph and not getattr(eng, '_step_graph_on', False):
+      eng.enable_step_graph()
     eng.load_batch(inputs, seq_lens)
-    eng.forward()
+    if not use_graph:
+      eng.forward()
     out = []
     avg_loss = None
     if loss or update:
       eng.set_labels(sparse_to_label_lists(labels))
-      # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
-      eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
-      if update:
+      if use_graph:
+        eng.train_step_graph(1.0 / len(seq_lens), self.learning_rate.value, self.max_gradient_norm)
+      else:
+        # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
+        eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
+      if update and not use_graph:
         if not self._training:
           raise RuntimeError('add_training_ops() was not called with labelled inputs')
         eng.backward(self._reducer.on_layer_done if self._reducer else None, self._reducer.hook_layers if self._reducer else None)

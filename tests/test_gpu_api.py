@@ -96,6 +96,41 @@ def test_model_step_protocol_and_training_reduces_loss(dev, tmp_path):
   coord.request_stop()
 
 
+def test_model_step_through_the_whole_step_graph_equals_the_eager_step(dev, tmp_path):
+  """`model.step_graph = True`: SpeechModel.step runs a training step as one HIP-graph launch (engine.train_step_graph).  Two models
+  over the same cyclic batches, started from the same weights: losses, decodes, global_step and weights stay identical step for
+  step, with the other fetches (decode, labels, summary) and an evaluation step (update=False) in between."""
+  from speecht_amd.speech_model import Session, create_default_model
+  flags = Flags()
+  flags.log_dir = str(tmp_path / 'log')
+  models = []
+  for use_graph in (False, True):
+    loader, coord, _ = make_loader(16, 4, [121, 100, 90, 121])
+    model = create_default_model(flags, 16, loader)
+    model.step_graph = use_graph
+    models.append((model, coord))
+  with Session(dev) as sess_a, Session(dev) as sess_b:
+    (a, _), (b, _) = models
+    a.init_session(sess_a)
+    b.init_session(sess_b)
+    b.engine.params.copy_(a.engine.params)          # (init_session draws an unseeded Xavier sample per model)
+    b.engine.mark_weights_changed()
+    for k in range(7):
+      kw = dict(decode=(k == 3), return_label=(k == 3), summary=(k == 4))
+      ra, rb = a.step(sess_a, **kw), b.step(sess_b, **kw)
+      assert float(ra[0]) == float(rb[0]), (k, ra[0], rb[0])
+      if k == 3:
+        assert np.array_equal(ra[1][0].values, rb[1][0].values) and np.array_equal(ra[1][0].indices, rb[1][0].indices)
+      if k == 5:                                    # an evaluation step in between: eager on both, nothing changes
+        ea, eb = a.step(sess_a, update=False), b.step(sess_b, update=False)
+        assert float(ea[0]) == float(eb[0])
+      assert torch.equal(a.engine.params, b.engine.params), k
+      assert a.global_step.eval() == b.global_step.eval() == k + 1
+    assert len(b.engine._step_graphs) >= 1 and not hasattr(a.engine, '_step_graphs')
+  for _, coord in models:
+    coord.request_stop()
+
+
 def test_single_input_inference_matches_batch_padding_semantics(dev, tmp_path):
   """F7: nothing is masked, so logits depend on the padded batch length; a single utterance fed
   through SingleInputLoader must equal the oracle on that [1, T, C] tensor."""

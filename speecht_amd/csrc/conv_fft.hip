@@ -1287,6 +1287,15 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
   const unsigned short* sfp = reinterpret_cast<const unsigned short*>(sf_planes);
   const unsigned short* zfp = reinterpret_cast<const unsigned short*>(zf_planes);
   const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
+  if (split_lag_products(half) && planes == 1 && npo % 128 == 0 && (2 * p.rows_pad) % 32 == 0 && st::tuning(st::TUNE_BF16_LAG_COPIES) == 0) {
+    // round 5: the same two products per bin straight from the spectra planes -- both operands are reduction-major as they lie,
+    // and ds_read_b64_tr_b16 hands the matrix pipe its reduction-minor fragments (wgrad_tr_bf16.hip); the rotated operand is a
+    // register shuffle there.  No transposing copies (2 launches, 52 us per step at config 2); st_set_tuning("bf16_lag_copies", 1)
+    // keeps the round-4 form for A/B runs and for the parity test that holds the two against each other.
+    if (int e = st::lag_products_tr_bf16(sfp, zfp, p.bins, p.rows_pad, half, npo, qf, s)) return e;
+    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+    return st::check_launch("conv fft planes bwd_filter");
+  }
   if (split_lag_products(half)) {
     // the split form of st_conv1d_nwc_bwd_filter_fft_f32: Re Q and Im Q as plain products over 2 * rows_pad (part, row) pairs,
     // the rotated operand S' = [S_i | -S_r] formed by the transposing copy (a sign flip of bf16 is exact); batch 2 b + j reads

@@ -47,6 +47,7 @@ struct TrParams {
   float* out;                    // [splits][width * x_cp][n_pad]
   long x_row0, z_row0;           // flat rows of tap 0 / of the gradient at reduction index 0
   long slab_stride;
+  long lag_im_offset;            // LAG: floats from a bin's real product to its imaginary one
   int x_cp, z_cp, n_pad, width;
   int stages, stages_per_split, splits;
   int mtiles_per_tap, tiles_m, tiles_n;
@@ -69,11 +70,26 @@ __device__ __forceinline__ void lds_wait(u64 (&r)[8]) {
                :
                : "memory");
 }
+// four consecutive reduction rows of one channel, (e0, e1, e2, e3) -> (e1, -e0, e3, -e2) when `on` (the rotated spectra operand)
+__device__ __forceinline__ u64 rotate_rows(u64 v, bool on) {
+  const unsigned sh = on ? 16u : 0u, flip = on ? 0x80000000u : 0u;
+  const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  const unsigned lo2 = __builtin_amdgcn_alignbit(lo, lo, sh) ^ flip, hi2 = __builtin_amdgcn_alignbit(hi, hi, sh) ^ flip;
+  return (u64)lo2 | ((u64)hi2 << 32);
+}
 __device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(bf16x8, u64x2{lo, hi});
 }
 
+// LAG: the lag products of a frequency-domain layer's filter gradient (conv_fft.hip, st_conv1d_nwc_bwd_filter_fft_planes with one
+// bf16 plane): a "split" is a frequency bin -- its 2 * rows_pad half-rows (a spectra row [re | im] read as two rows of half
+// length) are the reduction -- and blockIdx.y picks the real or the imaginary product of the bin:
+//   Re Q = S2^T Z2,   Im Q = S'2^T Z2  with  S' = [S_i | -S_r],  i.e. half-row 2 r of S'2 is half-row 2 r + 1 of S2 and half-row
+// 2 r + 1 is MINUS half-row 2 r: inside a fragment of four consecutive reduction rows the pairs change places and the odd ones
+// change sign -- a 16-bit rotation and a sign-bit flip of each 32-bit word, exact in bf16.  Rounds 4's reduction-minor copies of
+// both spectra (transpose_bf16_bins_split, 52 us per step) and the rotated copy they formed are not made any more.
+template <bool LAG>
 __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ST * STAGE_ELEMS];
   unsigned short* const As = smem;                              // [ST][32][128]
@@ -88,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  const bool rot = LAG && blockIdx.y == 1;                      // the imaginary product
   const int kt_begin = split * p.stages_per_split;
   const int nk = min(p.stages_per_split, p.stages - kt_begin);
   if (nk <= 0) return;
@@ -149,6 +166,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
     lds_wait(r0);
     u64 r1[8] = {lds_read_tr16<4096>(a0), lds_read_tr16<5120>(a0), lds_read_tr16<4096>(a1), lds_read_tr16<5120>(a1),
                  lds_read_tr16<4096>(b0), lds_read_tr16<5120>(b0), lds_read_tr16<4096>(b1), lds_read_tr16<5120>(b1)};
+    if (LAG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r0[q] = rotate_rows(r0[q], rot);
+    }
     {
       const bf16x8 fa0 = frag_of(r0[0], r0[1]), fa1 = frag_of(r0[2], r0[3]), fb0 = frag_of(r0[4], r0[5]), fb1 = frag_of(r0[6], r0[7]);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
@@ -157,6 +178,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
     }
     lds_wait(r1);
+    if (LAG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r1[q] = rotate_rows(r1[q], rot);
+    }
     {
       const bf16x8 fa0 = frag_of(r1[0], r1[1]), fa1 = frag_of(r1[2], r1[3]), fb0 = frag_of(r1[4], r1[5]), fb1 = frag_of(r1[6], r1[7]);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
   }
 
   // out[split][w * cp + c][n]: accumulator r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-  float* const out = p.out + (long)split * p.slab_stride;
+  float* const out = p.out + (long)split * p.slab_stride + (rot ? p.lag_im_offset : 0L);
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -284,6 +309,32 @@ bool tr_eligible(const st_tensor3* x, const st_tensor3* dz, int width, int strid
 
 }  // namespace
 
+// Q[2 b + j] = (j == 0 ? S2 : S'2)[b]^T Z2[b] for b < bins: S spectra [bins][rows][2 * half] and Z spectra [bins][rows][2 * npo] as one
+// bf16 plane each, Q fp32 [2 * bins][half][npo]; rows a multiple of 16, half and npo multiples of 128 (no read runs past a bin)
+int st::lag_products_tr_bf16(const void* s_plane, const void* z_plane, int bins, int rows, int half, int npo, float* q, hipStream_t s) {
+  if (!(s_plane && z_plane && q && bins > 0 && rows > 0 && (2 * rows) % TK == 0 && half % TM == 0 && npo % TN == 0)) {
+    st::set_error("lag_products_tr_bf16: bad shape bins=%d rows=%d half=%d npo=%d", bins, rows, half, npo);
+    return ST_EINVAL;
+  }
+  TrParams p{};
+  p.X = reinterpret_cast<const unsigned short*>(s_plane);
+  p.Z = reinterpret_cast<const unsigned short*>(z_plane);
+  p.out = q;
+  p.x_row0 = 0; p.z_row0 = 0;
+  p.slab_stride = 2L * half * npo;                   // bin b: Q[2 b] (real), then Q[2 b + 1] (imaginary)
+  p.lag_im_offset = (long)half * npo;
+  p.x_cp = half; p.z_cp = npo; p.n_pad = npo; p.width = 1;
+  p.stages_per_split = 2 * rows / TK; p.splits = bins; p.stages = bins * p.stages_per_split;
+  p.mtiles_per_tap = half / TM; p.tiles_m = p.mtiles_per_tap; p.tiles_n = npo / TN;
+  st::trace("wgrad_tr_bf16<128,128,32,lag> batched bins=%d M=%d Np=%d Kp=%d gflop=%.3f", 2 * bins, half, npo, 2 * rows,
+            2e-9 * 2.0 * bins * half * (double)npo * 2.0 * rows);
+  {
+    st::LaunchTimer timer(s);
+    st::launch_timed(timer, wgrad_tr_bf16_kernel<true>, dim3((unsigned)(bins * p.tiles_m * p.tiles_n), 2), dim3(256), s, p);
+  }
+  return st::check_launch("lag_products_tr_bf16");
+}
+
 extern "C" {
 
 int st_conv1d_bwd_filter_tr_bf16_slack_rows(void) { return SLACK_ROWS; }
@@ -322,7 +373,7 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
             t.splits, 2e-9 * (double)t.stages * TK * t.tiles_m * TM * t.tiles_n * TN);
   {
     st::LaunchTimer timer(s);
-    st::launch_timed(timer, wgrad_tr_bf16_kernel, dim3((unsigned)(t.splits * t.tiles_m * t.tiles_n)), dim3(256), s, p);
+    st::launch_timed(timer, wgrad_tr_bf16_kernel<false>, dim3((unsigned)(t.splits * t.tiles_m * t.tiles_n)), dim3(256), s, p);
   }
   if (int e = st::check_launch("wgrad_tr_bf16")) return e;
   const long z_rows = (long)dz->batch * dz->t_pitch;

@@ -65,16 +65,18 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
     eng.backward()
   torch.cuda.synchronize()
   eng.check_ctc_status()
-  assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 5, '\n'.join(tr.lines)   # L9's passes + two of L8's per-bin products
+  assert sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<256,NP=1>')) >= 4, '\n'.join(tr.lines)   # L9's passes + L8's forward per-bin products
   p64 = [(F.astype(np.float64), b.astype(np.float64)) for F, b in params]
   grads = eng.get_grads()
 
   # ---- end to end from the inputs ----
   t0 = time.time()
   spectral = set(eng.fftb)            # the 32-tap layer: block DFTs + per-bin products on bf16 spectra (its own storage model)
-  batched = lambda bins: sum(1 for l in tr.lines if l.startswith('gemm_nn_bf16<') and ' batched bins=%d ' % bins in l)
-  # (two per-bin products of 48 bins; the lag products as 96 real / imaginary ones)
-  assert spectral == {8} and batched(48) == 2 and batched(96) == 1, '\n'.join(tr.lines)
+  batched = lambda bins, kernel='gemm_nn_bf16<': sum(1 for l in tr.lines if l.startswith(kernel) and ' batched bins=%d ' % bins in l)
+  # (two per-bin products of 48 bins; the lag products as 96 real / imaginary ones, since round 5 straight from the spectra planes
+  # through the transposing-read kernel; the stride-1 layers' filter gradients on that kernel too: L1-L7, L9, L10)
+  assert spectral == {8} and batched(48) == 2 and batched(96, 'wgrad_tr_bf16<128,128,32,lag>') == 1, '\n'.join(tr.lines)
+  assert sum(1 for l in tr.lines if l.startswith('wgrad_tr_bf16<128,128,32> ')) == 9, '\n'.join(tr.lines)
   logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round, spectral=spectral)
   loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)
   ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round, spectral=spectral)

@@ -204,6 +204,25 @@ def test_fft_conv_on_the_bf16_matrix_pipe(dev, planes, W, B, T, cin, cout, relu)
   dF = dFd.view(W, cin, cout).cpu().numpy()
   # (bf16 spectra: an element within fp32 rounding of a bf16 boundary lands on the other side than in the float64 model)
   assert np.max(np.abs(dF - dF_ref)) < (1e-3 if bf else 2e-5) * np.max(np.abs(dF_ref))
+  if bf:
+    # round 5: the lag products read the spectra planes as they lie (transposing LDS reads, the rotated operand a register
+    # shuffle) where half-spectra and outputs tile the kernel; the round-4 form -- reduction-minor copies first -- is the same sum
+    # of the same bf16 products in another order
+    from speecht_amd._lib import launch_trace, set_tuning
+    with launch_trace() as tr:
+      call('st_conv1d_nwc_bwd_filter_fft_planes', xt.ref, dzt.ref, P(sf), P(zf), W, P(tables), P(dpacked), planes, P(ws), ws.numel() * 4, None)
+    direct = any(l.startswith('wgrad_tr_bf16<128,128,32,lag>') for l in tr.lines)
+    assert direct == ((cpi + 63) // 64 * 64 % 128 == 0 and npad.value % 128 == 0), tr.lines       # (half-spectrum columns, output columns)
+    if direct:
+      copies = torch.full((kp.value * npad.value,), 7.0, device=dev)
+      set_tuning('bf16_lag_copies', 1)
+      try:
+        with launch_trace() as tr2:
+          call('st_conv1d_nwc_bwd_filter_fft_planes', xt.ref, dzt.ref, P(sf), P(zf), W, P(tables), P(copies), planes, P(ws), ws.numel() * 4, None)
+      finally:
+        set_tuning('bf16_lag_copies', 0)
+      assert not any('lag' in l for l in tr2.lines) and any(l.startswith('gemm_nn_bf16<') for l in tr2.lines), tr2.lines
+      assert float((copies - dpacked).abs().max()) < 1e-5 * float(dpacked.abs().max())
   db = torch.full((npad.value,), 7.0, device=dev)
   call('st_conv1d_fft_bias_grad_dc_f32', P(dc), B * blocks.value, cout, npad.value, P(db), None)
   assert np.max(np.abs(db[:cout].cpu().numpy() - db_ref)) < 2e-5 * np.max(np.abs(db_ref))

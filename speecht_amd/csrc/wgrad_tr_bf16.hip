@@ -245,20 +245,48 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned
   if (cc < n_pad) part[(long)blockIdx.y * n_pad + cc] = cc < cp ? t : 0.f;
 }
 
-// dpacked = sum of the slabs (fixed order); dbias = sum of the column-sum partials (the first ceil(n_pad / 256) workgroups)
+// dpacked = sum of the slabs (fixed order); dbias = sum of the column-sum partials: the first n_pad / 32 workgroups take 32 columns
+// each, eight lanes per column summing every eighth chunk, then the eight in lane order (a fixed tree: deterministic)
 __global__ __launch_bounds__(256) void wgrad_tr_finish_kernel(const float* __restrict__ slabs, int n_slabs, size_t n4,
                                                               float* __restrict__ dpacked, const float* __restrict__ part, int chunks,
                                                               int n_pad, float* __restrict__ dbias) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < n_pad) {
+  __shared__ float red[8][33];
+  if ((int)blockIdx.x * 32 < n_pad) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
     float t = 0.f;
-    for (int k = 0; k < chunks; ++k) t += part[(long)k * n_pad + c];
-    dbias[c] = t;
+    if (c < n_pad) {
+      for (int k0 = r; k0 < chunks; k0 += 8 * 8) {               // eight loads in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = part[(long)min(k0 + 8 * k, chunks - 1) * n_pad + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + 8 * k < chunks) t += v[k];
+      }
+    }
+    red[r][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (r == 0 && c < n_pad) {
+      float a = red[0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) a += red[k][threadIdx.x];
+      dbias[c] = a;
+    }
   }
   if (slabs) {
+    // eight slabs' loads in flight at a time, added in slab order (a loop of one dependent load per slab was latency-bound: 21 us
+    // for the 16 MB of a 250-channel layer's nine slabs)
+    const f32x4* const src = reinterpret_cast<const f32x4*>(slabs);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-      f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
-      for (int s = 1; s < n_slabs; ++s) a += reinterpret_cast<const f32x4*>(slabs + (size_t)s * n4 * 4)[i];
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)min(s0 + k, n_slabs - 1) * n4 + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s0 + k < n_slabs) a += v[k];
+      }
       reinterpret_cast<f32x4*>(dpacked)[i] = a;
     }
   }
@@ -296,7 +324,7 @@ TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_lef
   t.stages_per_split = st::ceil_div(t.stages, splits);
   t.splits = st::ceil_div(t.stages, t.stages_per_split);
   t.slab_bytes = t.splits > 1 ? st::round_up((size_t)t.splits * width * x.c_pitch * t.n_pad * 4, 256) : 0;
-  t.chunks = 64;
+  t.chunks = std::max(64, std::min(256, 512 / st::ceil_div(t.n_pad, 256)));     // row chunks of the column sums: about 512 workgroups
   t.part_bytes = st::round_up((size_t)t.chunks * t.n_pad * 4, 256);
   return t;
 }
@@ -380,7 +408,7 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
   hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 256), t.chunks), dim3(256), 0, s, p.Z, z_rows, dz->c_pitch,
                      t.n_pad, part);
   const size_t n4 = (size_t)width * x->c_pitch * t.n_pad / 4;
-  const unsigned bias_blocks = (unsigned)st::ceil_div(t.n_pad, 256);
+  const unsigned bias_blocks = (unsigned)st::ceil_div(t.n_pad, 32);
   const unsigned sum_blocks = t.splits > 1 ? (unsigned)std::min<size_t>((n4 + 255) / 256, 2048) : 0u;
   hipLaunchKernelGGL(wgrad_tr_finish_kernel, dim3(std::max(bias_blocks, sum_blocks)), dim3(256), 0, s,
                      t.splits > 1 ? slabs : (const float*)nullptr, t.splits, n4, dpacked, part, t.chunks, t.n_pad, dbias);

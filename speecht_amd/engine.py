@@ -637,6 +637,14 @@ class Wav2LetterEngine(DecodeMixin):
     pinned, asynchronous copy each and a single event wait (a step's only host synchronisation).  float32 like
     tf.nn.ctc_loss; ``precise=True`` returns float64 = hi + lo of the kernel's (hi, lo) pairs (-log p to ~1e-6 where one
     fp32 ulp of a 10 s utterance's loss is 1.2e-4)."""
+    return self.fetch_losses_end(self.fetch_losses_begin(), precise)
+
+  def fetch_losses_begin(self):
+    """The read-back of `fetch_losses` enqueued where the stream stands NOW: losses, CTC status words, the update gate and the
+    library's lost-hand-off count go to pinned host memory behind everything enqueued so far, an event marks the copies.  Called
+    right behind `ctc_loss_grad`, with back-prop and the update enqueued after it, `fetch_losses_end` returns as soon as CTC is
+    through -- the host hands the loss back to its caller and prepares the next batch while the GPU is still in the backward pass
+    (single process only: under data parallelism the gate is all-reduced with the gradients and is final only after back-prop)."""
     B = self.loss.numel()
     if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < 2 * B:
       self._loss_host = (torch.empty(max(2 * B, 128), dtype=torch.float32, pin_memory=True),
@@ -650,6 +658,12 @@ class Wav2LetterEngine(DecodeMixin):
       status_h[:B].copy_(self.ctc_status, non_blocking=True)
       gate_h[:1].copy_(self.gate, non_blocking=True)
       event.record(stream)
+    return (B, lost_h)
+
+  def fetch_losses_end(self, handle, precise=False):
+    """Wait for the copies of `fetch_losses_begin`, check the status words (raises like `fetch_losses`), return the losses."""
+    B, lost_h = handle
+    loss_h, status_h, event, gate_h = self._loss_host
     event.synchronize()
     self._check_streamk_lost(lost_h)
     st = status_h[:B].numpy()

@@ -4,8 +4,8 @@
   bf16x6   the same with the wide 1 x 1 layers as fp32-accurate three-piece bf16 products (experimental, opt-in)
   bf16     bf16 activations and activation gradients, fp32 masters / accumulation / CTC / Adam (BASELINE configs[3])
 
-A mode object holds no tensors of its own: it reads and writes the engine's attributes (`ModeBase` forwards attribute access
-to the engine), so `eng.fft`, `eng.Xb`, ... stay where tests, bench.py and the profiling scripts look for them.
+A mode object holds no tensors of its own: it reads and writes the attributes of the engine it belongs to (`self.e`), so
+`eng.fft`, `eng.Xb`, ... stay where tests, bench.py and the profiling scripts look for them.
 """
 from .bf16 import Bf16Mode
 from .bf16x6 import Bf16x6Mode

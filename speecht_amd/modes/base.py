@@ -3,17 +3,12 @@
 
 class ModeBase:
   """A mode = the buffers derived from the weights and the activations that only this arithmetic needs, plus the launch
-  sequences of the forward and the backward pass.  State lives in the engine (shared buffers, streams, freshness flags):
-  attribute reads that the mode class does not define fall through to the engine, attribute writes go to the engine."""
+  sequences of the forward and the backward pass.  State lives in the engine core -- shared buffers, streams, freshness flags,
+  and the mode's own tensors too (`e.fft`, `e.Xb`, ...: where tests, bench.py and the profiling scripts look for them): a mode
+  holds a reference to its engine, `self.e`, and nothing else."""
 
   def __init__(self, engine):
-    object.__setattr__(self, 'e', engine)
-
-  def __getattr__(self, name):                       # only reached when the mode class has no such attribute
-    return object.__getattribute__(object.__getattribute__(self, 'e'), name)
-
-  def __setattr__(self, name, value):
-    setattr(object.__getattribute__(self, 'e'), name, value)
+    self.e = engine
 
   # ---- the interface -------------------------------------------------------------------------------------------
   def alloc(self, batch):

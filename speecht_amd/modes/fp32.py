@@ -20,28 +20,28 @@ class Fp32Mode(SpectralLayers, ModeBase):
   def alloc(self, batch):
     lib = _lib.load()
     ws = self._workspace_bytes(lib)
-    self.wgrad_ws, _ = self._storage.view('wgrad_ws', ws // 4 + 64)
+    self.e.wgrad_ws, _ = self.e._storage.view('wgrad_ws', ws // 4 + 64)
     # The classification layer (2000 -> 29): its filter gradient streams the activations, its back-prop to the input streams
     # the mask and writes dZ of the layer below -- two HBM-bound launches of ~90 us each that do not depend on each other.
     # Side by side on two streams (own scratch for the one on the side stream).
-    top = len(self.layers) - 1
-    self._side_wgrad_top = (self._top_gradient_beside and self.side_filter_gradient and os.environ.get('ST_WGRAD_SIDE_TOP', '1') != '0' and
-                            top > 0 and self.layers[top].cout <= 64 and self.layers[top].width == 1)
-    if self._side_wgrad_top:
-      ws_top = lib.st_conv1d_bwd_filter_ws(self.X[top].ref, self.dZ[top].ref, self.layers[top].width)
-      self.wgrad_ws_top, _ = self._storage.view('wgrad_ws_top', ws_top // 4 + 64)
+    top = len(self.e.layers) - 1
+    self.e._side_wgrad_top = (self._top_gradient_beside and self.e.side_filter_gradient and os.environ.get('ST_WGRAD_SIDE_TOP', '1') != '0' and
+                            top > 0 and self.e.layers[top].cout <= 64 and self.e.layers[top].width == 1)
+    if self.e._side_wgrad_top:
+      ws_top = lib.st_conv1d_bwd_filter_ws(self.e.X[top].ref, self.e.dZ[top].ref, self.e.layers[top].width)
+      self.e.wgrad_ws_top, _ = self.e._storage.view('wgrad_ws_top', ws_top // 4 + 64)
     # which layers run in the frequency domain is decided first: they leave the bf16x6 plane plumbing alone
-    self._fft_layers = {i for i in range(len(self.layers)) if self._use_fft(i, batch, self.geo[i][1])}
+    self.e._fft_layers = {i for i in range(len(self.e.layers)) if self._use_fft(i, batch, self.e.geo[i][1])}
     self._alloc_mode_planes()
     self._alloc_fft(batch)
 
   _top_gradient_beside = True
 
   def _workspace_bytes(self, lib):
-    ws = max(lib.st_conv1d_bwd_filter_ws(self.X[i].ref, self.dZ[i].ref, l.width) for i, l in enumerate(self.layers))
-    ws = max([ws] + [lib.st_conv1d_bwd_data_bias_ws(self.dZ[i].ref, self.dZ[i - 1].ref, l.width)
-                     for i, l in enumerate(self.layers) if i > 0])
-    return max([ws] + [lib.st_conv1d_fwd_ws(self.X[i].ref, self.X[i + 1].ref, l.width) for i, l in enumerate(self.layers)])
+    ws = max(lib.st_conv1d_bwd_filter_ws(self.e.X[i].ref, self.e.dZ[i].ref, l.width) for i, l in enumerate(self.e.layers))
+    ws = max([ws] + [lib.st_conv1d_bwd_data_bias_ws(self.e.dZ[i].ref, self.e.dZ[i - 1].ref, l.width)
+                     for i, l in enumerate(self.e.layers) if i > 0])
+    return max([ws] + [lib.st_conv1d_fwd_ws(self.e.X[i].ref, self.e.X[i + 1].ref, l.width) for i, l in enumerate(self.e.layers)])
 
   def _alloc_mode_planes(self):
     pass
@@ -76,21 +76,21 @@ class Fp32Mode(SpectralLayers, ModeBase):
     # the filter operands of back-prop (flipped / transposed copies of the weights Adam just updated) are rebuilt
     # on the side stream while the CTC recursion runs
     if not self._packed_t_ok() and self._flip_layers():
-      self._on_side_stream(self._refresh_backward_operands)
+      self.e._on_side_stream(self._refresh_backward_operands)
 
   def refresh_after_update(self):
     self._refresh_gfwd()          # the forward filter spectra of the frequency-domain layers for the next pass
 
   def prepare_forward_graph(self):
-    self._join_side_stream()
-    if self.fft and self.fft_conv and not self._gfwd_fresh:
+    self.e._join_side_stream()
+    if self.e.fft and self.e.fft_conv and not self.e._gfwd_fresh:
       self._refresh_fft_filters()
     self._wait_gfwd()                              # no waits on outside events inside a capture
 
   def _transposed_in_place(self, i):
     """Back-prop to the input of layer i reads the layer's own packed filters as a transposed operand
     (st_conv1d_1tap_bwd_data_bias_f32): one tap, whole 32-deep k-tiles over the output channels."""
-    l = self.layers[i]
+    l = self.e.layers[i]
     return (self._one_tap_in_place and i > 0 and l.width == 1 and l.stride == 1 and l.cout_pitch % 32 == 0 and
             l.n_pad >= l.cout_pitch and l.nt_pad % 128 == 0)
 
@@ -99,91 +99,91 @@ class Fp32Mode(SpectralLayers, ModeBase):
     more than one tap (and everything on the bf16x6 path, whose operand planes are split from those copies).  The
     frequency-domain layers read their forward spectra transposed, 1-tap layers their packed filters (round 4): at the
     model's training shapes NO copy is rebuilt any more (rounds 1-3: ~0.33 ms of HBM-bound launches per step)."""
-    return [i for i in range(1, len(self.layers))
-            if self._flip_every_layer or not ((i in self.fft and self.fft_conv) or self._transposed_in_place(i))]
+    return [i for i in range(1, len(self.e.layers))
+            if self._flip_every_layer or not ((i in self.e.fft and self.e.fft_conv) or self._transposed_in_place(i))]
 
   def _refresh_backward_operands(self):
     """The flipped / transposed weight copies of the layers that still need one (`_flip_layers`), top layer first, the order
     back-prop consumes them in; an event after each lets the compute stream wait for what it is about to use only."""
-    s = self.stream_ptr
-    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    self._bwd_ready = {}
+    s = self.e.stream_ptr
+    stream = self.e._stream if self.e._stream is not None else torch.cuda.current_stream(self.e.device)
+    self.e._bwd_ready = {}
     for i in reversed(self._flip_layers()):
-      l = self.layers[i]
-      call('st_filters_flip_transpose_f32', self._ptr(self._slice(self.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
-           l.cout_pitch, self._ptr(self.packed_t[i]), s)
+      l = self.e.layers[i]
+      call('st_filters_flip_transpose_f32', self.e._ptr(self.e._slice(self.e.params, i)[0]), l.width, l.cin, l.cout, l.cin_pitch,
+           l.cout_pitch, self.e._ptr(self.e.packed_t[i]), s)
       ev = torch.cuda.Event()
       ev.record(stream)
-      self._bwd_ready[i] = ev
-    self._packed_t_fresh = True
-    self._packed_t_layers = frozenset(self._flip_layers())
-    self._wtplanes_fresh = False
+      self.e._bwd_ready[i] = ev
+    self.e._packed_t_fresh = True
+    self.e._packed_t_layers = frozenset(self._flip_layers())
+    self.e._wtplanes_fresh = False
 
   def _packed_t_ok(self):
     """The flipped / transposed copies are current for every layer that needs one NOW: which layers do depends on state that
     can change between steps (the shape's frequency-domain set, `fft_conv`), so a refresh remembers the set it rebuilt."""
-    return self._packed_t_fresh and frozenset(self._flip_layers()) <= getattr(self, '_packed_t_layers', frozenset())
+    return self.e._packed_t_fresh and frozenset(self._flip_layers()) <= getattr(self.e, '_packed_t_layers', frozenset())
 
   def _wait_bwd_operands(self, i=None):
     """The compute stream waits for the back-prop operands of layer i (None: of every layer) if they were rebuilt on the
     side stream.  The side stream works top layer first, so a lower layer's event covers the ones above it."""
-    ready = getattr(self, '_bwd_ready', None)
+    ready = getattr(self.e, '_bwd_ready', None)
     if not ready:
       return
     keys = [k for k in ready if i is None or k >= i]
     if keys:
-      (self._stream if self._stream is not None else torch.cuda.current_stream(self.device)).wait_event(ready[min(keys)])
+      (self.e._stream if self.e._stream is not None else torch.cuda.current_stream(self.e.device)).wait_event(ready[min(keys)])
       for k in keys:
         del ready[k]
 
   def forward(self):
     """X[0] -> logits X[-1] through the eleven layers (speech_model.py:279-295): per layer the frequency-domain entry
     point, the W-tap kernel or -- in the bf16x6 mode -- that mode's kernel, as decided per shape by `_use_fft` / `_x6_fwd`."""
-    s = self.stream_ptr
+    s = self.e.stream_ptr
     self._forward_prologue()
     sf_ready = False                 # the previous layer's call left this layer's input spectra behind
-    for i, l in enumerate(self.layers):
-      pf, pb = self._slice(self.params, i)
-      if not (i in self.fft and self.fft_conv):
+    for i, l in enumerate(self.e.layers):
+      pf, pb = self.e._slice(self.e.params, i)
+      if not (i in self.e.fft and self.e.fft_conv):
         sf_ready = False
       if self._x6_fwd(i):
         self._x6_forward_layer(i, pb)
-      elif i in self.fft and self.fft_conv:
-        f = self.fft[i]
-        if not self._gfwd_fresh:
-          self._join_side_stream()
+      elif i in self.e.fft and self.e.fft_conv:
+        f = self.e.fft[i]
+        if not self.e._gfwd_fresh:
+          self.e._join_side_stream()
           self._refresh_fft_filters()
         self._wait_gfwd(i)                               # the filter spectra may still be on their way (side stream)
         # a chain of frequency-domain layers: where the shapes allow, this layer's inverse transform hands its frames to the
         # next layer's forward transform in registers and leaves that layer's input spectra behind (`sf_ready` for its call)
-        nxt = self.fft.get(i + 1) if self.fft_conv else None
+        nxt = self.e.fft.get(i + 1) if self.e.fft_conv else None
         if nxt is not None and nxt['shift'] is not None:
           nxt = None
         written = ctypes.c_int(0)
-        call('st_conv1d_nwc_fwd_fft_chain_f32', f['xref'], self._ptr(f['gfwd']), self._ptr(pb), f['width'], f['pl'],
-             int(l.relu), self.X[i + 1].ref, self._ptr(f['tables']), self._ptr(f['sf']), int(sf_ready),
-             self._ptr(nxt['tables']) if nxt else None, self._ptr(nxt['sf']) if nxt else None, nxt['width'] if nxt else 0,
-             nxt['pl'] if nxt else 0, ctypes.byref(written), self._ptr(f['ws']), f['ws'].numel() * 4, s)
+        call('st_conv1d_nwc_fwd_fft_chain_f32', f['xref'], self.e._ptr(f['gfwd']), self.e._ptr(pb), f['width'], f['pl'],
+             int(l.relu), self.e.X[i + 1].ref, self.e._ptr(f['tables']), self.e._ptr(f['sf']), int(sf_ready),
+             self.e._ptr(nxt['tables']) if nxt else None, self.e._ptr(nxt['sf']) if nxt else None, nxt['width'] if nxt else 0,
+             nxt['pl'] if nxt else 0, ctypes.byref(written), self.e._ptr(f['ws']), f['ws'].numel() * 4, s)
         sf_ready = written.value == 1
         continue
       else:
-        call('st_conv1d_nwc_fwd_ws_f32', self.X[i].ref, self._ptr(pf), self._ptr(pb), l.width, l.stride,
-             self.geo[i][2], int(l.relu), self.X[i + 1].ref, self._ptr(self.wgrad_ws),
-             self.wgrad_ws.numel() * 4 if self.split_small_batches else 0, s)
+        call('st_conv1d_nwc_fwd_ws_f32', self.e.X[i].ref, self.e._ptr(pf), self.e._ptr(pb), l.width, l.stride,
+             self.e.geo[i][2], int(l.relu), self.e.X[i + 1].ref, self.e._ptr(self.e.wgrad_ws),
+             self.e.wgrad_ws.numel() * 4 if self.e.split_small_batches else 0, s)
 
   def backward(self, on_layer_done, wanted):
     """Back-prop from dZ[-1] through the frequency-domain / W-tap (/ bf16x6) kernels; hooks as `Wav2LetterEngine.backward`
     describes them."""
-    s = self.stream_ptr
+    s = self.e.stream_ptr
     if not self._packed_t_ok():
       self._refresh_backward_operands()           # (normally done on the side stream by ctc_loss_grad; nothing at the model's shapes)
-    if self.fft and self.fft_conv and not self._gfwd_fresh:
-      self._join_side_stream()                    # (weights written after the forward pass: back-prop reads the same spectra)
+    if self.e.fft and self.e.fft_conv and not self.e._gfwd_fresh:
+      self.e._join_side_stream()                    # (weights written after the forward pass: back-prop reads the same spectra)
       self._refresh_fft_filters()
     self._wait_gfwd()
     self._backward_prologue()
     # waits per layer; after the two layers on top one wait covers everything below (by then the side stream is through)
-    wait_all_below = len(self.layers) - 3
+    wait_all_below = len(self.e.layers) - 3
     side_wgrad, deferred = False, None     # a filter gradient is in flight on the side stream; its layer's hook is due
     top_pending = None                     # the classification layer's filter gradient is in flight on the second side stream
     hook = on_layer_done
@@ -191,38 +191,38 @@ class Fp32Mode(SpectralLayers, ModeBase):
       def on_layer_done(j):
         nonlocal top_pending
         if top_pending is not None and top_pending != j:
-          self._join_side_stream(second_only=True)
+          self.e._join_side_stream(second_only=True)
           hook(top_pending)
           top_pending = None
         if top_pending != j:
           hook(j)
     bias_from_above = False      # layer i's bias gradient already written by the back-prop kernel of layer i + 1
     zf_ready = False             # layer i's dz spectra already written by the back-prop kernel of layer i + 1
-    for i in reversed(range(len(self.layers))):
-      l = self.layers[i]
-      gf, gb = self._slice(self.grads, i)
+    for i in reversed(range(len(self.e.layers))):
+      l = self.e.layers[i]
+      gf, gb = self.e._slice(self.e.grads, i)
       need_bias, bias_from_above = not bias_from_above, False
       if self._x6_wgrad(i):
         self._x6_filter_gradient(i, gf, gb, need_bias)
-      elif i in self.fft and self.fft_conv:
-        f = self.fft[i]
+      elif i in self.e.fft and self.e.fft_conv:
+        f = self.e.fft[i]
         # the spectra of dz serve the filter gradient here and back-prop to the input below (the layer above may have left
         # them behind already: its back-prop kernel transformed the frames it had just produced, `zf_ready`)
         if not zf_ready:
-          call('st_conv1d_fft_dz_spectra_f32', self.dZ[i].ref, f['width'], self._ptr(f['tables']), self._ptr(f['zf']), s)
+          call('st_conv1d_fft_dz_spectra_f32', self.e.dZ[i].ref, f['width'], self.e._ptr(f['tables']), self.e._ptr(f['zf']), s)
         zf_ready = False
         polyphase = f['shift'] is not None       # the gradient comes out in the shifted layout of the polyphase taps
 
         def filter_gradient(f=f, l=l, i=i, gf=gf, gb=gb, need_bias=need_bias, polyphase=polyphase, ws=f.get('ws2', f['ws'])):
-          call('st_conv1d_nwc_bwd_filter_fft_f32', f['xref'], self.dZ[i].ref, self._ptr(f['sf']), self._ptr(f['zf']), f['width'],
-               self._ptr(f['tables']), self._ptr(f['dpacked2'] if polyphase else gf), self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+          call('st_conv1d_nwc_bwd_filter_fft_f32', f['xref'], self.e.dZ[i].ref, self.e._ptr(f['sf']), self.e._ptr(f['zf']), f['width'],
+               self.e._ptr(f['tables']), self.e._ptr(f['dpacked2'] if polyphase else gf), self.e._ptr(ws), ws.numel() * 4, self.e.stream_ptr)
           if polyphase:
-            cp = self.X[i].c_pitch
+            cp = self.e.X[i].c_pitch
             n, o = l.width * cp * l.n_pad, f['shift'] * cp * l.n_pad
-            with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream(self.device)):
+            with torch.cuda.stream(self.e._stream if self.e._stream is not None else torch.cuda.current_stream(self.e.device)):
               gf[:n].copy_(f['dpacked2'][o:o + n], non_blocking=True)
           if need_bias:      # bin 0 of the spectra is the sum over the frames
-            call('st_conv1d_fft_bias_grad_f32', self.dZ[i].ref, f['width'], self._ptr(f['zf']), self._ptr(gb), self.stream_ptr)
+            call('st_conv1d_fft_bias_grad_f32', self.e.dZ[i].ref, f['width'], self.e._ptr(f['zf']), self.e._ptr(gb), self.e.stream_ptr)
         if 'ws2' in f:
           # The filter gradient (lag products, inverse transform of the filters, bias sum) and back-prop to the input
           # (products, inverse transform) both hang off the spectra of dz and are independent: on two streams.  The
@@ -231,64 +231,64 @@ class Fp32Mode(SpectralLayers, ModeBase):
           # matrix-pipe-bound products of the other (measured: 7.84 -> 7.43 ms per step).
           # (round 4: with back-prop's transforms fused the compute stream needs ~80 us per narrow layer, ONE side stream's
           # chain -- 73 + 42 + 9 us, in order -- had become the pace of the backward pass: the chains take the two side streams in turn)
-          self._on_side_stream(filter_gradient, second=(i % 2 == 1))
+          self.e._on_side_stream(filter_gradient, second=(i % 2 == 1))
           side_wgrad, deferred = True, i
         else:
           filter_gradient()
-      elif i + 1 == len(self.layers) and self._side_wgrad_top:
-        def top_gradient(i=i, l=l, gf=gf, gb=gb, need_bias=need_bias, ws=self.wgrad_ws_top):
-          call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
-               self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(ws), ws.numel() * 4, self.stream_ptr)
+      elif i + 1 == len(self.e.layers) and self.e._side_wgrad_top:
+        def top_gradient(i=i, l=l, gf=gf, gb=gb, need_bias=need_bias, ws=self.e.wgrad_ws_top):
+          call('st_conv1d_nwc_bwd_filter_f32', self.e.X[i].ref, self.e.dZ[i].ref, l.width, l.stride, self.e.geo[i][2],
+               self.e._ptr(gf), self.e._ptr(gb) if need_bias else None, self.e._ptr(ws), ws.numel() * 4, self.e.stream_ptr)
         # on the SECOND side stream (the first is still rebuilding back-prop operands when CTC ends); its hook is due with
         # the next layer's -- the two share a reduce bucket, and nothing waits for this launch until then
-        self._on_side_stream(top_gradient, second=True)
+        self.e._on_side_stream(top_gradient, second=True)
         top_pending = i
       else:
-        call('st_conv1d_nwc_bwd_filter_f32', self.X[i].ref, self.dZ[i].ref, l.width, l.stride, self.geo[i][2],
-             self._ptr(gf), self._ptr(gb) if need_bias else None, self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+        call('st_conv1d_nwc_bwd_filter_f32', self.e.X[i].ref, self.e.dZ[i].ref, l.width, l.stride, self.e.geo[i][2],
+             self.e._ptr(gf), self.e._ptr(gb) if need_bias else None, self.e._ptr(self.e.wgrad_ws), self.e.wgrad_ws.numel() * 4, s)
       if on_layer_done is not None and deferred != i and wanted(i):
         if side_wgrad:
           # this layer's own gradient ran on the compute stream, but its bucket also holds the layers above whose filter
           # gradients are still in flight on the side streams (the bottom bucket L0..L3: L1-L3 went there, L0 did not): the
           # exchange is ordered behind the compute stream only, so the compute stream waits for them first
-          self._join_side_stream()
+          self.e._join_side_stream()
           side_wgrad = False
         on_layer_done(i)
       if i > 0 and self._x6_bwd(i):
         self._x6_back_prop(i)
-      elif i > 0 and i in self.fft and self.fft_conv:
-        f = self.fft[i]
-        act = self.X[i].ref if self.layers[i - 1].relu else None
-        below = self.fft.get(i - 1)                # a frequency-domain layer below: its dz spectra can ride along
+      elif i > 0 and i in self.e.fft and self.e.fft_conv:
+        f = self.e.fft[i]
+        act = self.e.X[i].ref if self.e.layers[i - 1].relu else None
+        below = self.e.fft.get(i - 1)                # a frequency-domain layer below: its dz spectra can ride along
         written = ctypes.c_int(0)
-        call('st_conv1d_nwc_bwd_data_fft_chain_f32', self.dZ[i].ref, self._ptr(f['zf']), self._ptr(f['gfwd']), l.width,
-             self.geo[i][2], act, self.dZ[i - 1].ref, self._ptr(f['tables']), self._ptr(below['tables']) if below else None,
-             self._ptr(below['zf']) if below else None, below['width'] if below else 0, ctypes.byref(written), self._ptr(f['ws']),
+        call('st_conv1d_nwc_bwd_data_fft_chain_f32', self.e.dZ[i].ref, self.e._ptr(f['zf']), self.e._ptr(f['gfwd']), l.width,
+             self.e.geo[i][2], act, self.e.dZ[i - 1].ref, self.e._ptr(f['tables']), self.e._ptr(below['tables']) if below else None,
+             self.e._ptr(below['zf']) if below else None, below['width'] if below else 0, ctypes.byref(written), self.e._ptr(f['ws']),
              f['ws'].numel() * 4, s)
         zf_ready = written.value == 1
       elif i > 0:
         # X[i] is the ReLU output of layer i-1: its sign is the mask of tf.nn.relu's gradient
         # the kernel that writes dZ[i-1] also sums its columns: the bias gradient of layer i - 1
-        act = self.X[i].ref if self.layers[i - 1].relu else None
+        act = self.e.X[i].ref if self.e.layers[i - 1].relu else None
         if self._transposed_in_place(i):           # dx = dz W^T straight from the layer's packed filters
-          call('st_conv1d_1tap_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self._slice(self.params, i)[0]), act, self.dZ[i - 1].ref,
-               self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws), self.wgrad_ws.numel() * 4, s)
+          call('st_conv1d_1tap_bwd_data_bias_f32', self.e.dZ[i].ref, self.e._ptr(self.e._slice(self.e.params, i)[0]), act, self.e.dZ[i - 1].ref,
+               self.e._ptr(self.e._slice(self.e.grads, i - 1)[1]), self.e._ptr(self.e.wgrad_ws), self.e.wgrad_ws.numel() * 4, s)
         else:
           self._wait_bwd_operands(i if i > wait_all_below else None)
-          call('st_conv1d_nwc_bwd_data_bias_f32', self.dZ[i].ref, self._ptr(self.packed_t[i]), l.width, self.geo[i][2],
-               act, self.dZ[i - 1].ref, self._ptr(self._slice(self.grads, i - 1)[1]), self._ptr(self.wgrad_ws),
-               self.wgrad_ws.numel() * 4, s)
+          call('st_conv1d_nwc_bwd_data_bias_f32', self.e.dZ[i].ref, self.e._ptr(self.e.packed_t[i]), l.width, self.e.geo[i][2],
+               act, self.e.dZ[i - 1].ref, self.e._ptr(self.e._slice(self.e.grads, i - 1)[1]), self.e._ptr(self.e.wgrad_ws),
+               self.e.wgrad_ws.numel() * 4, s)
         bias_from_above = True
       if deferred == i and on_layer_done is not None and wanted(i):
         # the gradient of this layer is complete when the side stream is (and with it those of the layers above that went
         # the same way: the stream runs in order): hand the bucket to the all-reduce only now, with back-prop to the input
         # already enqueued beside it
-        self._join_side_stream()
+        self.e._join_side_stream()
         side_wgrad = False
         on_layer_done(i)
       if deferred == i:
         deferred = None
     if side_wgrad or top_pending is not None:
-      self._join_side_stream()
+      self.e._join_side_stream()
     if top_pending is not None and hook is not None:
       hook(top_pending)

@@ -373,6 +373,10 @@ class SpeechModel:
       else:
         # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
         eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
+      # single process: the loss read-back is enqueued right behind CTC and waited for after back-prop and the update have been
+      # enqueued -- step() returns while the GPU is still in the backward pass, and the caller's next step() overlaps its host
+      # side (dequeue, batch hand-over, first launches) with it.  (Data parallel: the gate is final only after the exchange.)
+      early = eng.fetch_losses_begin() if (self._world == 1 and not use_graph) else None
       if update and not use_graph:
         if not self._training:
           raise RuntimeError('add_training_ops() was not called with labelled inputs')
@@ -382,7 +386,8 @@ class SpeechModel:
         eng.apply_update(self.learning_rate.value, self.max_gradient_norm)   # no-op on the device if CTC rejected the batch
       # raises on a CTC status word (of any rank) -- before global_step moves: like TF's failed sess.run, a rejected
       # batch leaves weights, Adam state and counters as they were
-      avg_loss = np.float32(eng.fetch_losses(precise=True).mean())     # mean of -log p in float64, returned as TF's float32
+      losses = eng.fetch_losses_end(early, precise=True) if early is not None else eng.fetch_losses(precise=True)
+      avg_loss = np.float32(losses.mean())     # mean of -log p in float64, returned as TF's float32
       if update:
         self.global_step.value += 1
       if self._world > 1:

@@ -22,7 +22,7 @@ class Flags:
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--steps', type=int, default=40)
+  ap.add_argument('--steps', type=int, default=100)
   ap.add_argument('--conv-mode', default=None)
   ap.add_argument('--graph', action='store_true', help='model.step_graph = True: the training step as one HIP-graph launch')
   args = ap.parse_args()

@@ -1007,7 +1007,14 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
     f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
-    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(slabs)[i + k * n4];
+    for (int k0 = 1; k0 < splits; k0 += 8) {                     // eight slabs' loads in flight, added in slab order
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const f32x4*>(slabs)[i + (long)min(k0 + j, splits - 1) * n4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < splits) s += v[j];
+    }
     reinterpret_cast<f32x4*>(dst)[i] = s;
   }
 }
@@ -1048,8 +1055,18 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < np)
-    for (int k = r; k < chunks; k += 8) s += partial[(long)k * np + c];
+  if (c < np) {
+    // eight loads in flight, added in chunk order: a loop of one load per ordered add is a latency chain (round 5: the 252
+    // partial rows of the 2000 x 2000 layer took 15-17 us this way, twice per step on the compute stream)
+    for (int k0 = r; k0 < chunks; k0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = partial[(long)min(k0 + 8 * j, chunks - 1) * np + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + 8 * j < chunks) s += v[j];
+    }
+  }
   red[r][cl] = s;
   __syncthreads();
   if (r == 0 && c < np) {

@@ -50,7 +50,7 @@ def main():
                             None if last else eng._ptr(eng.Xb[i + 1]), eng._ptr(eng.X[i + 1].buf) if last else None,
                             ws, wsb, s), args.reps)
     gf, gb = eng._slice(eng.grads, i)
-    w = timeit(lambda: call('st_conv1d_nwc_bwd_filter_bf16', eng.X[i].ref, eng._ptr(eng.Xb[i]), eng.dZ[i].ref,
+    w = timeit(lambda: call('st_conv1d_nwc_bwd_filter_tr_bf16' if eng._wgrad_tr[i] else 'st_conv1d_nwc_bwd_filter_bf16', eng.X[i].ref, eng._ptr(eng.Xb[i]), eng.dZ[i].ref,
                             eng._ptr(eng.dZb[i]), l.width, l.stride, pl, eng._ptr(gf), eng._ptr(gb), ws, wsb, s), args.reps)
     d = 0.0
     if i > 0:

@@ -1269,6 +1269,8 @@ int st_conv1d_nwc_fwd_ws_bf16(const st_tensor3* x, const void* x_bf16, const voi
                  x->batch == y->batch && x->c_pitch % 16 == 0 && y->c_pitch % 16 == 0,
              "conv fwd bf16: bad geometry");
   ST_REQUIRE(x->halo - pad_left + (y->frames - 1) * stride + width <= x->t_pitch, "conv fwd bf16: right halo too small");
+  if (stride == 1 && y_bf16 && !y_f32 && st::conv_taps_bf16_eligible(*x, *y, width, pad_left, nullptr))
+    return st::conv_taps_bf16(*x, x_bf16, wt_bf16, bias, width, pad_left, relu, nullptr, nullptr, *y, y_bf16, st::as_stream(stream));
   int splits = fwd_splits(*x, *y, width);
   if (!workspace || workspace_bytes < st_conv1d_fwd_bf16_ws(x, y, width)) splits = 1;
   return conv_fwd<1>(x, x_bf16, wt_bf16, bias, width, stride, pad_left, relu, y, y_f32, y_bf16, st::as_stream(stream),
@@ -1298,6 +1300,8 @@ int st_conv1d_nwc_bwd_data_bf16(const st_tensor3* dz, const void* dz_bf16, const
              "conv bwd-data bf16: bad geometry (stride-1 layers only)");
   ST_REQUIRE(!act || (act->frames == dx->frames && act->batch == dx->batch && act->c_pitch >= dx->c_pitch),
              "conv bwd-data bf16: mask geometry");
+  if (st::conv_taps_bf16_eligible(*dz, *dx, width, lead, act))
+    return st::conv_taps_bf16(*dz, dz_bf16, wtt_bf16, nullptr, width, lead, 0, act, act_bf16, *dx, dx_bf16, st::as_stream(stream));
   const int splits = bwd_data_splits(*dz, *dx, width);
   const size_t need = st_conv1d_bwd_data_bf16_ws(dz, dx, width);
   if (need && (!workspace || workspace_bytes < need)) {

@@ -40,7 +40,7 @@ inline void launch_timed(const LaunchTimer& t, void (*kernel)(KArgs...), const d
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
        TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_STREAMK_SLOTS, TUNE_NO_FUSED_TRANSFORMS,
-       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_COUNT };
+       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_BF16_WGRAD_RING, TUNE_BF16_TAPS_PANEL, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
@@ -61,6 +61,11 @@ int gemm_bf16_bins(int planes, const void* a_planes, size_t a_plane, long a_rows
                    int b_bin_shift = 0);
 // wgrad_tr_bf16.hip: the lag products of the filter gradient straight from the spectra planes (LDS transposing reads)
 int lag_products_tr_bf16(const void* s_plane, const void* z_plane, int bins, int rows, int half, int npo, float* q, hipStream_t s);
+// conv_taps_bf16.hip: stride-1 W-tap layers on 256-channel bf16 rows with the input panel resident in LDS (tap w of output frame
+// t reads operand frame t + w - lead; `act`: keep the result where the bf16 plane of `act` is positive)
+bool conv_taps_bf16_eligible(const st_tensor3& a, const st_tensor3& y, int width, int lead, const st_tensor3* act);
+int conv_taps_bf16(const st_tensor3& a, const void* a_plane, const void* filters, const float* bias, int width, int lead, int relu,
+                   const st_tensor3* act, const void* act_plane, const st_tensor3& y, void* y_plane, hipStream_t s);
 int transpose_bf16_bins(const void* src, void* dst, int bins, int rows, int cols, hipStream_t s);
 int transpose_bf16_bins_split(const void* src, void* dst, int bins, int rows, int cols, int forms, hipStream_t s);
 

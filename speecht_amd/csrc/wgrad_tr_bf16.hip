@@ -14,7 +14,8 @@
 // 256-byte rows) and transposed on their way into the registers: two reads per 32 x 16 fragment, no copy, no extra pass.
 //
 // Tile 128 (input channels of one tap) x 128 (output channels), four waves of 64 x 64, 32 reduction rows per stage in a ring of
-// four 16 KB stages (two workgroups per CU), counted vmcnt + one barrier per stage.  LDS image of a stage: [32 rows][16 chunks of
+// four 16 KB stages (two workgroups per CU) -- eight when the grid gives a CU one workgroup anyway (seven stages in flight hide
+// more of the fabric latency) --, counted vmcnt + one barrier per stage, fragments read one stage ahead of their MFMAs.  LDS image of a stage: [32 rows][16 chunks of
 // 16 bytes], physical chunk = chunk ^ (4 * (row & 3)) applied on the SOURCE side of the DMA: the four rows a transposing read
 // touches land in four different quarter-rows, so the 32 lanes of a half-wave cover all 64 banks exactly once.
 // The reduction is cut into `splits` contiguous runs of stages whose fp32 slabs wgrad_tr_finish_kernel sums in a fixed order
@@ -23,6 +24,7 @@
 // Contract with the caller (st_conv1d_nwc_bwd_filter_tr_bf16): both planes are READABLE and ZERO for 40 rows behind their last
 // row (the last stage and the last taps read past the end; what they read meets zero gradient rows).
 #include <algorithm>
+#include <type_traits>
 
 #include "st_common.h"
 
@@ -37,7 +39,6 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int TM = 128, TN = 128, TK = 32;         // tile: input channels x output channels x reduction rows per stage
-constexpr int ST = 4;                              // LDS ring depth
 constexpr int STAGE_ELEMS = TK * 128;              // bf16 elements of one operand's stage (32 rows x 256 bytes)
 constexpr int SLACK_ROWS = 40;
 
@@ -89,8 +90,8 @@ __device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
 // 2 r + 1 is MINUS half-row 2 r: inside a fragment of four consecutive reduction rows the pairs change places and the odd ones
 // change sign -- a 16-bit rotation and a sign-bit flip of each 32-bit word, exact in bf16.  Rounds 4's reduction-minor copies of
 // both spectra (transpose_bf16_bins_split, 52 us per step) and the rotated copy they formed are not made any more.
-template <bool LAG>
-__global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
+template <bool LAG, int ST>
+__global__ __launch_bounds__(256, ST <= 4 ? 2 : 1) void wgrad_tr_bf16_kernel(TrParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ST * STAGE_ELEMS];
   unsigned short* const As = smem;                              // [ST][32][128]
   unsigned short* const Bs = smem + ST * STAGE_ELEMS;
@@ -149,46 +150,85 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(TrParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int kt = 0; kt < ST - 1 && kt < nk; ++kt) issue(kt);
-  for (int kt = 0; kt < nk; ++kt) {
+  // One stage BEHIND: the sixteen transposing reads of stage kt are issued after its barrier and return while the eight MFMAs
+  // of stage kt - 1 run from the registers filled an iteration earlier (a workgroup alone on its CU used to wait for the first
+  // k-step's reads with nothing to do: 0.32 us per stage for 0.11 us of MFMAs).  Ring slot kt - 1 is free for the DMA of stage
+  // kt + ST - 1 all the same: its reads were waited for (lds_wait) before this stage's barrier.
+  // A wave issues in order: sixteen reads in a row hold the MFMAs behind them back for as long as the LDS takes to accept them, so
+  // a stage is issued as eight groups -- one MFMA of the stage in hand, up to three fragment reads of the next stage in its
+  // 32-cycle shadow, none under the last two (they cover the latency of the last read) -- with a scheduling fence after each.
+  // k-step 0 of a stage: rows 0..15 (reads at +0 and +4 rows); k-step 1: +16 and +20 rows.
+  auto step = [&](auto do_mul, auto do_read, u64 (&p0)[8], u64 (&p1)[8], u64 (&n0)[8], u64 (&n1)[8], int kt) {
+    constexpr bool M = decltype(do_mul)::value, R = decltype(do_read)::value;
+    const unsigned so = (unsigned)((kt % ST) * STAGE_ELEMS * 2);
+    const unsigned a0 = a_at[0] + so, a1 = a_at[1] + so, b0 = b_at[0] + so, b1 = b_at[1] + so;
+    bf16x8 fa0{}, fa1{}, fb0{}, fb1{};
+    auto frags = [&](u64 (&r)[8]) {
+      if (LAG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = rotate_rows(r[q], rot);
+      }
+      fa0 = frag_of(r[0], r[1]), fa1 = frag_of(r[2], r[3]), fb0 = frag_of(r[4], r[5]), fb1 = frag_of(r[6], r[7]);
+    };
+    if (M) frags(p0);
+    if (M) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+    if (R) n0[0] = lds_read_tr16<0>(a0), n0[1] = lds_read_tr16<1024>(a0), n0[2] = lds_read_tr16<0>(a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+    if (R) n0[3] = lds_read_tr16<1024>(a1), n0[4] = lds_read_tr16<0>(b0), n0[5] = lds_read_tr16<1024>(b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+    if (R) n0[6] = lds_read_tr16<0>(b1), n0[7] = lds_read_tr16<1024>(b1), n1[0] = lds_read_tr16<4096>(a0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    if (R) n1[1] = lds_read_tr16<5120>(a0), n1[2] = lds_read_tr16<4096>(a1), n1[3] = lds_read_tr16<5120>(a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) frags(p1);
+    if (M) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+    if (R) n1[4] = lds_read_tr16<4096>(b0), n1[5] = lds_read_tr16<5120>(b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+    if (R) n1[6] = lds_read_tr16<4096>(b1), n1[7] = lds_read_tr16<5120>(b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (M) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+    if (M) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const std::true_type yes{};
+  const std::false_type no{};
+  auto land = [&](int kt) {
     // this wave's pieces of stage kt have landed when at most the younger stages' (4 instructions each) are outstanding
-    // (a bare s_barrier: __syncthreads() is a fence too and would drain every DMA in flight -- vmcnt(0) -- each stage.  The
-    // fragment reads of stage kt - 1 are complete: the MFMAs that consumed them have been issued.)
+    // (a bare s_barrier: __syncthreads() is a fence too and would drain every DMA in flight -- vmcnt(0) -- each stage)
     if (kt + ST - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (ST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + ST - 1 < nk) issue(kt + ST - 1);                    // into the slot of stage kt - 1: everyone is past reading it
-    const unsigned so = (unsigned)((kt % ST) * STAGE_ELEMS * 2);
-    const unsigned a0 = a_at[0] + so, a1 = a_at[1] + so, b0 = b_at[0] + so, b1 = b_at[1] + so;
-    // k-step 0 (rows 0..15 of the stage: reads at +0 and +4 rows), then k-step 1 (+16, +20 rows); the second k-step's reads are
-    // issued before the first one's MFMAs and return under them
-    u64 r0[8] = {lds_read_tr16<0>(a0), lds_read_tr16<1024>(a0), lds_read_tr16<0>(a1), lds_read_tr16<1024>(a1),
-                 lds_read_tr16<0>(b0), lds_read_tr16<1024>(b0), lds_read_tr16<0>(b1), lds_read_tr16<1024>(b1)};
-    lds_wait(r0);
-    u64 r1[8] = {lds_read_tr16<4096>(a0), lds_read_tr16<5120>(a0), lds_read_tr16<4096>(a1), lds_read_tr16<5120>(a1),
-                 lds_read_tr16<4096>(b0), lds_read_tr16<5120>(b0), lds_read_tr16<4096>(b1), lds_read_tr16<5120>(b1)};
-    if (LAG) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r0[q] = rotate_rows(r0[q], rot);
-    }
-    {
-      const bf16x8 fa0 = frag_of(r0[0], r0[1]), fa1 = frag_of(r0[2], r0[3]), fb0 = frag_of(r0[4], r0[5]), fb1 = frag_of(r0[6], r0[7]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
-    }
-    lds_wait(r1);
-    if (LAG) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r1[q] = rotate_rows(r1[q], rot);
-    }
-    {
-      const bf16x8 fa0 = frag_of(r1[0], r1[1]), fa1 = frag_of(r1[2], r1[3]), fb0 = frag_of(r1[4], r1[5]), fb1 = frag_of(r1[6], r1[7]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
-    }
+  };
+
+  for (int kt = 0; kt < ST - 1 && kt < nk; ++kt) issue(kt);
+  u64 e0[8], e1[8], o0[8], o1[8];                                // fragments of the even / the odd stages
+  land(0);
+  step(no, yes, o0, o1, e0, e1, 0);
+  lds_wait(e0);
+  lds_wait(e1);
+  int kt = 1;
+  for (; kt + 1 < nk; kt += 2) {
+    land(kt);
+    step(yes, yes, e0, e1, o0, o1, kt);
+    lds_wait(o0);
+    lds_wait(o1);
+    land(kt + 1);
+    step(yes, yes, o0, o1, e0, e1, kt + 1);
+    lds_wait(e0);
+    lds_wait(e1);
+  }
+  if (kt < nk) {                                                 // an even number of stages: one odd stage is left
+    land(kt);
+    step(yes, yes, e0, e1, o0, o1, kt);
+    lds_wait(o0);
+    lds_wait(o1);
+    step(yes, no, o0, o1, e0, e1, 0);
+  } else {
+    step(yes, no, e0, e1, o0, o1, 0);
   }
 
   // out[split][w * cp + c][n]: accumulator r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
@@ -358,7 +398,7 @@ int st::lag_products_tr_bf16(const void* s_plane, const void* z_plane, int bins,
             2e-9 * 2.0 * bins * half * (double)npo * 2.0 * rows);
   {
     st::LaunchTimer timer(s);
-    st::launch_timed(timer, wgrad_tr_bf16_kernel<true>, dim3((unsigned)(bins * p.tiles_m * p.tiles_n), 2), dim3(256), s, p);
+    st::launch_timed(timer, wgrad_tr_bf16_kernel<true, 4>, dim3((unsigned)(bins * p.tiles_m * p.tiles_n), 2), dim3(256), s, p);
   }
   return st::check_launch("lag_products_tr_bf16");
 }
@@ -401,7 +441,12 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
             t.splits, 2e-9 * (double)t.stages * TK * t.tiles_m * TM * t.tiles_n * TN);
   {
     st::LaunchTimer timer(s);
-    st::launch_timed(timer, wgrad_tr_bf16_kernel<false>, dim3((unsigned)(t.splits * t.tiles_m * t.tiles_n)), dim3(256), s, p);
+    // ring depth: a grid of about one workgroup per CU cannot hide the fabric latency behind a second workgroup: eight 16 KB
+    // stages (seven in flight) instead of four, the whole LDS for the one workgroup a CU gets anyway
+    const unsigned grid = (unsigned)(t.splits * t.tiles_m * t.tiles_n);
+    const int ring = st::tuning(st::TUNE_BF16_WGRAD_RING) ? st::tuning(st::TUNE_BF16_WGRAD_RING) : (grid <= 320 ? 8 : 4);
+    if (ring == 8) st::launch_timed(timer, wgrad_tr_bf16_kernel<false, 8>, dim3(grid), dim3(256), s, p);
+    else st::launch_timed(timer, wgrad_tr_bf16_kernel<false, 4>, dim3(grid), dim3(256), s, p);
   }
   if (int e = st::check_launch("wgrad_tr_bf16")) return e;
   const long z_rows = (long)dz->batch * dz->t_pitch;

@@ -138,19 +138,23 @@ class Bf16Mode(ModeBase):
 
   def _refresh_wb_after_update(self):
     """After an update: the bottom layer's bf16 filter copy on the compute stream (the next forward pass needs it at
-    once), the others on the side stream, bottom layer first, an event per layer -- the forward pass waits layer by
-    layer instead of for the whole list (eleven small kernels, ~130 us end to end, during which the chip was idle)."""
+    once), the others on the side stream -- the small copies bottom layer first, the frequency-domain layers' filter spectra
+    (L9: a 16 M-weight transform and its second operand layout, 0.16 ms) LAST, an event per layer: the forward pass waits for
+    what a layer reads, not for the whole list, and the spectra are built beside the eight layers below them."""
     L = len(self.e.layers)
     self.e._wb_ready = {}
     self._refresh_bf16_filters(False, layers=[0])
+    fftb = getattr(self.e, 'fftb', {})
+    order = [i for i in range(1, L) if i not in fftb] + [i for i in range(1, L) if i in fftb]
 
     def rest():
-      for i in range(1, L):
+      for i in order:
         self._refresh_bf16_filters(False, layers=[i])
         ev = torch.cuda.Event()
         ev.record(self.e._stream)
         self.e._wb_ready[i] = ev
     self.e._on_side_stream(rest)
+    self.e._wb_order = order
     self.e._wplanes_fresh = True
 
   def _forward_bf16(self):
@@ -164,14 +168,17 @@ class Bf16Mode(ModeBase):
     call('st_cast_bf16', self.e._ptr(self.e.X[0].buf), self.e.X[0].buf.numel(), self.e._ptr(self.e.Xb[0]), s)
     for i, l in enumerate(self.e.layers):
       last = i + 1 == L
-      if ready:
-        # the side stream works bottom layer first: the first layers wait for their own copy, the fourth for all that
-        # remain (by then the side stream is through; every wait costs the compute stream a few microseconds)
-        if i >= 3:
-          main.wait_event(ready[L - 1])
-          ready.clear()
-        elif i in ready:
+      if i in ready:
+        # the side stream works in self.e._wb_order: the first layers wait for their own copy, the fourth for every small copy
+        # (by then they are through; every wait costs the compute stream a few microseconds), a frequency-domain layer for its
+        # own spectra
+        if i in self.e.fftb or i < 3:
           main.wait_event(ready.pop(i))
+        else:
+          small = [j for j in self.e._wb_order if j not in self.e.fftb]
+          main.wait_event(ready[small[-1]])
+          for j in small:
+            ready.pop(j, None)
       if i in self.e.fftb and not last:
         f = self.e.fftb[i]
         call('st_conv1d_nwc_fwd_fft_planes', self.e.X[i].ref, self.e._ptr(self.e.Xb[i]), self.e._ptr(f['gt']), self.e._ptr(self.e._slice(self.e.params, i)[1]),

@@ -252,3 +252,76 @@ def test_odd_shapes_bf16(dev, frames):
     if np.max(np.abs(rF)) > 1e-12:
       assert scaled_err(gF, rF)[0] < 16 * ULP, i
       assert scaled_err(gb, rb)[0] < 16 * ULP, i
+
+
+def test_panel_kernel_7tap_layers_bf16(dev):
+  """The 7-tap 250 -> 250 layers at a batch that fills the chip run on conv_taps_bf16.hip (input panel resident in LDS) in the
+  forward pass and in back-prop to the input.  Ragged batch, three such layers + head:
+    * the launch trace names the kernel for forward L0, L1 and back-prop through L1 (the layers whose two tensors share a frame
+      pitch);
+    * on the device's OWN stored operands the stored results are round_bf16 of the float64 oracle's (<= 1 bf16 spacing on a
+      rounding boundary, a handful of elements);
+    * the rows between utterances stay zero, and the general kernel (st_set_tuning bf16_taps_panel = 1) stores the same planes
+      up to such boundary cases."""
+  from speecht_amd._lib import launch_trace, set_tuning
+  layers = [(7, 1, 250, 250, True)] * 3 + [(1, 1, 250, 29, False)]
+  frames = [1001, 1000, 777, 640, 1001, 333, 901, 5, 999, 1001]
+  B, T = len(frames), max(frames)
+  rng = np.random.default_rng(77)
+  params = WL.xavier_params(layers, seed=5, bias_range=0.05)
+  x = np.zeros((B, T, 250))
+  for b, t in enumerate(frames):
+    x[b, :t] = rng.standard_normal((t, 250))
+  eng = engine(layers, dev)
+  eng.set_weights(params)
+  dl = rng.standard_normal((B, T, 29)) / (B * T)
+
+  def run():
+    eng.load_batch(x, frames)
+    eng.forward()
+    eng.dZ[-1].interior().copy_(torch.as_tensor(dl, dtype=torch.float32))
+    eng.backward()
+    torch.cuda.synchronize()
+    return [eng.Xb[i].clone() for i in range(4)], [eng.dZb[i].clone() for i in range(3)]
+
+  with launch_trace() as tr:
+    Xp, dZp = run()
+  taps = [l for l in tr.lines if l.startswith('conv_taps_bf16<128,128,64,panel>')]
+  assert len(taps) == 3, '\n'.join(tr.lines)
+  try:
+    set_tuning('bf16_taps_panel', 1)
+    with launch_trace() as tr:
+      Xg, dZg = run()
+    assert not any(l.startswith('conv_taps_bf16') for l in tr.lines)
+  finally:
+    set_tuning('bf16_taps_panel', 0)
+
+  def frames_of(t3, plane):
+    return plane.view(t3.batch, t3.t_pitch, t3.c_pitch)[:, t3.halo:t3.halo + t3.frames].float().cpu().numpy().astype(np.float64)
+
+  def same(a, b, what):                      # the two kernels sum in a different order: values on a rounding boundary may differ
+    a, b = a.float(), b.float()
+    d = (a - b).abs()
+    scale = float(b.abs().max())
+    assert float(d.max()) <= 2 * ULP * scale and int((d > 0).sum()) < 1e-3 * d.numel(), (what, float(d.max()) / scale)
+
+  for i in (1, 2):
+    same(Xp[i], Xg[i], 'X%d' % i)
+    t3 = eng.X[i]
+    v = Xp[i].view(t3.batch, t3.t_pitch, t3.c_pitch).float()
+    assert float(v[:, :t3.halo].abs().max()) == 0 and float(v[:, t3.halo + t3.frames:].abs().max()) == 0, 'halo rows of X%d' % i
+    assert float(v[:, :, 250:].abs().max()) == 0, 'padding channels of X%d' % i
+  same(dZp[0], dZg[0], 'dZ0')
+  v = dZp[0].view(eng.dZ[0].batch, eng.dZ[0].t_pitch, eng.dZ[0].c_pitch).float()
+  assert float(v[:, :eng.dZ[0].halo].abs().max()) == 0 and float(v[:, eng.dZ[0].halo + eng.dZ[0].frames:].abs().max()) == 0
+
+  # against the oracle on the stored operands
+  F64 = [(O.bf16_round(F.astype(np.float64)), b.astype(np.float64)) for F, b in params]
+  for i in (0, 1):
+    y = O.conv1d_same_fwd(frames_of(eng.X[i], Xp[i])[:, :, :250], F64[i][0], F64[i][1], 1, True)
+    mx, mean = scaled_err(frames_of(eng.X[i + 1], Xp[i + 1])[:, :, :250], O.bf16_round(y))
+    assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('forward', i, mx / ULP, mean / ULP)
+  xs1 = frames_of(eng.X[1], Xp[1])[:, :, :250]
+  dx, _, _ = O.conv1d_same_bwd(xs1, F64[1][0], None, frames_of(eng.dZ[1], dZp[1])[:, :, :250], 1, relu=False, need_dx=True)
+  mx, mean = scaled_err(frames_of(eng.dZ[0], dZp[0])[:, :, :250], O.bf16_round(dx * (xs1 > 0)))
+  assert mx <= 2.01 * ULP and mean < 0.01 * ULP, ('back-prop', mx / ULP, mean / ULP)

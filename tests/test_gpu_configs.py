@@ -77,6 +77,8 @@ def test_config3_rank_shard_bf16_training_step_vs_bf16_storage_oracle():
   # through the transposing-read kernel; the stride-1 layers' filter gradients on that kernel too: L1-L7, L9, L10)
   assert spectral == {8} and batched(48) == 2 and batched(96, 'wgrad_tr_bf16<128,128,32,lag>') == 1, '\n'.join(tr.lines)
   assert sum(1 for l in tr.lines if l.startswith('wgrad_tr_bf16<128,128,32> ')) == 9, '\n'.join(tr.lines)
+  # (the 7-tap layers whose two tensors share a frame pitch on the panel kernel: forward L1-L6, back-prop to the input L2-L7)
+  assert sum(1 for l in tr.lines if l.startswith('conv_taps_bf16<128,128,64,panel> ')) == 12, '\n'.join(tr.lines)
   logits, acts = O.wav2letter_forward(x.astype(np.float64), p64, layers, keep=True, store=O.bf16_round, spectral=spectral)
   loss, g_logits = O.ctc_loss_and_grad(logits, labels, seq // 2)
   ref_grads = O.wav2letter_backward(acts, p64, layers, g_logits / (8 * B), store=O.bf16_round, spectral=spectral)

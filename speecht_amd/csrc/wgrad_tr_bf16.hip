@@ -52,6 +52,8 @@ struct TrParams {
   int x_cp, z_cp, n_pad, width;
   int stages, stages_per_split, splits;
   int mtiles_per_tap, tiles_m, tiles_n;
+  float* bias_direct;            // non-null: the bias gradient rides on row x_cp - 1 of tap 0 (see `bias_tile`) and, unsplit, is stored here
+  int bias_in_tile;
 };
 
 // ds_read_b64_tr_b16 as inline assembly, OFF = immediate byte offset.  (Through __builtin_amdgcn_ds_read_tr16_b64 the compiler sees
@@ -106,6 +108,11 @@ __global__ __launch_bounds__(256, ST <= 4 ? 2 : 1) void wgrad_tr_bf16_kernel(TrP
   const int wm = wave >> 1, wn = wave & 1;
 
   const bool rot = LAG && blockIdx.y == 1;                      // the imaginary product
+  // The bias gradient is the column sum of the gradient plane: the product of a row of ONES with it.  The last channel of the
+  // channel pitch is padding (x_cp > channels, x_cp a multiple of 128: asked for by the caller) -- its row of the filter gradient is
+  // zero by construction and nobody's -- so the wave that owns row x_cp - 1 of tap 0 feeds ones instead of that channel's zeros:
+  // the column sums come out of the same MFMAs, in the same slabs, and the separate pass over the plane (7.5 us per layer) is gone.
+  const bool bias_wave = !LAG && p.bias_in_tile && w == 0 && c0 + TM == p.x_cp && wm == 1;
   const int kt_begin = split * p.stages_per_split;
   const int nk = min(p.stages_per_split, p.stages - kt_begin);
   if (nk <= 0) return;
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256, ST <= 4 ? 2 : 1) void wgrad_tr_bf16_kernel(TrP
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[q] = rotate_rows(r[q], rot);
       }
+      if (!LAG && bias_wave && (lane & 31) == 31) r[2] = r[3] = 0x3F803F803F803F80ull;      // channel c0 + 127: four bf16 ones
       fa0 = frag_of(r[0], r[1]), fa1 = frag_of(r[2], r[3]), fb0 = frag_of(r[4], r[5]), fb1 = frag_of(r[6], r[7]);
     };
     if (M) frags(p0);
@@ -243,7 +251,14 @@ __global__ __launch_bounds__(256, ST <= 4 ? 2 : 1) void wgrad_tr_bf16_kernel(TrP
       for (int r = 0; r < 16; ++r) {
         const int c = c0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         // (columns between the gradient's channel pitch and n_pad met the NEXT row's bytes: they are padding, exactly zero)
-        if (c < p.x_cp && n < p.n_pad) out[((long)w * p.x_cp + c) * p.n_pad + n] = n < p.z_cp ? acc[i][j][r] : 0.f;
+        if (c < p.x_cp && n < p.n_pad) {
+          float v = n < p.z_cp ? acc[i][j][r] : 0.f;
+          if (!LAG && bias_wave && c == p.x_cp - 1 && p.bias_direct) {       // unsplit: straight to the bias gradient, the row stays zero
+            p.bias_direct[n] = v;
+            v = 0.f;
+          }
+          out[((long)w * p.x_cp + c) * p.n_pad + n] = v;
+        }
       }
     }
 }
@@ -289,9 +304,9 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned
 // each, eight lanes per column summing every eighth chunk, then the eight in lane order (a fixed tree: deterministic)
 __global__ __launch_bounds__(256) void wgrad_tr_finish_kernel(const float* __restrict__ slabs, int n_slabs, size_t n4,
                                                               float* __restrict__ dpacked, const float* __restrict__ part, int chunks,
-                                                              int n_pad, float* __restrict__ dbias) {
+                                                              int n_pad, float* __restrict__ dbias, size_t bias_row4) {
   __shared__ float red[8][33];
-  if ((int)blockIdx.x * 32 < n_pad) {
+  if (part && (int)blockIdx.x * 32 < n_pad) {
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
     float t = 0.f;
     if (c < n_pad) {
@@ -326,6 +341,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_finish_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (s0 + k < n_slabs) a += v[k];
+      }
+      if (bias_row4 && i >= bias_row4 && i < bias_row4 + (size_t)n_pad / 4) {    // row x_cp - 1 of tap 0 carried the column sums
+        reinterpret_cast<f32x4*>(dbias)[i - bias_row4] = a;
+        a = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       reinterpret_cast<f32x4*>(dpacked)[i] = a;
     }
@@ -437,6 +456,10 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
   p.x_cp = x->c_pitch; p.z_cp = dz->c_pitch; p.n_pad = t.n_pad; p.width = width;
   p.stages = t.stages; p.stages_per_split = t.stages_per_split; p.splits = t.splits;
   p.mtiles_per_tap = t.mtiles_per_tap; p.tiles_m = t.tiles_m; p.tiles_n = t.tiles_n;
+  // the bias gradient from the same MFMAs (see the kernel) when the input's channel pitch has a padding channel to carry it
+  const bool in_tile = x->c_pitch > x->channels && x->c_pitch % TM == 0 && st::tuning(st::TUNE_BF16_WGRAD_BIAS_PASS) == 0;
+  p.bias_in_tile = in_tile ? 1 : 0;
+  p.bias_direct = in_tile && t.splits == 1 ? dbias : nullptr;
   st::trace("wgrad_tr_bf16<128,128,32> M=%d Np=%d rows=%ld stages=%d splits=%d gflop=%.3f", width * x->c_pitch, t.n_pad, t.rows, t.stages,
             t.splits, 2e-9 * (double)t.stages * TK * t.tiles_m * TM * t.tiles_n * TN);
   {
@@ -449,14 +472,19 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
     else st::launch_timed(timer, wgrad_tr_bf16_kernel<false, 4>, dim3(grid), dim3(256), s, p);
   }
   if (int e = st::check_launch("wgrad_tr_bf16")) return e;
-  const long z_rows = (long)dz->batch * dz->t_pitch;
-  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 256), t.chunks), dim3(256), 0, s, p.Z, z_rows, dz->c_pitch,
-                     t.n_pad, part);
+  if (!in_tile) {
+    const long z_rows = (long)dz->batch * dz->t_pitch;
+    hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(st::ceil_div(t.n_pad, 256), t.chunks), dim3(256), 0, s, p.Z, z_rows,
+                       dz->c_pitch, t.n_pad, part);
+  } else if (t.splits == 1) {
+    return 0;                                                    // filter and bias gradient are both where they belong
+  }
   const size_t n4 = (size_t)width * x->c_pitch * t.n_pad / 4;
-  const unsigned bias_blocks = (unsigned)st::ceil_div(t.n_pad, 32);
+  const unsigned bias_blocks = in_tile ? 1u : (unsigned)st::ceil_div(t.n_pad, 32);
   const unsigned sum_blocks = t.splits > 1 ? (unsigned)std::min<size_t>((n4 + 255) / 256, 2048) : 0u;
   hipLaunchKernelGGL(wgrad_tr_finish_kernel, dim3(std::max(bias_blocks, sum_blocks)), dim3(256), 0, s,
-                     t.splits > 1 ? slabs : (const float*)nullptr, t.splits, n4, dpacked, part, t.chunks, t.n_pad, dbias);
+                     t.splits > 1 ? slabs : (const float*)nullptr, t.splits, n4, dpacked, in_tile ? (const float*)nullptr : part, t.chunks,
+                     t.n_pad, dbias, in_tile ? (size_t)(x->c_pitch - 1) * t.n_pad / 4 : (size_t)0);
   return st::check_launch("wgrad_tr_finish");
 }
 

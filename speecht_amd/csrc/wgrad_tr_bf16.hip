@@ -52,6 +52,7 @@ struct TrParams {
   int x_cp, z_cp, n_pad, width;
   int stages, stages_per_split, splits;
   int mtiles_per_tap, tiles_m, tiles_n;
+  int map, map_a, map_b;         // workgroup -> (split, tile) order, see the kernel
   float* bias_direct;            // non-null: the bias gradient rides on row x_cp - 1 of tap 0 (see `bias_tile`) and, unsplit, is stored here
   int bias_in_tile;
 };
@@ -98,16 +99,44 @@ __global__ __launch_bounds__(256, ST <= 4 ? 2 : 1) void wgrad_tr_bf16_kernel(TrP
   unsigned short* const As = smem;                              // [ST][32][128]
   unsigned short* const Bs = smem + ST * STAGE_ELEMS;
 
+  // Workgroup -> (split, tile, real / imaginary).  Workgroups go to the eight XCDs in turn (id & 7), each XCD has its own L2: what
+  // shares operand rows must share an XCD, or every L2 fetches the same rows over the fabric (measured with the plain order
+  // id = split * tiles + tile: 100 MB per launch for a 7-tap layer's 16.6 MB of operands, 640 for the 2000 x 2000 layer's 131).
+  //   map 1 (splits a multiple of 8): an XCD owns whole splits -- every row range is fetched by one L2;
+  //   map 2 (8 a multiple of splits): the XCDs of a split take contiguous runs of its tiles;
+  //   map 3 (LAG): the workgroups that read one (bin, column tile) panel of the gradient spectra -- both row tiles, real and
+  //          imaginary product -- follow each other on one XCD;
+  //   map 0: the plain order.
   const int tiles = p.tiles_m * p.tiles_n;
-  const int split = blockIdx.x / tiles;
-  const int tile = blockIdx.x - split * tiles;
+  int split, tile;
+  bool rot = false;
+  {
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    if (p.map == 1) {
+      split = xcd * p.map_a + j % p.map_a;                       // map_a = splits / 8
+      tile = j / p.map_a;
+    } else if (p.map == 2) {
+      split = xcd / p.map_a;                                     // map_a = 8 / splits XCDs per split, map_b tiles each
+      tile = (xcd % p.map_a) * p.map_b + j;
+      if (j >= p.map_b || tile >= tiles) return;
+    } else if (p.map == 3) {
+      const int members = 2 * p.tiles_m, g = (j / members) * 8 + xcd, m = j % members;      // g = bin * tiles_n + column tile
+      if (g >= p.splits * p.tiles_n) return;
+      split = g / p.tiles_n;
+      tile = (g - split * p.tiles_n) * p.tiles_m + (m >> 1);
+      rot = LAG && (m & 1);                                      // the imaginary product
+    } else {
+      split = id / tiles;
+      tile = id - split * tiles;
+      rot = LAG && blockIdx.y == 1;
+    }
+  }
   const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;   // row tiles fastest: neighbours share the gradient panel
   const int w = tm / p.mtiles_per_tap, c0 = (tm - w * p.mtiles_per_tap) * TM, n0 = tn * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const bool rot = LAG && blockIdx.y == 1;                      // the imaginary product
   // The bias gradient is the column sum of the gradient plane: the product of a row of ONES with it.  The last channel of the
   // channel pitch is padding (x_cp > channels, x_cp a multiple of 128: asked for by the caller) -- its row of the filter gradient is
   // zero by construction and nobody's -- so the wave that owns row x_cp - 1 of tap 0 feeds ones instead of that channel's zeros:
@@ -379,6 +408,9 @@ TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_lef
   const int target = st::tuning(st::TUNE_BF16_WGRAD_TARGET) > 0 ? st::tuning(st::TUNE_BF16_WGRAD_TARGET) : 256;
   int splits = forced ? forced : (int)std::max(1L, std::min<long>(target / std::max(1L, tiles), t.stages / 8));
   if (!forced && splits == 1 && tiles >= 128 && tiles <= 320 && t.stages >= 64) splits = 2;
+  // (a power of two, so that splits and XCDs divide each other: whole splits per XCD or whole XCDs per split, see the kernel)
+  if (!forced && !st::tuning(st::TUNE_BF16_WGRAD_PLAIN_ORDER))
+    while (splits & (splits - 1)) splits &= splits - 1;
   splits = std::max(1, std::min(splits, t.stages));
   t.stages_per_split = st::ceil_div(t.stages, splits);
   t.splits = st::ceil_div(t.stages, t.stages_per_split);
@@ -417,7 +449,13 @@ int st::lag_products_tr_bf16(const void* s_plane, const void* z_plane, int bins,
             2e-9 * 2.0 * bins * half * (double)npo * 2.0 * rows);
   {
     st::LaunchTimer timer(s);
-    st::launch_timed(timer, wgrad_tr_bf16_kernel<true, 4>, dim3((unsigned)(bins * p.tiles_m * p.tiles_n), 2), dim3(256), s, p);
+    if (st::tuning(st::TUNE_BF16_WGRAD_PLAIN_ORDER)) {
+      st::launch_timed(timer, wgrad_tr_bf16_kernel<true, 4>, dim3((unsigned)(bins * p.tiles_m * p.tiles_n), 2), dim3(256), s, p);
+    } else {
+      p.map = 3;
+      const unsigned groups = (unsigned)(bins * p.tiles_n), members = 2u * p.tiles_m;
+      st::launch_timed(timer, wgrad_tr_bf16_kernel<true, 4>, dim3(8u * st::ceil_div(groups, 8u) * members), dim3(256), s, p);
+    }
   }
   return st::check_launch("lag_products_tr_bf16");
 }
@@ -466,8 +504,17 @@ int st_conv1d_nwc_bwd_filter_tr_bf16(const st_tensor3* x, const void* x_bf16, co
     st::LaunchTimer timer(s);
     // ring depth: a grid of about one workgroup per CU cannot hide the fabric latency behind a second workgroup: eight 16 KB
     // stages (seven in flight) instead of four, the whole LDS for the one workgroup a CU gets anyway
-    const unsigned grid = (unsigned)(t.splits * t.tiles_m * t.tiles_n);
+    const int tiles = t.tiles_m * t.tiles_n;
+    unsigned grid = (unsigned)(t.splits * tiles);
     const int ring = st::tuning(st::TUNE_BF16_WGRAD_RING) ? st::tuning(st::TUNE_BF16_WGRAD_RING) : (grid <= 320 ? 8 : 4);
+    if (!st::tuning(st::TUNE_BF16_WGRAD_PLAIN_ORDER)) {
+      if (t.splits % 8 == 0) {
+        p.map = 1; p.map_a = t.splits / 8;
+      } else if (8 % t.splits == 0) {
+        p.map = 2; p.map_a = 8 / t.splits; p.map_b = st::ceil_div(tiles, p.map_a);
+        grid = 8u * p.map_b;
+      }
+    }
     if (ring == 8) st::launch_timed(timer, wgrad_tr_bf16_kernel<false, 8>, dim3(grid), dim3(256), s, p);
     else st::launch_timed(timer, wgrad_tr_bf16_kernel<false, 4>, dim3(grid), dim3(256), s, p);
   }

@@ -22,6 +22,7 @@ cp $F/inference_config3_fp32.json ${P}_inference_config3_fp32.json
 cp $F/inference_config3_bf16.json ${P}_inference_config3_bf16.json
 cp $F/pmc_shapes_bf16.txt ${P}_pmc_shapes_bf16.txt
 cp $F/pmc_shapes_fp32.txt ${P}_pmc_shapes_fp32.txt
+[ -f $F/pmc_shapes_bf16_round5_kernels.txt ] && cp $F/pmc_shapes_bf16_round5_kernels.txt ${P}_pmc_shapes_bf16_round5_kernels.txt
 cp $F/pytest_gpu.log ${P}_pytest_gpu.log
 cp $F/traffic_bf16.json profiles/traffic_bf16.json
 cp $F/mel_traffic_b32.json ${P}_mel_traffic_b32.json

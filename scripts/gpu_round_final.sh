@@ -32,5 +32,7 @@ for MODE in bf16 bf16x6; do
 done
 bash scripts/gpu_pmc_shapes.sh r${R}_bf16 --conv-mode bf16 > $F/pmc_shapes_bf16.txt 2>&1
 bash scripts/gpu_pmc_shapes.sh r${R}_fp32 > $F/pmc_shapes_fp32.txt 2>&1
+# the bf16 step's own kernels (filter gradients through transposing reads, the 7-tap panel kernel): same counters
+KERNEL_FILTER='((?:conv_taps_bf16_kernel|wgrad_tr_bf16_kernel<[^>]*>))' bash scripts/gpu_pmc_shapes.sh r${R}_bf16_new --conv-mode bf16 > $F/pmc_shapes_bf16_round5_kernels.txt 2>&1
 find gpurun_out -name '*.csv' -size +4M -delete
 du -sh gpurun_out | tail -1

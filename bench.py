@@ -66,8 +66,6 @@ class HostFeed:
 
 def train_step(eng, feed, reducer, lr, global_batch):
   feed.next()
-  if getattr(eng, '_step_graph_on', False) and reducer is None:
-    return eng.train_step_graph(1.0 / global_batch, lr)     # the same launch sequence, replayed from a HIP graph
   eng.forward()
   eng.ctc_loss_grad(1.0 / global_batch)
   eng.backward(reducer.on_layer_done if reducer else None, reducer.hook_layers if reducer else None)
@@ -388,38 +386,26 @@ def roofline_bf16_in_step(eng, step_fn, ms_per_step, steps=4):
   return out
 
 
-def host_cost_and_graph(eng, feed, lr, global_batch, steps, ahead):
-  """What the host side of a step costs and what a whole-step HIP graph changes: the same steps timed three
-  ways on this engine -- `host_enqueue_ms` is the CPU time inside the calls that enqueue one step (Python + ctypes; the pacing
-  wait that keeps two steps in flight is NOT in it), `ms_per_step` the wall clock per step -- once through the eager launch
-  sequence and once through engine.train_step_graph (one graph launch per step; capture happens in the warm-up)."""
-  res = {}
-  for name, graph in (('eager', False), ('graph', True)):
-    eng.enable_step_graph(graph)
-    for _ in range(6):                                        # (graph: first sight of both parities, capture, replay)
-      train_step(eng, feed, None, lr, global_batch)
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event() for _ in range(steps)]
-    host = 0.0
-    t0 = time.perf_counter()
-    for k in range(steps):
-      if ahead and k >= ahead:
-        marks[k - ahead].synchronize()
-      h0 = time.perf_counter()
-      train_step(eng, feed, None, lr, global_batch)
-      host += time.perf_counter() - h0
-      marks[k].record()
-    torch.cuda.synchronize()
-    res[name] = dict(ms_per_step=round((time.perf_counter() - t0) / steps * 1e3, 3), host_enqueue_ms=round(host / steps * 1e3, 3))
-  eng.enable_step_graph(False)
-  for _ in range(2):                                          # back on the eager path: derived operands rebuilt, uploads unfixed
+def host_cost(eng, feed, lr, global_batch, steps, ahead):
+  """What the host side of a step costs: `host_enqueue_ms` is the CPU time inside the calls that enqueue one step (Python + ctypes;
+  the pacing wait that keeps two steps in flight is NOT in it), `ms_per_step` the wall clock per step of the same loop.  (Rounds
+  5 carried a whole-step HIP graph beside it: bit-identical, half the enqueue time, but a SLOWER replay -- 7.08 against 6.83 ms
+  fp32, 2.49 against 2.42 bf16 -- because the capture froze a worse stream -> queue assignment; removed in round 6, docs/history/r5.md.)"""
+  for _ in range(3):
     train_step(eng, feed, None, lr, global_batch)
   torch.cuda.synchronize()
-  res['graphs_captured'] = len(getattr(eng, '_step_graphs', {}))
-  res['note'] = ('graph = forward + CTC + backward + clip / Adam replayed as ONE hipGraphLaunch (bit-identical to the eager step, '
-                 'tests/test_gpu_api.py); the host enqueues an eager step in about a millisecond while the GPU needs 2.5 - 7, two steps '
-                 'ahead: the eager sequence is not host-bound, and the graph replays its multi-stream launch sequence no faster')
-  return res
+  marks = [torch.cuda.Event() for _ in range(steps)]
+  host = 0.0
+  t0 = time.perf_counter()
+  for k in range(steps):
+    if ahead and k >= ahead:
+      marks[k - ahead].synchronize()
+    h0 = time.perf_counter()
+    train_step(eng, feed, None, lr, global_batch)
+    host += time.perf_counter() - h0
+    marks[k].record()
+  torch.cuda.synchronize()
+  return dict(ms_per_step=round((time.perf_counter() - t0) / steps * 1e3, 3), host_enqueue_ms=round(host / steps * 1e3, 3))
 
 
 def comm_model(eng, feed, lr, global_batch, step_ms, world=8, reps=5):
@@ -824,7 +810,6 @@ def main():
   ap.add_argument('--allreduce', choices=('torch', 'rccl'), default=None,
                   help='gradient exchange transport: the library\'s own RCCL communicator behind the C ABI (st_allreduce_buckets_f32; '
                        'default for --gpus > 1, falls back to torch.distributed if it cannot be set up) or torch.distributed')
-  ap.add_argument('--graph', action='store_true', help='replay the step from a whole-step HIP graph (engine.train_step_graph; single rank)')
   ap.add_argument('--tune', action='append', default=[], help='name=value override of a library policy (st_set_tuning; experiments only)')
   args = ap.parse_args()
   for kv in args.tune:
@@ -869,8 +854,6 @@ def main():
     print('bench.py: PARITY FAILED against the oracle on the bench inputs, no result line is printed: ' + json.dumps(parity),
           file=sys.stderr)
     sys.exit(3)
-  if args.graph:
-    eng.enable_step_graph()
   feed = HostFeed(eng, x, seq_lens, labels)
   reducer, transport_note = None, None
   if world > 1 or args.force_allreduce:
@@ -1045,7 +1028,7 @@ def main():
       out['comm_probe_world1'] = comm_probe_world1(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and reducer is None and not args.no_alt:
       out['comm_model_8gpu'] = comm_model(eng, feed, lr, global_batch, ms)
-      out['whole_step_graph'] = host_cost_and_graph(eng, feed, lr, global_batch, args.steps, ahead)
+      out['host_cost'] = host_cost(eng, feed, lr, global_batch, args.steps, ahead)
     if world == 1 and eng.conv_mode == 'fp32' and not args.no_alt:
       # Side measurements on the same box and inputs, NOT the headline:
       #  * bf16x6 (experimental): fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on the bf16
@@ -1084,7 +1067,7 @@ def main():
                     'final_avg_loss': round(float(alt.loss.mean()), 4), 'dtype': dtype, 'note': note}
         if mode == 'bf16':
           # the comm model first (plain events), the roofline pass last: its timed launches switch the queues to profiling mode
-          out[key]['whole_step_graph'] = host_cost_and_graph(alt, alt_feed, lr, global_batch, args.steps, ahead)
+          out[key]['host_cost'] = host_cost(alt, alt_feed, lr, global_batch, args.steps, ahead)
           out[key]['comm_probe_world1'] = comm_probe_world1(alt, alt_feed, lr, global_batch, args.steps, ahead)
           out[key]['comm_model_8gpu'] = comm_model(alt, alt_feed, lr, global_batch, alt_ms)
           out[key]['roofline'] = roofline_bf16_in_step(alt, lambda: train_step(alt, alt_feed, None, lr, global_batch), alt_ms)

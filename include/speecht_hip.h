@@ -319,17 +319,19 @@ int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, fl
  * speech_model.py:74) and the failing sess.run then touches no variable (speech_model.py:82).  Here the CTC
  * kernel reports such utterances in `status`; st_ctc_status_gate_f32 folds the status words into one device float
  * (the number of bad utterances; data-parallel training all-reduces it with the gradients), and the update
- * becomes a no-op -- params, m and v untouched, stats still written -- when *gate != 0.  gate == NULL: ungated. */
+ * becomes a no-op -- params, m and v untouched, stats still written -- when *gate != 0.  gate == NULL: ungated.
+ * The update is also skipped when the global norm is not finite (stats[0] then holds the NaN / Inf): a poisoned gradient never
+ * reaches params, m or v. */
 int st_ctc_status_gate_f32(const int32_t* status, int batch, float* gate, void* stream);
+/* ... and this rank's share of the GLOBAL mean loss (speech_model.py:75 reduce_mean) in gate[1] = sum_b (loss_hi[b] + loss_lo[b]) *
+ * loss_scale (summed in double; loss_lo may be NULL; loss_scale = 1 / global batch): gate[0..1] sit inside the first gradient
+ * bucket, so data-parallel training gets the mean loss out of the gradient exchange itself -- no scalar all-reduce per step. */
+int st_ctc_status_gate_loss_f32(const int32_t* status, int batch, const float* loss_hi, const float* loss_lo, float loss_scale,
+                                float* gate, void* stream);
 int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float* m, float* v, size_t n,
                                        float clip_norm, float lr_t, float beta1, float beta2, float eps,
                                        float* stats, const float* gate, void* workspace,
                                        size_t workspace_bytes, void* stream);
-/* ... with the bias-corrected rate read from DEVICE memory when lr_t_dev is not null (lr_t is then ignored): the form a launch
- * replayed from a HIP graph needs -- the rate changes every step, the captured arguments do not (engine.train_step_graph). */
-int st_global_norm_clip_adam_gated_dev_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
-                                           float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps, float* stats,
-                                           const float* gate, void* workspace, size_t workspace_bytes, void* stream);
 /* norm only (stats[0] = ||g||, stats[1] = clip/max(norm,clip)); used for reporting */
 int st_global_norm_f32(const float* grads, size_t n, float clip_norm, float* stats,
                        void* workspace, size_t workspace_bytes, void* stream);

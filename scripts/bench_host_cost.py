@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU time the host spends ENQUEUEING one training step (not the paced wait of the bench loop): the step's Python + ctypes
-calls timed with the GPU kept at most one step behind, per phase, for a conv mode -- what a whole-step HIP graph or a C-side
-driver could give back.  bench.py's workload (32 x 10 s, 80-mel), data resident."""
+calls timed with the GPU kept at most one step behind, per phase, for a conv mode -- what a C-side driver of the
+step could give back.  bench.py's workload (32 x 10 s, 80-mel), data resident."""
 import argparse
 import json
 import os
@@ -22,7 +22,6 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--conv-mode', default='fp32')
   ap.add_argument('--steps', type=int, default=40)
-  ap.add_argument('--graph', action='store_true', help='replay the captured whole-step graph (engine.train_step_graph)')
   args = ap.parse_args()
   layers = WL.w2l_layers(80)
   eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode=args.conv_mode)
@@ -38,14 +37,10 @@ def main():
   def step(timed):
     t = [time.perf_counter()]
     feed.next(); t.append(time.perf_counter())
-    if args.graph:
-      eng.train_step_graph(1.0 / 32, 1e-4)
-      t += [time.perf_counter()] * 4
-    else:
-      eng.forward(); t.append(time.perf_counter())
-      eng.ctc_loss_grad(1.0 / 32); t.append(time.perf_counter())
-      eng.backward(); t.append(time.perf_counter())
-      eng.apply_update(1e-4); t.append(time.perf_counter())
+    eng.forward(); t.append(time.perf_counter())
+    eng.ctc_loss_grad(1.0 / 32); t.append(time.perf_counter())
+    eng.backward(); t.append(time.perf_counter())
+    eng.apply_update(1e-4); t.append(time.perf_counter())
     if timed:
       for n, a, b in zip(names, t, t[1:]):
         acc[n] += b - a
@@ -63,7 +58,7 @@ def main():
   torch.cuda.synchronize()
   wall = (time.perf_counter() - t0) / args.steps
   host = sum(acc.values()) / args.steps
-  print(json.dumps(dict(workload='32 x 10 s, 80-mel training step, resident data', conv_mode=args.conv_mode, graph=bool(args.graph),
+  print(json.dumps(dict(workload='32 x 10 s, 80-mel training step, resident data', conv_mode=args.conv_mode, 
                         ms_per_step=round(wall * 1e3, 3), host_enqueue_ms_per_step=round(host * 1e3, 3),
                         host_enqueue_by_phase_ms={n: round(v / args.steps * 1e3, 3) for n, v in acc.items()})))
 

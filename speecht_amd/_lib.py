@@ -110,12 +110,10 @@ _SIGNATURES = {
     'st_global_norm_clip_adam_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                              c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_ctc_status_gate_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'st_ctc_status_gate_loss_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'st_global_norm_clip_adam_gated_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
                                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                                    c_void_p]),
-    'st_global_norm_clip_adam_gated_dev_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p,
-                                                       c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                       c_void_p]),
     'st_global_norm_f32': (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_melspec_plan_bytes': (c_size_t, []),
     'st_melspec_plan_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -61,16 +61,18 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         const float* __restrict__ partial, float clip, float lr_t_value,
                                                         float b1, float b2, float eps, float* __restrict__ stats,
-                                                        const float* __restrict__ gate, const float* __restrict__ lr_t_dev) {
+                                                        const float* __restrict__ gate) {
   __shared__ float red[4];
-  // the bias-corrected rate changes every step: a launch replayed from a graph reads it from device memory
-  const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_value;
+  const float lr_t = lr_t_value;
   const float gn = sqrtf(total_sumsq(partial, red));
   const float scale = clip / fmaxf(gn, clip);
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats) { stats[0] = gn; stats[1] = scale; }
   // a batch that tf.nn.ctc_loss would have rejected (InvalidArgument fails the whole sess.run before any variable
   // is touched, speech_model.py:74,82) must leave weights and Adam state alone: uniform early exit
   if (gate && gate[0] != 0.f) return;
+  // a gradient that is not finite (a poisoned stream-K tile, an overflow) must not reach params / m / v: fmaxf(NaN, clip)
+  // would keep the scale at 1 and Adam would store the NaN.  stats[0] carries the norm, so the host sees why nothing moved.
+  if (!(gn <= 3.0e38f)) return;
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * scale;
@@ -97,11 +99,24 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   }
 }
 
-__global__ void status_gate_kernel(const int* __restrict__ status, int n, float* __restrict__ gate) {
+// gate[0] = number of utterances CTC refused; with `loss_hi`: gate[1] = sum_b (hi_b + lo_b) * loss_scale, summed in double in a
+// fixed order (lane-strided partials, then a butterfly) -- this rank's share of the global mean loss, which travels with the
+// gradients through the all-reduce (the slots sit inside the first reduce bucket) instead of a second, blocking scalar exchange
+__global__ void status_gate_kernel(const int* __restrict__ status, int n, float* __restrict__ gate,
+                                   const float* __restrict__ loss_hi, const float* __restrict__ loss_lo, float loss_scale) {
   int bad = 0;
-  for (int i = threadIdx.x; i < n; i += 64) bad += status[i] != 0;
+  double sum = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    bad += status[i] != 0;
+    if (loss_hi) sum += (double)loss_hi[i] + (loss_lo ? (double)loss_lo[i] : 0.0);
+  }
   bad = (int)st::wave_sum((float)bad);
-  if (threadIdx.x == 0) gate[0] = (float)bad;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (threadIdx.x == 0) {
+    gate[0] = (float)bad;
+    if (loss_hi) gate[1] = (float)(sum * (double)loss_scale);
+  }
 }
 
 }  // namespace
@@ -110,8 +125,16 @@ extern "C" {
 
 int st_ctc_status_gate_f32(const int32_t* status, int batch, float* gate, void* stream) {
   ST_REQUIRE(status && gate && batch > 0, "status_gate: bad args");
-  hipLaunchKernelGGL(status_gate_kernel, dim3(1), dim3(64), 0, st::as_stream(stream), status, batch, gate);
+  hipLaunchKernelGGL(status_gate_kernel, dim3(1), dim3(64), 0, st::as_stream(stream), status, batch, gate, (const float*)nullptr,
+                     (const float*)nullptr, 0.f);
   return st::check_launch("status_gate");
+}
+
+int st_ctc_status_gate_loss_f32(const int32_t* status, int batch, const float* loss_hi, const float* loss_lo, float loss_scale,
+                                float* gate, void* stream) {
+  ST_REQUIRE(status && gate && loss_hi && batch > 0, "status_gate_loss: bad args");
+  hipLaunchKernelGGL(status_gate_kernel, dim3(1), dim3(64), 0, st::as_stream(stream), status, batch, gate, loss_hi, loss_lo, loss_scale);
+  return st::check_launch("status_gate_loss");
 }
 
 size_t st_global_norm_ws(size_t n) { (void)n; return NORM_BLOCKS * sizeof(float); }
@@ -137,13 +160,6 @@ int st_global_norm_clip_adam_f32(float* params, const float* grads, float* m, fl
 int st_global_norm_clip_adam_gated_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
                                        float lr_t, float beta1, float beta2, float eps, float* stats, const float* gate,
                                        void* workspace, size_t workspace_bytes, void* stream) {
-  return st_global_norm_clip_adam_gated_dev_f32(params, grads, m, v, n, clip_norm, lr_t, nullptr, beta1, beta2, eps, stats, gate, workspace,
-                                                workspace_bytes, stream);
-}
-
-int st_global_norm_clip_adam_gated_dev_f32(float* params, const float* grads, float* m, float* v, size_t n, float clip_norm,
-                                           float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps, float* stats,
-                                           const float* gate, void* workspace, size_t workspace_bytes, void* stream) {
   ST_REQUIRE(params && grads && m && v && workspace && workspace_bytes >= st_global_norm_ws(n), "clip_adam: bad args");
   ST_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "clip_adam: buffers must be 16-byte aligned");
@@ -152,7 +168,7 @@ int st_global_norm_clip_adam_gated_dev_f32(float* params, const float* grads, fl
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, partial);
   const int blocks = (int)std::max<size_t>(1, std::min<size_t>((n / 4 + 255) / 256, 2048));
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, partial, clip_norm,
-                     lr_t, beta1, beta2, eps, stats, gate, lr_t_dev);
+                     lr_t, beta1, beta2, eps, stats, gate);
   return st::check_launch("clip_adam");
 }
 

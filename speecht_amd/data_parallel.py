@@ -17,6 +17,50 @@ import torch
 import torch.distributed as dist
 
 
+def job():
+  """(rank, world) of the running job: torch.distributed's view once the process group exists, (0, 1) otherwise."""
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank(), dist.get_world_size()
+  return 0, 1
+
+
+def init_job(flags=None):
+  """Join the data-parallel job a launcher started this process for (`torchrun --nproc-per-node N speecht-cli train ...`:
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): one process per GPU, ``flags.device`` becomes this rank's GPU,
+  backend nccl (= RCCL; ST_DIST_BACKEND=gloo and ST_SHARE_GPU=1 are test knobs: host transport, every rank on cuda:0).  Without
+  WORLD_SIZE > 1 in the environment nothing happens.  Returns (rank, world)."""
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world <= 1 or dist.is_initialized():
+    return job()
+  rank, local_rank = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  os.environ.setdefault('MASTER_PORT', '29571')
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
+  backend = os.environ.get('ST_DIST_BACKEND', 'nccl')
+  device = getattr(flags, 'device', None) or 'cuda:0'
+  if str(device).startswith('cuda'):
+    if os.environ.get('ST_SHARE_GPU'):
+      local_rank = 0
+    device = 'cuda:%d' % local_rank
+    torch.cuda.set_device(local_rank)
+  if flags is not None:
+    flags.device = device
+  if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+  else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
+  return rank, world
+
+
+def broadcast_seed(group=None):
+  """One random 31-bit seed, the same on every rank (rank 0 draws it)."""
+  import random
+  box = [random.SystemRandom().randrange(1 << 31)]
+  if dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+  return int(box[0])
+
+
 def shard_range(n_items, rank, world):
   """Contiguous equal shards; requires n_items % world == 0 so mean-of-means is exact."""
   if n_items % world:
@@ -141,6 +185,10 @@ class GradientAllReducer:
     self._ready_at = {lo: (s, e) for lo, s, e in self.buckets}
     self._pending = []
     self._compute_stream = compute_stream
+    # called once per step right after the FIRST bucket (the top layers' slice, which also carries the update gate and the
+    # mean-loss slot) has been handed to the all-reduce, with a function `wait(stream)` that makes `stream` wait for that
+    # bucket's reduction only: SpeechModel.step reads the reduced slots back from there, long before back-prop ends
+    self.after_first_bucket = None
     self.comm = RcclCommunicator(flat_grads.device, group) if (self.active and self.transport == 'rccl') else None
 
   @property
@@ -148,6 +196,17 @@ class GradientAllReducer:
     """The layers whose completion makes a bucket ready (the lowest layer of each bucket): the only ones
     ``engine.backward`` has to call ``on_layer_done`` for."""
     return set(self._ready_at) if self.active else set()
+
+  def readback_stream(self):
+    """Where a read-back that must follow a bucket's reduction is enqueued: the library communicator's stream (in order behind
+    the all-reduce), or the process's 'collective' role stream for the torch transport -- both on a hardware queue the compute
+    stream does not use (engine_streams.role_stream)."""
+    if self.comm is not None:
+      return self.comm.stream
+    if self.flat.device.type != 'cuda':
+      return None                      # (host tensors: the CPU tests of the control flow)
+    from .engine_streams import role_stream
+    return role_stream(self.flat.device, 'collective')
 
   def _stream(self):
     return self._compute_stream if self._compute_stream is not None else torch.cuda.current_stream(self.flat.device)
@@ -158,8 +217,20 @@ class GradientAllReducer:
     s, e = self._ready_at[i]
     if self.comm is not None:
       self.comm.all_reduce_slices(self.flat, [(s, e)], self._stream())
+      reduced = self.comm._joined
+      wait = lambda stream: stream.wait_event(reduced)      # noqa: E731
     else:
-      self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+      work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+      self._pending.append(work)
+
+      def wait(stream, work=work):
+        if stream is None:
+          work.wait()                # (host tensors)
+          return
+        with torch.cuda.stream(stream):
+          work.wait()                # nccl: a stream-side wait; gloo (tests): blocks the host until the bucket is reduced
+    if i == self.buckets[0][0] and self.after_first_bucket is not None:
+      self.after_first_bucket(wait)
 
   def finish(self):
     if self.comm is not None:
@@ -167,6 +238,37 @@ class GradientAllReducer:
     for w in self._pending:
       w.wait()
     self._pending = []
+
+
+def make_reducer(flat_grads, layer_offsets, group=None, transport=None, force=False):
+  """The gradient exchange of a data-parallel job, by the rule bench.py and SpeechModel.enable_data_parallel share: the library's
+  own RCCL communicator (st_allreduce_buckets_f32) when the job runs on the nccl backend with one GPU per rank -- but only if it
+  really spans the job (its ncclCommCount equals the world size on EVERY rank), else every rank falls back to
+  torch.distributed together.  ``transport``: 'rccl' / 'torch' to force one (env ST_ALLREDUCE does the same).  Returns
+  (reducer, note) -- note says why a fallback happened, or None."""
+  world = dist.get_world_size(group) if dist.is_initialized() else 1
+  want = transport or os.environ.get('ST_ALLREDUCE')
+  if want is None:
+    nccl = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+    want = 'rccl' if (world > 1 and nccl and not os.environ.get('ST_SHARE_GPU')) else 'torch'
+  reducer, note = None, None
+  if want == 'rccl':
+    ok = 1
+    try:
+      reducer = GradientAllReducer(flat_grads, layer_offsets, group, force=force, transport='rccl')
+      ok = int(reducer.comm is not None and reducer.comm.count() == world)
+    except Exception as e:      # noqa: BLE001 -- whatever the set-up raises, the exchange must still happen somehow
+      ok, note = 0, 'library communicator failed: %r' % (e,)
+    if dist.is_initialized() and world > 1:
+      flag = torch.tensor([ok], dtype=torch.int32, device=flat_grads.device)
+      dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+      ok = int(flag[0])
+    if not ok:
+      note = note or 'library communicator does not span the job (count != world) on some rank'
+      reducer = None
+  if reducer is None:
+    reducer = GradientAllReducer(flat_grads, layer_offsets, group, force=force, transport='torch')
+  return reducer, note
 
 
 def all_reduce_mean_scalar(value, device, group=None):

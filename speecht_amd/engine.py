@@ -5,7 +5,7 @@ arithmetic op of the path is a call into libspeecht_hip.so through ``_lib`` (no 
 
 The engine is the CORE shared by the three arithmetic modes: weights / gradients / Adam state in four flat fp32 buffers, the
 padded NWC activation tensors (engine_buffers.py), the role streams and the side-stream fork / join (engine_streams.py), the
-input side (H2D staging, label uploads), CTC, clip + Adam, the whole-step graph, loss read-back and the decoders
+input side (H2D staging, label uploads), CTC, clip + Adam, loss read-back and the decoders
 (engine_decode.py).  What differs between fp32, bf16x6 and bf16 -- derived operands and the forward / backward launch
 sequences -- lives in speecht_amd/modes/ behind `self.mode`.
 """
@@ -76,6 +76,9 @@ class Wav2LetterEngine(DecodeMixin):
     self.reduce_buffer = torch.zeros(self.n_flat + 16, dtype=torch.float32, device=self.device)
     self.grads = self.reduce_buffer[:self.n_flat]
     self.gate = self.reduce_buffer[self.n_flat:self.n_flat + 1]
+    # ... and next to it this rank's share of the global mean loss (st_ctc_status_gate_loss_f32): SUM-reduced with the gradients,
+    # slot 1 holds the mean loss of the GLOBAL batch on every rank -- no scalar exchange of its own (speech_model.py:75)
+    self.gate_slots = self.reduce_buffer[self.n_flat:self.n_flat + 2]
     self.packed_t = [None] + [torch.zeros(l.kt_pad * l.nt_pad, dtype=torch.float32, device=self.device)
                               for l in self.layers[1:]]
     self._packed_t_fresh = False
@@ -274,7 +277,7 @@ class Wav2LetterEngine(DecodeMixin):
       staged.consumed.record(self._stream if self._stream is not None else torch.cuda.current_stream(self.device))
     self.seq_lens_host = np.asarray(seq_lens, dtype=np.int64)
     # the reference feeds sequence_lengths // 2 to CTC and the decoder (speech_model.py:74,114)
-    self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32), fixed='ctc_lens')
+    self.ctc_lens = self._upload_i32((self.seq_lens_host // 2).astype(np.int32))
 
   def stage_host_batch(self, x_host):
     """Asynchronous H2D copy of a padded feature batch [B, T, C] (float32; a pinned torch tensor copies without
@@ -319,13 +322,10 @@ class Wav2LetterEngine(DecodeMixin):
       staged.taken = True
       staged.consumed.record(self._h2d['stream'])      # "consumed" right behind the copy on the copy stream
 
-  def _upload_i32(self, values, fixed=None):
+  def _upload_i32(self, values):
     """Small int32 host array -> device through a ring of pinned slots.  A hipMemcpyAsync from pageable memory
     only returns once the stream's earlier kernels have finished, which would stall the thread that enqueues
-    the next batch behind the previous batch's forward; from pinned memory the copy is a stream operation.
-    ``fixed``: with whole-step graphs on (`enable_step_graph`) the array goes to a persistent device buffer of that name --
-    one per step parity, so that the upload of step k + 1 does not wait for step k's kernels -- whose address a captured
-    launch can hold."""
+    the next batch behind the previous batch's forward; from pinned memory the copy is a stream operation."""
     if not hasattr(self, '_pin_ring'):
       self._pin_ring, self._pin_turn = [[None, None] for _ in range(8)], 0
     slot = self._pin_ring[self._pin_turn % len(self._pin_ring)]
@@ -342,20 +342,7 @@ class Wav2LetterEngine(DecodeMixin):
     if not hasattr(self, '_up_stream'):
       self._up_stream, self._uploads = role_stream(self.device, 'upload'), []
     with torch.cuda.stream(self._up_stream):
-      if fixed is not None and getattr(self, '_step_graph_on', False):
-        par = self._step_parity
-        dev = self._storage.view('%s_par%d' % (fixed, par), _round_up(max(n, 1), 4096), torch.int32)[0][:n]
-        if fixed in self._parity_written[par]:
-          # written before and not consumed by a graph step since (eager passes in between: evaluation, a decode): whatever is
-          # enqueued on the compute stream so far may still read the buffer
-          busy = torch.cuda.Event()
-          busy.record(main)
-          self._up_stream.wait_event(busy)
-        elif self._parity_consumed[par] is not None:
-          self._up_stream.wait_event(self._parity_consumed[par])      # the step that last read this parity's buffers is through
-        self._parity_written[par].add(fixed)
-      else:
-        dev = torch.empty(n, dtype=torch.int32, device=self.device)
+      dev = torch.empty(n, dtype=torch.int32, device=self.device)
       dev.copy_(slot[0][:n], non_blocking=True)
       if slot[1] is None:
         slot[1] = torch.cuda.Event()
@@ -433,8 +420,8 @@ class Wav2LetterEngine(DecodeMixin):
       offs[1:] = np.cumsum(lens)
       self.max_label_len = int(max(lens + [0]))
       ids = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in label_list] + [np.zeros(1, np.int32)])
-    self.label_ids = self._upload_i32(ids, fixed='label_ids')
-    self.label_offs = self._upload_i32(offs, fixed='label_offs')
+    self.label_ids = self._upload_i32(ids)
+    self.label_offs = self._upload_i32(offs)
 
   def _on_side_stream(self, fn, second=False):
     """Run ``fn`` (which enqueues kernels through ``self.stream_ptr``) on the engine's side stream (``second``: on a
@@ -490,7 +477,8 @@ class Wav2LetterEngine(DecodeMixin):
       stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
       with torch.cuda.stream(stream):
         self.ctc_status.index_fill_(0, torch.as_tensor(self._rejected_labels, dtype=torch.int64).to(self.device, non_blocking=True), 2)
-    call('st_ctc_status_gate_f32', self._ptr(self.ctc_status), B, self._ptr(self.gate), self.stream_ptr)
+    call('st_ctc_status_gate_loss_f32', self._ptr(self.ctc_status), B, self._ptr(self.loss), self._ptr(self.loss_lo), float(grad_scale),
+         self._ptr(self.gate), self.stream_ptr)
 
   def backward(self, on_layer_done=None, hook_layers=None):
     """Back-prop from dZ[-1] (already holding d avg_loss / d logits).  ``on_layer_done(i)`` is
@@ -526,112 +514,6 @@ class Wav2LetterEngine(DecodeMixin):
     self.mark_weights_changed()
     self._refresh_after_update()
 
-  # ---- the whole training step from a HIP graph ------------------------------------------------------------------
-
-  def enable_step_graph(self, on=True):
-    """From the next `load_batch` on, lengths and labels are uploaded into persistent per-parity device buffers so that
-    `train_step_graph` can replay captured launches that hold their addresses."""
-    self._step_graph_on = bool(on)
-    if not hasattr(self, '_step_parity'):
-      self._step_parity, self._parity_consumed, self._parity_written = 0, [None, None], [set(), set()]
-      self._step_graphs, self._step_graph_seen = {}, set()
-      self._rate_host = torch.zeros(16, dtype=torch.float32, pin_memory=True)
-      self._rate_turn = 0
-      # the device scalars of the Adam rate exist (and are zero-filled) before any stream copies into them: created lazily, the
-      # fill kernel on a busy compute stream ran AFTER the copy on the idle upload stream and wiped the step's rate
-      for par in (0, 1):
-        self._storage.view('adam_rate_par%d' % par, 4)
-      torch.cuda.synchronize(self.device)
-
-  def _step_body(self, grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev):
-    """The launch sequence of one training step in the order a captured graph holds it: the operands derived from the weights
-    FIRST (what `apply_update` does at its end for the next step: inside a graph nothing may outlive the capture, and at the
-    head of the step the rebuild still overlaps the first layers), forward, CTC, backward, clip + Adam with the rate read from
-    device memory; every side stream joined at the end."""
-    self.mark_weights_changed()
-    self._refresh_after_update()
-    self.forward()
-    self.ctc_loss_grad(grad_scale)
-    self.backward()
-    call('st_global_norm_clip_adam_gated_dev_f32', self._ptr(self.params), self._ptr(self.grads), self._ptr(self.adam_m),
-         self._ptr(self.adam_v), self.n_flat, float(max_grad_norm), 0.0, self._ptr(rate_dev), beta1, beta2, eps,
-         self._ptr(self.stats), self._ptr(self.gate), self._ptr(self.norm_ws), self.norm_ws.numel() * 4, self.stream_ptr)
-    self._join_side_stream()
-    for name in ('_gfwd_ready', '_wb_ready', '_bwd_ready'):      # events of this sequence: consumed inside it
-      d = getattr(self, name, None)
-      if d:
-        d.clear()
-
-  def train_step_graph(self, grad_scale, lr, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-3):
-    """forward + ctc_loss_grad + backward + apply_update of the batch `load_batch` / `set_labels` staged, as ONE graph launch.
-
-    The step's ~100 kernel launches and ~40 cross-stream events are captured once per (shape, label-length class, parity) -- the
-    second time a key shows up; the first time runs the same sequence eagerly -- and replayed afterwards: the launch sequence,
-    its side-stream forks and joins included, is identical, so the result is bit-identical to the eager step
-    (tests/test_gpu_api.py).  What changes from step to step lives in device memory the captured launches point at: the input
-    batch (X[0]), lengths and labels (per-parity buffers, `enable_step_graph`), the Adam rate (a device scalar per parity,
-    uploaded with them).  Single-process training only: the data-parallel exchange stays on the eager path."""
-    if not getattr(self, '_step_graph_on', False):
-      raise RuntimeError('train_step_graph: call enable_step_graph() before load_batch / set_labels')
-    lib = _lib.load()
-    B, T = self.X[-1].batch, self.X[-1].frames
-    kpl_len = next((k * 32 - 1 for k in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16) if k * 64 >= 2 * self.max_label_len + 1), None)
-    if kpl_len is None:
-      raise ValueError('label of length {} is too long for the CTC kernel (max 511)'.format(self.max_label_len))
-    par = self._step_parity
-    main = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
-    # the rate of this update: pinned slot -> this parity's device scalar, with the step's other uploads
-    lr_t = self._adam_rate(lr, beta1, beta2)
-    self._rate_turn = (self._rate_turn + 1) % 16
-    self._rate_host[self._rate_turn] = lr_t
-    rate_dev = self._storage.view('adam_rate_par%d' % par, 4)[0]
-    with torch.cuda.stream(self._up_stream):
-      if self._parity_consumed[par] is not None:
-        self._up_stream.wait_event(self._parity_consumed[par])
-      rate_dev[:1].copy_(self._rate_host[self._rate_turn:self._rate_turn + 1], non_blocking=True)
-      ev = torch.cuda.Event()
-      ev.record(self._up_stream)
-      self._uploads.append(ev)
-    need = lib.st_ctc_ws(B, T, kpl_len)
-    if self.ctc_ws is None or self.ctc_ws.numel() * 4 < need:
-      self.ctc_ws = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
-    key = (self._shape, self._storage.generation, kpl_len, par, float(grad_scale), float(max_grad_norm), beta1, beta2, eps,
-           self.fft_conv, self.ctc_ws.data_ptr())
-    # everything enqueued outside the graph that it depends on: uploads, side-stream work of an eager step before this one
-    self._wait_uploads()
-    self._join_side_stream()
-    saved_len, self.max_label_len = self.max_label_len, kpl_len      # (the CTC launch depends on the length class only)
-    try:
-      graph = self._step_graphs.get(key)
-      if getattr(self, '_rejected_labels', None):
-        graph = None                                                  # (deferred label errors: the eager sequence marks them)
-        self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
-      elif graph is None and key not in self._step_graph_seen:
-        self._step_graph_seen = {k for k in self._step_graph_seen if k[1] == self._storage.generation} | {key}
-        self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
-      else:
-        if graph is None:
-          self._step_graphs = {k: g for k, g in self._step_graphs.items() if k[1] == self._storage.generation}
-          torch.cuda.synchronize(self.device)
-          graph = torch.cuda.CUDAGraph()
-          own_stream, self._stream = self._stream, None
-          try:
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-              self._step_body(grad_scale, max_grad_norm, beta1, beta2, eps, rate_dev)
-          finally:
-            self._stream = own_stream
-          self._step_graphs[key] = graph
-        graph.replay()
-    finally:
-      self.max_label_len = saved_len
-    self._updates_in_flight = getattr(self, '_updates_in_flight', 0) + 1
-    self.mark_weights_changed()                  # an eager pass after this one rebuilds its operands itself
-    done = torch.cuda.Event()
-    done.record(main)
-    self._parity_consumed[par] = done
-    self._parity_written[par].clear()
-    self._step_parity = par ^ 1
-
   def fetch_losses(self, precise=False):
     """Per-utterance CTC losses [B] on the host, after checking the status words: both arrays come back in one
     pinned, asynchronous copy each and a single event wait (a step's only host synchronisation).  float32 like
@@ -639,24 +521,27 @@ class Wav2LetterEngine(DecodeMixin):
     fp32 ulp of a 10 s utterance's loss is 1.2e-4)."""
     return self.fetch_losses_end(self.fetch_losses_begin(), precise)
 
-  def fetch_losses_begin(self):
-    """The read-back of `fetch_losses` enqueued where the stream stands NOW: losses, CTC status words, the update gate and the
-    library's lost-hand-off count go to pinned host memory behind everything enqueued so far, an event marks the copies.  Called
-    right behind `ctc_loss_grad`, with back-prop and the update enqueued after it, `fetch_losses_end` returns as soon as CTC is
-    through -- the host hands the loss back to its caller and prepares the next batch while the GPU is still in the backward pass
-    (single process only: under data parallelism the gate is all-reduced with the gradients and is final only after back-prop)."""
+  def fetch_losses_begin(self, stream=None):
+    """The read-back of `fetch_losses` enqueued where the stream stands NOW: losses, CTC status words, the update gate, the mean-loss
+    slot and the library's lost-hand-off count go to pinned host memory behind everything enqueued so far, an event marks the
+    copies.  Called right behind `ctc_loss_grad`, with back-prop and the update enqueued after it, `fetch_losses_end` returns as
+    soon as CTC is through -- the host hands the loss back to its caller and prepares the next batch while the GPU is still in the
+    backward pass.  ``stream``: read back on that stream instead of the compute stream (data parallelism: the gate and the mean
+    loss are final once the FIRST gradient bucket is reduced -- the caller makes ``stream`` wait for that bucket and nothing else,
+    `GradientAllReducer.after_first_bucket`)."""
     B = self.loss.numel()
     if not hasattr(self, '_loss_host') or self._loss_host[0].numel() < 2 * B:
       self._loss_host = (torch.empty(max(2 * B, 128), dtype=torch.float32, pin_memory=True),
                          torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True), torch.cuda.Event(),
                          torch.empty(16, dtype=torch.float32, pin_memory=True))
     loss_h, status_h, event, gate_h = self._loss_host
-    stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+    if stream is None:
+      stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
     lost_h = self._streamk_lost_async(stream)
     with torch.cuda.stream(stream):
       loss_h[:2 * B].copy_(self.loss_pair, non_blocking=True)
       status_h[:B].copy_(self.ctc_status, non_blocking=True)
-      gate_h[:1].copy_(self.gate, non_blocking=True)
+      gate_h[:2].copy_(self.gate_slots, non_blocking=True)
       event.record(stream)
     return (B, lost_h)
 
@@ -681,6 +566,7 @@ class Wav2LetterEngine(DecodeMixin):
       raise ValueError('batch rejected: {:g} utterance(s) on other ranks had no valid CTC alignment or out-of-range label ids'
                        .format(float(gate_h[0])))
     pair = loss_h[:2 * B].numpy()
+    self.mean_loss_reduced = float(gate_h[1])      # sum over ranks of (sum_b loss_b) * grad_scale: the global mean under data parallelism
     if precise:
       return pair[:B].astype(np.float64) + pair[B:].astype(np.float64)
     return pair[:B].copy()

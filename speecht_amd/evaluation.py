@@ -51,18 +51,22 @@ class Evaluation(execution.DatasetExecutor):
 
   def create_sample_generator(self, limit_count: int):
     return self.reader.load_samples(self.flags.dataset, loop_infinitely=False, limit_count=limit_count,
-                                    feature_type=self.flags.feature_type)
+                                    feature_type=self.flags.feature_type, shuffle_seed=self.shuffle_seed)
 
   def get_loader_limit_count(self):
-    return self.flags.batch_size * self.flags.step_count
+    return self.flags.batch_size * self.world * self.flags.step_count
 
   def get_max_steps(self):
     return self.flags.step_count if self.flags.step_count else None
 
   def run(self):
     stats = EvalStatistics()
-    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
+    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess, self.quiet_unless_rank0():
       model = self.create_model(sess)
+      if self.world > 1:
+        # replicas: every rank evaluates its rows of each global batch with the same checkpoint; the loss is averaged over
+        # ranks per step, the statistics are gathered at the end (rank 0 prints its own rows and the global line)
+        model.enable_data_parallel()
       print('Starting input pipeline')
       coordinator = self.start_pipeline(sess)
       print('Begin evaluation')
@@ -75,8 +79,21 @@ class Evaluation(execution.DatasetExecutor):
         print('Done evaluating -- step limit reached')
       finally:
         coordinator.request_stop()
+      stats = self.gather_statistics(stats)
       self.print_global_statistics(stats)
       coordinator.join()
+    return stats
+
+  def gather_statistics(self, stats):
+    """Data-parallel evaluation: the running sums of every rank added up (the same object on a single process)."""
+    if self.world <= 1:
+      return stats
+    import torch.distributed as dist
+    mine = dict(decodings_counter=stats.decodings_counter, **{'sum_' + f: getattr(stats, 'sum_' + f) for f in stats._FIELDS})
+    every = [None] * self.world
+    dist.all_gather_object(every, mine)
+    for key in mine:
+      setattr(stats, key, sum(e[key] for e in every))
     return stats
 
   @staticmethod

@@ -186,13 +186,19 @@ class SpeechCorpusReader:
         audio_id = self._extract_audio_id(f)
         np.savez(out_directory + '/' + audio_id, audio_fragments=feat, transcript=self._transcript_dict[audio_id])
 
-  def load_samples(self, directory, max_size=False, loop_infinitely=False, limit_count=0, feature_type='mfcc'):
-    """Iterator over (audio_fragments, transcript), same semantics as preprocessing.py:243-279."""
+  def load_samples(self, directory, max_size=False, loop_infinitely=False, limit_count=0, feature_type='mfcc', shuffle_seed=None):
+    """Iterator over (audio_fragments, transcript), same semantics as preprocessing.py:243-279.
+    ``shuffle_seed`` (not a reference argument): shuffle with a generator of its own seeded with it, over the SORTED file list,
+    instead of the process-wide ``random`` state -- every rank of a data-parallel job must walk the samples in the same order."""
     load_directory = self._get_directory(feature_type, directory)
     if not os.path.exists(load_directory):
       raise ValueError('Directory {} does not exist'.format(load_directory))
     files = list(iglob_recursive(load_directory, '*.npz'))
-    random.shuffle(files)
+    shuffle = random.shuffle
+    if shuffle_seed is not None:
+      files.sort()
+      shuffle = random.Random(shuffle_seed).shuffle
+    shuffle(files)
     if limit_count:
       files = files[:limit_count]
     while True:
@@ -205,7 +211,7 @@ class SpeechCorpusReader:
             logging.warning('Audio snippet too long: {}'.format(frames))
       if not loop_infinitely:
         break
-      random.shuffle(files)
+      shuffle(files)
 
 
 def load_audio(path):

@@ -110,6 +110,39 @@ def sparse_to_label_lists(labels):
   return np.split(values, np.cumsum(counts)[:-1]) if batch else []
 
 
+def bucket_by_length(samples, batch_size, window=16, seed=None):
+  """Opt-in length-bucketed shuffled sampler (not reference behaviour: the reference batches consecutive samples of its
+  shuffled generator, speech_input.py:169-179, and pads each batch to its own longest member -- ~40 % padding on 2-15 s
+  speech).  Reads ``window`` batches' worth of samples from ``samples``, sorts them by frame count, cuts the sorted run into
+  batches of neighbouring lengths and yields those batches in shuffled order, sample by sample -- so that the loader's
+  ``zip(*[iter]*B)`` regroups exactly them.  Every sample is yielded once; a final short window is sorted and yielded too
+  (the loader drops its last partial batch as always).  SURVEY F7: padding is never masked, so an utterance's logits near
+  its end depend on the padded length of its batch -- bucketing changes those tails like any other batch composition does."""
+  import random as _random
+  rng = _random.Random(seed)
+  it = iter(samples)
+  while True:
+    chunk = []
+    for sample in it:
+      chunk.append(sample)
+      if len(chunk) == window * batch_size:
+        break
+    if not chunk:
+      return
+    chunk.sort(key=lambda s: s[0].shape[0])
+    batches = [chunk[i:i + batch_size] for i in range(0, len(chunk), batch_size)]
+    tail = batches.pop() if len(batches[-1]) < batch_size else None
+    rng.shuffle(batches)
+    for b in batches:
+      for sample in b:
+        yield sample
+    if tail:
+      for sample in tail:
+        yield sample
+    if len(chunk) < window * batch_size:
+      return
+
+
 class SingleInputLoader(BaseInputLoader):
   """Feeds one utterance per step (speech_input.py:79-127), used for live / ad-hoc inference."""
 
@@ -145,9 +178,15 @@ class InputBatchLoader(BaseInputLoader):
   CAPACITY = 100
   DEVICE_PREFETCH = 3          # batches staged in HBM ahead of the consumer (copy stream, own thread)
 
-  def __init__(self, input_size, batch_size, data_generator_creator, max_steps=None):
+  def __init__(self, input_size, batch_size, data_generator_creator, max_steps=None, shard=None):
+    """``shard = (rank, world)`` (not a reference argument; data-parallel training): the loader forms the GLOBAL
+    batches of ``batch_size * world`` consecutive samples -- the batches one process with that batch size would see, every rank
+    from an identically ordered generator -- pads each to the global batch's longest member (padding is never masked, SURVEY F7:
+    an utterance's logits depend on the padded length, so the shard must be padded like the whole batch) and keeps rows
+    ``[rank * batch_size, (rank + 1) * batch_size)``."""
     super().__init__(input_size)
     self.batch_size = batch_size
+    self.shard = tuple(shard) if shard is not None and int(shard[1]) > 1 else None
     self.data_generator_creator = data_generator_creator
     self.steps_left = max_steps
     self.inputs = Placeholder('inputs')
@@ -163,14 +202,28 @@ class InputBatchLoader(BaseInputLoader):
     return self.inputs, self.sequence_lengths, self.labels
 
   def _batch(self, iterable):
-    return zip(*([iter(iterable)] * self.batch_size))
+    return zip(*([iter(iterable)] * (self.batch_size * (self.shard[1] if self.shard else 1))))
+
+  def _feed_item(self, sample_batch):
+    """One (inputs, sequence_lengths, labels) queue item from a tuple of samples; with ``shard`` this rank's rows of it."""
+    input_list, label_list = zip(*sample_batch)
+    if self.shard is None:
+      input_tensor, sequence_lengths, max_time = self._get_inputs_feed_item(input_list)
+      return input_tensor, sequence_lengths, self._get_labels_feed_item(label_list, max_time)
+    rank = int(self.shard[0])
+    lo, hi = rank * self.batch_size, (rank + 1) * self.batch_size
+    max_time = max(item.shape[0] for item in input_list)                # of the GLOBAL batch
+    mine = input_list[lo:hi]
+    sequence_lengths = np.fromiter((item.shape[0] for item in mine), dtype=np.int64, count=len(mine))
+    input_tensor = np.zeros((len(mine), max_time, self.input_size), dtype=np.float32)
+    for row, item in zip(input_tensor, mine):
+      row[:item.shape[0]] = item
+    return input_tensor, sequence_lengths, self._get_labels_feed_item(label_list[lo:hi], max_time)
 
   def _enqueue(self, sess, coord):
     try:
       for sample_batch in self._batch(self.data_generator_creator()):
-        input_list, label_list = zip(*sample_batch)
-        input_tensor, sequence_lengths, max_time = self._get_inputs_feed_item(input_list)
-        item = (input_tensor, sequence_lengths, self._get_labels_feed_item(label_list, max_time))
+        item = self._feed_item(sample_batch)
         while not (self._closed.is_set() or coord.should_stop()):
           try:
             self._queue.put(item, timeout=0.1)

@@ -259,7 +259,6 @@ class SpeechModel:
     self._reducer = None
     self._world = 1
     self._rank = 0
-    self.step_graph = os.environ.get('ST_STEP_GRAPH', '0') == '1'      # training steps as one HIP-graph launch (see `step`)
 
   # ---- graph-building protocol ---------------------------------------------------------------
   def _convolution(self, value, filter_width, stride, input_channels, out_channels, apply_non_linearity=True):
@@ -311,20 +310,23 @@ class SpeechModel:
   def init_session(self, sess, init_variables=True):
     eng = self._ensure_engine(sess)
     if init_variables:
-      eng.init_xavier()        # xavier_initializer filters, zero biases (speech_model.py:150-152)
+      eng.init_xavier(getattr(self, 'init_seed', None))        # xavier_initializer filters, zero biases (speech_model.py:150-152)
       eng.adam_m.zero_(); eng.adam_v.zero_()
       eng.step_count = 0
       self.global_step.value = 0
     self.summary_writer.add_graph(None)
 
-  def enable_data_parallel(self, group=None):
-    """Shard-by-utterance data parallelism: see data_parallel.py.  Call after init_session."""
+  def enable_data_parallel(self, group=None, transport=None):
+    """Shard-by-utterance data parallelism: see data_parallel.py.  Call after init_session / restore.  ``transport``: None =
+    the library's own RCCL communicator when the job runs on the nccl backend with a GPU per rank and the communicator spans the
+    job (`data_parallel.make_reducer`, the rule bench.py follows), torch.distributed otherwise; 'rccl' / 'torch' force one."""
     import torch.distributed as dist
-    from .data_parallel import GradientAllReducer
+    from .data_parallel import make_reducer
     self._world = dist.get_world_size(group) if dist.is_initialized() else 1
     eng = self.engine
     self._rank = dist.get_rank(group) if dist.is_initialized() else 0
-    self._reducer = GradientAllReducer(eng.reduce_buffer, eng.reduce_ranges, group) if self._world > 1 else None
+    self._reducer, self._transport_note = (make_reducer(eng.reduce_buffer, eng.reduce_ranges, group, transport)
+                                           if self._world > 1 else (None, None))
     # a label the host refuses must not raise on one rank while the others wait in the all-reduce: it becomes a status
     # word that travels with the gradients, and every rank raises together after the step (engine.set_labels)
     eng.defer_label_errors = self._world > 1
@@ -341,6 +343,16 @@ class SpeechModel:
       if box[0][2] is not None and hasattr(self, 'learning_rate'):
         self.learning_rate.value = float(box[0][2])
       eng.mark_weights_changed()
+      # the read-back of a step's status words / gate / mean loss is enqueued behind the FIRST gradient bucket's all-reduce (the
+      # gate and the mean-loss slot travel in it) on the collective's own stream -- never on a stream that shares a hardware
+      # queue with the compute stream, where the wait would hold back-prop back: `step` returns while back-prop is still running
+      self._early = None
+
+      def after_first_bucket(wait):
+        stream = self._reducer.readback_stream()
+        wait(stream)
+        self._early = eng.fetch_losses_begin(stream=stream)
+      self._reducer.after_first_bucket = after_first_bucket
 
   def step(self, sess, loss=True, update=True, decode=False, return_label=False, summary=False, feed_dict=None):
     """One evaluation of the path.  Returns, in this order and only when requested:
@@ -353,31 +365,22 @@ class SpeechModel:
       labels = feed_dict.get(self.labels, labels) if self.labels is not None else labels
     if (loss or update) and labels is None:
       raise ValueError('loss/update requested but the input loader provides no labels')
-    # opt-in (`model.step_graph = True` / ST_STEP_GRAPH=1): a training step of a single process as ONE HIP-graph launch
-    # (engine.train_step_graph: bit-identical to the sequence below).  It pays where the host is the limit -- this method reads the
-    # loss back every step, so the enqueue cost of the ~100 launches is not hidden behind the GPU as in a loop that runs ahead:
-    # bf16 activations 3.16 -> see DESIGN 4.9 -- and costs a capture per (batch shape, label-length class), so it is off by default
-    # for corpora whose padded batch length changes every step.
-    use_graph = bool(getattr(self, 'step_graph', False)) and update and self._training and self._world == 1 and labels is not None
-    if use_graph and not getattr(eng, '_step_graph_on', False):
-      eng.enable_step_graph()
     eng.load_batch(inputs, seq_lens)
-    if not use_graph:
-      eng.forward()
+    eng.forward()
     out = []
     avg_loss = None
     if loss or update:
       eng.set_labels(sparse_to_label_lists(labels))
-      if use_graph:
-        eng.train_step_graph(1.0 / len(seq_lens), self.learning_rate.value, self.max_gradient_norm)
-      else:
-        # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
-        eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
+      # d(avg_loss)/d(loss_b) = 1 / global batch (speech_model.py:75)
+      eng.ctc_loss_grad(1.0 / (len(seq_lens) * self._world))
       # single process: the loss read-back is enqueued right behind CTC and waited for after back-prop and the update have been
       # enqueued -- step() returns while the GPU is still in the backward pass, and the caller's next step() overlaps its host
-      # side (dequeue, batch hand-over, first launches) with it.  (Data parallel: the gate is final only after the exchange.)
-      early = eng.fetch_losses_begin() if (self._world == 1 and not use_graph) else None
-      if update and not use_graph:
+      # side (dequeue, batch hand-over, first launches) with it.  Data parallel: the update gate and the global mean loss ride
+      # in the FIRST gradient bucket (engine.gate_slots); the read-back is enqueued behind that bucket's all-reduce on a stream of
+      # its own (`enable_data_parallel`), so the step has the same single, early host wait and no collective of its own.
+      early = eng.fetch_losses_begin() if (self._world == 1 or not update) else None
+      self._early = None
+      if update:
         if not self._training:
           raise RuntimeError('add_training_ops() was not called with labelled inputs')
         eng.backward(self._reducer.on_layer_done if self._reducer else None, self._reducer.hook_layers if self._reducer else None)
@@ -386,13 +389,18 @@ class SpeechModel:
         eng.apply_update(self.learning_rate.value, self.max_gradient_norm)   # no-op on the device if CTC rejected the batch
       # raises on a CTC status word (of any rank) -- before global_step moves: like TF's failed sess.run, a rejected
       # batch leaves weights, Adam state and counters as they were
-      losses = eng.fetch_losses_end(early, precise=True) if early is not None else eng.fetch_losses(precise=True)
+      if early is None:
+        early = self._early if self._early is not None else eng.fetch_losses_begin()
+      losses = eng.fetch_losses_end(early, precise=True)
       avg_loss = np.float32(losses.mean())     # mean of -log p in float64, returned as TF's float32
       if update:
         self.global_step.value += 1
       if self._world > 1:
-        from .data_parallel import all_reduce_mean_scalar
-        avg_loss = np.float32(all_reduce_mean_scalar(float(avg_loss), eng.device))
+        if update:
+          avg_loss = np.float32(eng.mean_loss_reduced)         # the global mean, out of the gradient exchange itself
+        else:
+          from .data_parallel import all_reduce_mean_scalar     # evaluation steps exchange no gradients: one scalar all-reduce
+          avg_loss = np.float32(all_reduce_mean_scalar(float(avg_loss), eng.device))
     if loss:
       out.append(avg_loss)
     if decode:
@@ -489,4 +497,5 @@ def create_default_model(flags, input_size: int, speech_input: BaseInputLoader) 
                            beam_width=getattr(flags, 'beam_width', 0), beam_input=getattr(flags, 'beam_input', None))
   model.finalize(log_dir=flags.log_dir, run_name=flags.run_name, run_type=flags.run_type)
   model.checkpoint_format = 'tf' if getattr(flags, 'tf_checkpoints', False) else 'npz'
+  model.init_seed = getattr(flags, 'seed', None)       # (extension; None = unseeded like the reference)
   return model

@@ -33,8 +33,14 @@ class Training(execution.DatasetExecutor):
   CHECKPOINT_NAME = 'speechT.ckpt'
 
   def create_sample_generator(self, limit_count: int):
-    return self.reader.load_samples('train', loop_infinitely=True, limit_count=limit_count,
-                                    feature_type=self.flags.feature_type)
+    samples = self.reader.load_samples('train', loop_infinitely=True, limit_count=limit_count,
+                                       feature_type=self.flags.feature_type, shuffle_seed=self.shuffle_seed)
+    window = getattr(self.flags, 'bucket_window', 0)
+    if window and not getattr(self, 'peeking', False):
+      # opt-in: batches of neighbouring lengths (4 % padding instead of ~40 % on 2-15 s speech, scripts/bench_varlen_train.py);
+      # under data parallelism the GLOBAL batches are bucketed, with the job's seed, so every rank cuts the same batches
+      samples = speech_input.bucket_by_length(samples, self.flags.batch_size * self.world, window, seed=self.shuffle_seed)
+    return samples
 
   def get_loader_limit_count(self) -> int:
     return self.flags.limit_training_set
@@ -43,6 +49,10 @@ class Training(execution.DatasetExecutor):
     model = speech_model.create_default_model(self.flags, self.input_size, self.speech_input)
     reset_to = self.flags.learning_rate if self.flags.reset_learning_rate else None
     model.restore_or_create(sess, self.flags.run_train_dir, reset_to)
+    if self.world > 1:
+      # data parallel: rank 0's weights / Adam state / counters go to every rank, gradients are SUM-all-reduced in buckets
+      # under back-prop, the global mean loss rides in the first bucket (speech_model.enable_data_parallel)
+      model.enable_data_parallel()
     return model
 
   def _end_of_window(self, sess, model, window, last_loss, summary, history):
@@ -50,7 +60,8 @@ class Training(execution.DatasetExecutor):
     perplexity = math.exp(float(last_loss)) if last_loss < 300 else float('inf')
     print('global step {:d} learning rate {:.4f} step-time {:.2f} average loss {:.2f} perplexity {:.2f}'.format(
         step, model.learning_rate.eval(), window.mean_step_time, last_loss, perplexity))
-    model.summary_writer.add_summary(summary, step)
+    if self.rank == 0:
+      model.summary_writer.add_summary(summary, step)
     decay = self.flags.learning_rate_decay_factor
     if decay > 0 and len(history) > 2 and window.mean_loss > max(history[-3:]):
       sess.run(model.learning_rate_decay_op)
@@ -61,7 +72,7 @@ class Training(execution.DatasetExecutor):
 
   def run(self, max_steps=None):
     """``max_steps`` (not a reference flag) bounds the loop for tests and smoke runs."""
-    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess:
+    with speech_model.Session(getattr(self.flags, 'device', 'cuda:0')) as sess, self.quiet_unless_rank0():
       model = self.create_model(sess)
       coordinator = self.start_pipeline(sess, n_threads=2)
       window = _Window(self.flags.steps_per_checkpoint)

@@ -96,41 +96,6 @@ def test_model_step_protocol_and_training_reduces_loss(dev, tmp_path):
   coord.request_stop()
 
 
-def test_model_step_through_the_whole_step_graph_equals_the_eager_step(dev, tmp_path):
-  """`model.step_graph = True`: SpeechModel.step runs a training step as one HIP-graph launch (engine.train_step_graph).  Two models
-  over the same cyclic batches, started from the same weights: losses, decodes, global_step and weights stay identical step for
-  step, with the other fetches (decode, labels, summary) and an evaluation step (update=False) in between."""
-  from speecht_amd.speech_model import Session, create_default_model
-  flags = Flags()
-  flags.log_dir = str(tmp_path / 'log')
-  models = []
-  for use_graph in (False, True):
-    loader, coord, _ = make_loader(16, 4, [121, 100, 90, 121])
-    model = create_default_model(flags, 16, loader)
-    model.step_graph = use_graph
-    models.append((model, coord))
-  with Session(dev) as sess_a, Session(dev) as sess_b:
-    (a, _), (b, _) = models
-    a.init_session(sess_a)
-    b.init_session(sess_b)
-    b.engine.params.copy_(a.engine.params)          # (init_session draws an unseeded Xavier sample per model)
-    b.engine.mark_weights_changed()
-    for k in range(7):
-      kw = dict(decode=(k == 3), return_label=(k == 3), summary=(k == 4))
-      ra, rb = a.step(sess_a, **kw), b.step(sess_b, **kw)
-      assert float(ra[0]) == float(rb[0]), (k, ra[0], rb[0])
-      if k == 3:
-        assert np.array_equal(ra[1][0].values, rb[1][0].values) and np.array_equal(ra[1][0].indices, rb[1][0].indices)
-      if k == 5:                                    # an evaluation step in between: eager on both, nothing changes
-        ea, eb = a.step(sess_a, update=False), b.step(sess_b, update=False)
-        assert float(ea[0]) == float(eb[0])
-      assert torch.equal(a.engine.params, b.engine.params), k
-      assert a.global_step.eval() == b.global_step.eval() == k + 1
-    assert len(b.engine._step_graphs) >= 1 and not hasattr(a.engine, '_step_graphs')
-  for _, coord in models:
-    coord.request_stop()
-
-
 def test_single_input_inference_matches_batch_padding_semantics(dev, tmp_path):
   """F7: nothing is masked, so logits depend on the padded batch length; a single utterance fed
   through SingleInputLoader must equal the oracle on that [1, T, C] tensor."""
@@ -283,69 +248,6 @@ def test_forward_graph_replays_bit_exactly(dev, mode):
   assert torch.equal(eng.logits_time_major(), eager)
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16x6'])
-def test_whole_step_graph_replay_is_bit_identical_to_the_eager_step(dev, mode):
-  """engine.train_step_graph: forward + CTC + backward + clip / Adam of a step as ONE captured HIP graph.  Two
-  engines from the same weights walk the same six steps over two alternating batches (same shape, different features, lengths and
-  labels -- one label set long enough to change the CTC kernel's states-per-lane class, i.e. a second graph key): one through the
-  eager sequence, one through train_step_graph (first sight of a key runs eagerly, the second captures, later ones replay; both
-  parities).  Weights, Adam moments and per-utterance losses must be bit-identical after every step; an eager step after the
-  graph steps continues bit-identically too (derived operands are rebuilt)."""
-  from speecht_amd.engine import Wav2LetterEngine
-  layers = WL.w2l_layers(16, width=128, fc=256)
-  params = WL.xavier_params(layers, seed=5, bias_range=0.05)
-  batches = []
-  for k, frames in enumerate(([200, 161, 200, 133], [97, 200, 200, 180])):
-    x, seq, labels = WL.make_batch(frames, 16, seed=10 + k)
-    batches.append((x, seq, labels))
-  long_labels = [list(np.random.default_rng(3).integers(0, 28, 40)) for _ in range(4)]      # 2 * 40 + 1 > 64: another class
-  batches.append((batches[0][0], batches[0][1], long_labels))
-
-  def make():
-    e = Wav2LetterEngine(layers, device=dev, conv_mode=mode)
-    e.fft_min_rows = e.fft_min_rows_narrow = 1               # every layer that can takes the frequency-domain path
-    e.set_weights(params)
-    return e
-
-  eager, graph = make(), make()
-  graph.enable_step_graph()
-  order = [0, 1, 0, 1, 0, 1, 2, 2, 2, 0, 1]
-  for step, k in enumerate(order):
-    x, seq, labels = batches[k]
-    for e in (eager, graph):
-      e.load_batch(x, seq)
-      e.set_labels(labels)
-    eager.forward()
-    eager.ctc_loss_grad(0.25)
-    eager.backward()
-    eager.apply_update(1e-3)
-    graph.train_step_graph(0.25, 1e-3)
-    la, lb = eager.fetch_losses(precise=True), graph.fetch_losses(precise=True)
-    assert np.array_equal(la, lb), (step, la, lb)
-    assert torch.equal(eager.params, graph.params) and torch.equal(eager.adam_m, graph.adam_m) and \
-        torch.equal(eager.adam_v, graph.adam_v), step
-    assert eager.step_count == graph.step_count == step + 1
-  assert len(graph._step_graphs) >= 3                        # both parities of the short-label class, and the long-label class
-  if mode == 'fp32':
-    assert len(graph.fft) == 9
-  # an eager step on the graph engine afterwards (evaluation, a caller that mixes the two): still in lock-step
-  x, seq, labels = batches[1]
-  for e in (eager, graph):
-    e.load_batch(x, seq)
-    e.set_labels(labels)
-    e.forward()
-    e.ctc_loss_grad(0.25)
-    e.backward()
-    e.apply_update(1e-3)
-  torch.cuda.synchronize()
-  assert torch.equal(eager.params, graph.params)
-  graph.load_batch(*batches[0][:2]); graph.set_labels(batches[0][2]); graph.train_step_graph(0.25, 1e-3)
-  eager.load_batch(*batches[0][:2]); eager.set_labels(batches[0][2])
-  eager.forward(); eager.ctc_loss_grad(0.25); eager.backward(); eager.apply_update(1e-3)
-  torch.cuda.synchronize()
-  assert torch.equal(eager.params, graph.params)
-
-
 DP_GPU_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
@@ -426,6 +328,50 @@ def test_data_parallel_two_ranks_on_one_gpu_match_single_process(dev, tmp_path):
   outs = [p.communicate(timeout=400)[0].decode() for p in procs]
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0 and 'ok' in o, 'rank {} failed:\n{}'.format(r, o)
+
+
+def test_cli_train_under_a_launcher_is_data_parallel(dev, tmp_path):
+  """`torchrun --nproc-per-node 2 speecht-cli train` (reference loop training.py:44-98): the two ranks share
+  cuda:0 over gloo (ST_SHARE_GPU / ST_DIST_BACKEND, the test knobs), each takes its rows of every global batch, gradients are
+  exchanged in buckets with the mean loss in the first one; rank 0 alone prints and writes.  Against ONE process with the global
+  batch size on the same seeded sample stream: same losses, same checkpoint to fp32 summation order; then `evaluate` under the
+  launcher: statistics gathered over the ranks."""
+  from tests.test_cli_data_parallel_cpu import make_corpus
+  make_corpus(str(tmp_path / 'data' / 'preprocessed-power' / 'train'), 12, 16, seed=2)
+  make_corpus(str(tmp_path / 'data' / 'preprocessed-power' / 'test'), 8, 16, seed=3)
+  cli = os.path.join(ROOT, 'speecht-cli')
+
+  def run(name, world, batch, command='train', extra=()):
+    args = [command, '--data-dir', str(tmp_path / 'data'), '--train-dir', str(tmp_path / ('train_' + name)), '--log-dir',
+            str(tmp_path / ('log_' + name)), '--run-name', 'dp', '--batch-size', str(batch), '--seed', '11'] + list(extra)
+    env = dict(os.environ, ST_SHARE_GPU='1', ST_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    head = [sys.executable] if world == 1 else [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+                                                str(world), '--master-addr', '127.0.0.1', '--master-port', '29671']
+    r = subprocess.run(head + [cli] + args, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+  train = ['--steps-per-checkpoint', '2', '--max-steps', '4', '--learning-rate', '1e-3']
+  single, dp = run('single', 1, 4, extra=train), run('dp', 2, 2, extra=train)
+  lines = lambda out: [l for l in out.splitlines() if l.startswith('global step')]
+  assert single.count('Model saved') == dp.count('Model saved') == 2 and dp.count('Begin training') == 1
+  for a, b in zip(lines(dp), lines(single)):
+    assert a.split()[:6] == b.split()[:6] and abs(float(a.split()[-3]) - float(b.split()[-3])) < 0.02, (a, b)
+  ck = lambda name: np.load(str(tmp_path / ('train_' + name) / 'dp' / 'speechT.ckpt-4.npz'))
+  a, b = ck('dp'), ck('single')
+  start = np.load(str(tmp_path / 'train_single' / 'dp' / 'speechT.ckpt-2.npz'))
+  moved = float(np.max(np.abs(b['params'] - start['params'])))
+  err = float(np.max(np.abs(a['params'] - b['params'])))
+  assert int(a['global_step']) == 4 and moved > 1e-4 and err < 2e-3 * moved, (err, moved)
+  assert sorted(os.listdir(str(tmp_path / 'train_dp' / 'dp'))) == sorted(os.listdir(str(tmp_path / 'train_single' / 'dp')))
+  # evaluation as replicas: every utterance of the global batches is decoded once, the global line counts them all
+  ev = ['--step-count', '2', '--no-save', '--pair-by-row']
+  one, two = run('single', 1, 4, 'evaluate', ev), run('single', 2, 2, 'evaluate', ev)
+  assert one.count('expected: ') == 8 and two.count('expected: ') == 4 and two.count('Global statistics') == 1
+  rates = lambda out: [float(v) for v in out.splitlines()[-1].replace(':', ' ').split()[1::2]]         # LED LER WED WER
+  # the same utterances, the same weights: the gathered line equals the single process's (a greedy tie may flip under another
+  # batch size's summation order, hence not to the last digit)
+  assert len(rates(two)) == 4 and np.allclose(rates(one), rates(two), atol=0.05), (one.splitlines()[-1], two.splitlines()[-1])
 
 
 def test_rejected_batch_leaves_weights_and_counters_untouched(dev, tmp_path):

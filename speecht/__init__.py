@@ -32,13 +32,19 @@ class _AliasFinder:
     import importlib.util
 
     class _Loader:
-      @staticmethod
-      def create_module(spec):
-        return importlib.import_module('speecht_amd.' + tail)
+      real_spec = None
 
-      @staticmethod
-      def exec_module(module):
-        pass
+      @classmethod
+      def create_module(cls, spec):
+        module = importlib.import_module('speecht_amd.' + tail)
+        cls.real_spec = module.__spec__
+        return module
+
+      @classmethod
+      def exec_module(cls, module):
+        # the import machinery has just stamped the ALIAS spec onto the speecht_amd module it was handed: put the module's own
+        # spec back, or `importlib.reload(speecht_amd.<module>)` would go looking for a loader that loads nothing
+        module.__spec__ = cls.real_spec
     return importlib.util.spec_from_loader(fullname, _Loader())
 
 

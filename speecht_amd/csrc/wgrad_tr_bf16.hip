@@ -421,9 +421,24 @@ TrPlan tr_plan(const st_tensor3& x, const st_tensor3& dz, int width, int pad_lef
 }
 
 bool tr_eligible(const st_tensor3* x, const st_tensor3* dz, int width, int stride, int pad_left) {
-  return x && dz && stride == 1 && width >= 1 && x->t_pitch == dz->t_pitch && x->batch == dz->batch && x->frames == dz->frames &&
-         x->halo >= pad_left && x->c_pitch % 8 == 0 && dz->c_pitch % 8 == 0 && dz->c_pitch >= dz->channels &&
-         (long)(x->halo - pad_left) + width - 1 <= (long)x->t_pitch;
+  if (!(x && dz && stride == 1 && width >= 1 && x->t_pitch == dz->t_pitch && x->batch == dz->batch && x->frames == dz->frames &&
+        x->halo >= pad_left && x->c_pitch % 8 == 0 && dz->c_pitch % 8 == 0 && dz->c_pitch >= dz->channels &&
+        (long)(x->halo - pad_left) + width - 1 <= (long)x->t_pitch))
+    return false;
+  // The kernel walks WHOLE 32-row stages over the flat rows and whole 128-column tiles over a row: its last stage, the taps'
+  // row shifts and a tile wider than what is left of the channel pitch all read past the last row of the planes.  The caller's
+  // contract is SLACK_ROWS readable zero rows behind each plane (st_conv1d_bwd_filter_tr_bf16_slack_rows): a geometry whose
+  // furthest read would leave that slack is refused here (workspace query 0, launch ST_EINVAL) instead of reading beyond it.
+  auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+  const long plane_rows = (long)x->batch * x->t_pitch;
+  const long rows = (long)(dz->batch - 1) * dz->t_pitch + dz->frames;
+  const long staged = cdiv(rows, TK) * TK;                                                 // rows the stages cover
+  const int n_pad = npad_of(dz->channels);
+  const long x_over = cdiv(x->c_pitch, TM) * TM - x->c_pitch, z_over = cdiv(n_pad, TN) * TN - dz->c_pitch;
+  const long x_spill = x_over > 0 ? cdiv(x_over, x->c_pitch) : 0, z_spill = z_over > 0 ? cdiv(z_over, dz->c_pitch) : 0;
+  const long x_last = (long)(x->halo - pad_left) + (width - 1) + staged - 1 + x_spill;     // furthest input row read
+  const long z_last = (long)dz->halo + staged - 1 + z_spill;                               // furthest gradient row read
+  return x_last < plane_rows + SLACK_ROWS && z_last < plane_rows + SLACK_ROWS;
 }
 
 }  // namespace

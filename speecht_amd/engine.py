@@ -245,6 +245,17 @@ class Wav2LetterEngine(DecodeMixin):
     self.mode.alloc(batch)                         # what this arithmetic needs beyond the shared buffers
     self._shape = (batch, frames)
 
+  def reserve(self, batch, max_frames, min_frames=None, step=64):
+    """Size every named device buffer for training batches of up to ``batch`` x ``max_frames`` BEFORE the first step: the
+    reference pads every batch to its own longest member (speech_input.py:37-45), so (B, max_T) changes nearly every step, and
+    the grow-only storage would otherwise re-allocate whenever a longer batch arrives.  Buffer sizes are not monotone in the
+    length (short batches split their reductions into slabs, the frequency-domain layers switch on above a row count), so a
+    ladder of lengths is described once -- host work and a few halo-clearing launches each -- largest first."""
+    lo = int(min_frames) if min_frames else int(step)
+    ladder = sorted({int(max_frames)} | set(range(lo, int(max_frames), int(step))), reverse=True)
+    for frames in ladder:
+      self._ensure_shape(int(batch), frames)
+
   def _planes(self, name, numel, n=3, slack=0):
     """n zeroed bf16 planes of `numel` elements each (whole buffer cleared when re-used).  ``slack``: that many further zero
     elements stay allocated behind the (single) plane -- readable zeros for kernels that run past the last row

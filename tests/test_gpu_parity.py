@@ -23,9 +23,9 @@ def dev():
   return 'cuda:0'
 
 
-def make_engine(layers, dev):
+def make_engine(layers, dev, conv_mode=None):
   from speecht_amd.engine import Wav2LetterEngine
-  return Wav2LetterEngine(layers, device=dev)
+  return Wav2LetterEngine(layers, device=dev, conv_mode=conv_mode)
 
 
 def rel_err(a, b):
@@ -578,6 +578,57 @@ def test_shape_switching_reuses_buffers_exactly(dev):
     assert torch.equal(outs[0][0], outs[1][0]), k
     assert torch.equal(outs[0][1], outs[1][1]), k
     assert torch.equal(outs[0][2], outs[1][2]), k
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_fifty_shapes_of_training_stay_bit_identical_to_fresh_engines_and_allocate_nothing(dev, mode):
+  """The reference's regime (speech_input.py:37-45,169-179; training.py:57-65): a new (B, max_T) nearly every step.  Fifty
+  training steps -- forward, CTC, backward, clip + Adam -- over ragged batches of changing batch size and length on ONE engine
+  (buffers re-described per shape, halos re-zeroed, derived operands rebuilt after every update); every step's logits, losses,
+  gradients and updated weights equal, bit for bit, those of an engine built fresh for that step from the same state.  Then
+  the same fifty shapes again on the warm engine: no buffer of its storage is re-allocated and the process makes no device
+  allocation at all (`reserve` + one pass is the warm-up)."""
+  layers = WL.w2l_layers(16, width=40, fc=72)
+  params = WL.xavier_params(layers, seed=9)
+  rng = np.random.default_rng(50)
+  shapes = [sorted(rng.integers(24, 200, int(rng.integers(2, 6))).tolist(), reverse=True) for _ in range(50)]
+  eng = make_engine(layers, dev, conv_mode=mode)
+  eng.set_weights(params)
+  eng.reserve(5, 200, min_frames=24, step=16)
+
+  def one_step(e, k, frames):
+    x, seq, labels = WL.make_batch(frames, 16, seed=300 + k)
+    e.load_batch(x, seq)
+    e.set_labels(labels)
+    e.forward()
+    e.ctc_loss_grad(1.0 / len(frames))
+    e.backward()
+    logits, grads, loss = e.X[-1].interior().clone(), e.grads.clone(), e.loss.clone()
+    e.apply_update(1e-3)
+    torch.cuda.synchronize()
+    return logits, grads, loss, e.params.clone()
+
+  for k, frames in enumerate(shapes):
+    fresh = make_engine(layers, dev, conv_mode=mode)
+    for name in ('params', 'adam_m', 'adam_v'):
+      getattr(fresh, name).copy_(getattr(eng, name))
+    fresh.step_count = eng.step_count
+    fresh.mark_weights_changed()
+    a, b = one_step(eng, k, frames), one_step(fresh, k, frames)
+    for what, u, v in zip(('logits', 'gradients', 'losses', 'weights'), a, b):
+      assert torch.equal(u, v), (k, frames, what, float((u - v).abs().max()))
+    del fresh
+  torch.cuda.synchronize()
+  torch.cuda.empty_cache()
+  generation = eng._storage.generation
+  stats = torch.cuda.memory_stats(dev)
+  mallocs, reserved = stats.get('num_device_alloc'), torch.cuda.memory_reserved(dev)
+  for k, frames in enumerate(shapes):
+    one_step(eng, k, frames)
+  assert eng._storage.generation == generation, 'the engine re-allocated a buffer on a shape it had seen'
+  # (one_step's clones come out of the caching allocator's pool; the engine itself must not have asked the device for memory)
+  after = torch.cuda.memory_stats(dev).get('num_device_alloc')
+  assert torch.cuda.memory_reserved(dev) <= reserved + (64 << 20) and (mallocs is None or after - mallocs <= 4), (mallocs, after)
 
 
 def test_ctc_long_form_kpl16(dev):

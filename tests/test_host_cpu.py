@@ -121,6 +121,7 @@ def test_speecht_import_names_resolve_to_the_native_modules():
   for name in ('vocabulary', 'preprocessing', 'speech_input', 'speech_model', 'evaluation', 'training', 'execution', 'exporting'):
     assert importlib.import_module('speecht.' + name) is importlib.import_module('speecht_amd.' + name), name
     assert getattr(speecht, name) is importlib.import_module('speecht_amd.' + name)
+    assert importlib.import_module('speecht_amd.' + name).__spec__.name == 'speecht_amd.' + name       # the alias import leaves the module's own spec
   from speecht.speech_model import Wav2LetterModel, create_default_model      # noqa: F401
   from speecht.speech_input import InputBatchLoader, SingleInputLoader       # noqa: F401
   from speecht import vocabulary

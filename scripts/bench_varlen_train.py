@@ -117,8 +117,44 @@ def run(order, batch, mels, rate, steps, warmup, pool_size, conv_mode, seed=0):
   return out
 
 
+def sweep(batch, mels, conv_mode, lengths, steps=12):
+  """Fixed-shape training steps (engine loop, data resident) at each padded length: which shapes run below the rate of the
+  bench shape -- per padded audio second -- and by how much."""
+  import bench
+  from speecht_amd.engine import Wav2LetterEngine
+  layers = WL.w2l_layers(mels)
+  eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode=conv_mode)
+  eng.init_xavier(seed=1)
+  rows = []
+  for frames in lengths:
+    x, seq, labels = WL.make_batch([frames] * batch, mels, seed=7)
+    feed = bench.HostFeed(eng, x, seq, labels)
+    for _ in range(3):
+      bench.train_step(eng, feed, None, 1e-4, batch)
+    torch.cuda.synchronize()
+    marks = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+      if k >= 2:
+        marks[k - 2].synchronize()
+      bench.train_step(eng, feed, None, 1e-4, batch)
+      ev = torch.cuda.Event()
+      ev.record()
+      marks.append(ev)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    blocks = -(-((frames + 1) // 2) // 64)
+    rows.append(dict(frames=frames, out_frames=(frames + 1) // 2, blocks=blocks, rows=batch * blocks, ms_per_step=round(ms, 3),
+                     us_per_padded_audio_second=round(ms * 1e3 / (batch * (frames - 1) / 100.0), 2),
+                     spectral_layers=sorted(getattr(eng, 'fft', {}) or getattr(eng, 'fftb', {}))))
+    print(json.dumps(rows[-1]))
+    sys.stdout.flush()
+  return rows
+
+
 def main():
   ap = argparse.ArgumentParser()
+  ap.add_argument('--sweep', type=int, nargs='*', default=None, help='fixed-shape step time at these padded lengths (frames) instead of the pool runs')
   ap.add_argument('--steps', type=int, default=60)
   ap.add_argument('--warmup', type=int, default=24)
   ap.add_argument('--pool', type=int, default=512)
@@ -129,6 +165,14 @@ def main():
   ap.add_argument('--conv-mode', default=None)
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
+  if args.sweep is not None:
+    lengths = args.sweep or list(range(201, 1502, 100))
+    rows = sweep(args.batch[0], args.mels[0], args.conv_mode, lengths)
+    if args.out:
+      with open(args.out, 'w') as f:
+        json.dump(rows, f, indent=1)
+    sys.stdout.flush()
+    os._exit(0)
   results = []
   for mels in args.mels:
     for batch in args.batch:

@@ -89,7 +89,7 @@ def trace_symbol(line):
 
 def trace_key(line):
   """A trace line without its measurements: identifies (kernel, shape, policy) of a launch."""
-  return ' '.join(t for t in line.split() if not (t.startswith('gflop=') or t.startswith('ms=')))
+  return ' '.join(t for t in line.split() if not (t.startswith('gflop=') or t.startswith('ms=') or t.startswith('mb=')))
 
 
 def trace_field(line, name):
@@ -244,6 +244,14 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
     if known:
       g.update(achieved=round(rate(fl, ms), 2), frac=round(rate(fl, ms) / PEAK_F32_TFLOPS, 4),
                algorithmic_gflop_per_launch=round(fl / n / 1e9, 2), algorithmic_mb_per_launch=round(by / n / 1e6, 2))
+    mb = [trace_field(l, 'mb') for l in rows]
+    if rows and all(v is not None for v in mb):
+      # the DFT / inverse-DFT transforms: bound by the bytes they move (HBM roof) with their matrix-pipe share beside it -- the
+      # trace line carries both the executed FLOPs and the algorithmic bytes of the launch (csrc/conv_fft.hip)
+      g.update(bound='hbm', algorithmic_mb_per_launch=round(sum(mb) / len(rows), 2),
+               hbm_gbs=round(sum(mb) / profiled_steps * 1e6 / (ms * 1e-3) / 1e9, 1),
+               hbm_frac=round(sum(mb) / profiled_steps * 1e6 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+               mfma_frac=round(rate(ex * 1e9, ms) / PEAK_F32_TFLOPS, 4))
     g['per_shape'] = {k: dict(launches_per_step=round(len(v) / profiled_steps, 2), avg_ms=round(float(np.mean(v)), 4),
                               tflops=round(rate(alg[k][0], float(np.mean(v))), 1) if k in alg else None) for k, v in per.items()}
     return g

@@ -143,6 +143,7 @@ def sweep(batch, mels, conv_mode, lengths, steps=12):
       marks.append(ev)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    eng.discard_staged_batch(feed.staged)          # (the feed keeps one batch staged ahead: release its buffer for the next shape's)
     blocks = -(-((frames + 1) // 2) // 64)
     rows.append(dict(frames=frames, out_frames=(frames + 1) // 2, blocks=blocks, rows=batch * blocks, ms_per_step=round(ms, 3),
                      us_per_padded_audio_second=round(ms * 1e3 / (batch * (frames - 1) / 100.0), 2),

@@ -65,13 +65,19 @@ int half_of(int cp) { return (int)st::round_up(cp, 64); }
 struct Plan {
   int n, blocks, bins, rows, rows_pad;
 };
-Plan make_plan(int width, int frames, int batch) {
+// rows of a bin's plane are padded to whole GEMM row tiles.  ROWS_F32 (the fp32 entry points): 64 -- the persistent per-bin
+// kernel's tile height; the 128-row kernels take a partial last tile.  Real training batches change (B, max_T) every step
+// (speech_input.py:37-45): with 32 utterances every odd block count padded to 128 rows wasted up to 37 % of the per-bin products
+// (601 input frames: 160 rows -> 256; scripts/bench_varlen_train.py --sweep).  The plane entry points (bf16 matrix pipe: 256- and
+// 128-row tiles without partial-tile handling) and the sizing functions keep 128 (sizes: an upper bound for both).
+constexpr int ROWS_F32 = 64;
+Plan make_plan(int width, int frames, int batch, int row_granule = 128) {
   Plan p;
   p.n = V + width - 1;
   p.blocks = st::ceil_div(frames, V);
   p.bins = p.n / 2 + 1;
   p.rows = batch * p.blocks;
-  p.rows_pad = (int)st::round_up(p.rows, 128);
+  p.rows_pad = (int)st::round_up(p.rows, row_granule);
   return p;
 }
 
@@ -846,8 +852,11 @@ void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float
   const int nchunks = st::ceil_div(half, 32);
   const int wgs = std::min(transform_wgs(), st::ceil_div(pl.rows_pad * nchunks, 4));
   const int nst = frames_used <= 6 * CH ? 3 : 4;                           // the matrix has no columns past frames_used
-  st::trace("dft_rows<%d%s%s> rows=%d chunks=%d bins=%d gflop=%.3f", nst, tb ? ",bf16-in" : "", planes == 1 ? ",bf16-out" : planes == 3 ? ",x3-out" : "",
-            pl.rows, nchunks, pl.bins, 4096e-9 * pl.rows * (double)nchunks * nst * CH * 3);
+  // mb = the bytes the transform has to move: every frame of the tensor once, every spectrum value (and its rotated copy) once
+  const double esz_in = tb ? 2.0 : 4.0, esz_out = planes == 0 ? 4.0 : 2.0 * planes;
+  st::trace("dft_rows<%d%s%s> rows=%d chunks=%d bins=%d gflop=%.3f mb=%.2f", nst, tb ? ",bf16-in" : "", planes == 1 ? ",bf16-out" : planes == 3 ? ",x3-out" : "",
+            pl.rows, nchunks, pl.bins, 4096e-9 * pl.rows * (double)nchunks * nst * CH * 3,
+            1e-6 * ((double)t.batch * t.frames * t.c_pitch * esz_in + (double)pl.bins * pl.rows * 2 * half * esz_out * (out2 ? 2 : 1)));
   RowsIn x = rows_in(t);
   if (tb) x.base_b = reinterpret_cast<const unsigned short*>(tb) + (long)t.halo * t.c_pitch;
   unsigned short* ob = reinterpret_cast<unsigned short*>(outb);
@@ -870,8 +879,9 @@ void launch_idft(const float* in, const float* winv, const Plan& p, int half_in,
   const dim3 grid(std::min(transform_wgs(), st::ceil_div(p.rows * nchunks, 4)));
   const int hp = p.bins <= 36 ? 18 : 24;
   const bool bf = out.base_b != nullptr;                       // bf16 activations: bf16 output and bf16 mask source
-  st::trace("idft_rows<%d,%d%s> rows=%d chunks=%d bins=%d gflop=%.3f", TERMS, hp, bf ? ",bf16" : "", p.rows, nchunks, p.bins,
-            4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1));
+  st::trace("idft_rows<%d,%d%s> rows=%d chunks=%d bins=%d gflop=%.3f mb=%.2f", TERMS, hp, bf ? ",bf16" : "", p.rows, nchunks, p.bins,
+            4096e-9 * p.rows * (double)nchunks * 2 * hp * (TERMS + 1),
+            1e-6 * ((double)p.bins * p.rows * 2 * half_in * 4 + (double)p.rows * V * out.c_pitch * (bf ? 2.0 : 4.0) * (mask ? 2 : 1)));
   const float* mk = reinterpret_cast<const float*>(mask);
   st::LaunchTimer timer(s);
 #define ST_IDFT(HPV, BFV)                                                                                                     \
@@ -1033,7 +1043,7 @@ int st_conv1d_nwc_fwd_fft_chain_f32(const st_tensor3* x, const float* gfwd, cons
   ST_REQUIRE(npad_of(y->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, y, width), "conv fft fwd: workspace / shape");
   if (next_sf_written) *next_sf_written = 0;
   hipStream_t s = st::as_stream(stream);
-  const Plan p = make_plan(width, y->frames, y->batch);
+  const Plan p = make_plan(width, y->frames, y->batch, ROWS_F32);
   const int ka = 2 * half_of(x->c_pitch), npo = npad_of(y->channels), nf = 2 * npo;
   float* const sk = reinterpret_cast<float*>(workspace);
   float* yf = sk + st::SK_WS_FLOATS;
@@ -1047,11 +1057,15 @@ int st_conv1d_nwc_fwd_fft_chain_f32(const st_tensor3* x, const float* gfwd, cons
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames, nullptr};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
   if (next_tables && next_sf && can_fuse_next(p, *y, next_width, next_pad_left)) {
-    const Plan pn = make_plan(next_width, y->frames, y->batch);
+    const Plan pn = make_plan(next_width, y->frames, y->batch, ROWS_F32);
     const int half_n = half_of(y->c_pitch), ka_n = 2 * half_n;
     const long sn_bin = 2L * pn.rows_pad * ka_n;
     float* rot = split_lag_products(half_n) ? next_sf + (long)pn.rows_pad * ka_n : nullptr;
-    st::trace("idft_dft_rows<%d> rows=%d chunks=%d bins=%d next_bins=%d", p.bins <= 36 ? 18 : 24, p.rows, nchunks, p.bins, pn.bins);
+    // gflop: the inverse transform's 2 * HP k-steps on two 32-frame tiles, then 32 + FUSE_HALO k-steps on the next layer's three
+    // 32-row tiles; mb: this layer's output spectra in, the activation tensor and the next layer's input spectra (+ rotated copy) out
+    st::trace("idft_dft_rows<%d> rows=%d chunks=%d bins=%d next_bins=%d gflop=%.3f mb=%.2f", p.bins <= 36 ? 18 : 24, p.rows, nchunks, p.bins, pn.bins,
+              4096e-9 * p.rows * (double)nchunks * (2 * (p.bins <= 36 ? 18 : 24) * 2 + (32 + FUSE_HALO) * 3),
+              1e-6 * 4 * ((double)p.bins * p.rows * 2 * npo + (double)p.rows * V * y->c_pitch + (double)pn.bins * p.rows * 2 * half_n * (rot ? 2 : 1)));
     const dim3 grid(y->batch * nchunks), block(64 * FUSE_BLOCKS);
     st::LaunchTimer timer(s);
     if (p.bins <= 36)
@@ -1076,14 +1090,14 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
 
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tables && zf && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft dz spectra: bad argument");
-  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
   launch_dft(*dz, nullptr, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, nullptr, 0, 0, nullptr, st::as_stream(stream));
   return st::check_launch("conv fft dz spectra");
 }
 
 int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf, float* dbias, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && zf && dbias && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft bias grad: bad argument");
-  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
   const int np = npad_of(dz->channels);
   hipLaunchKernelGGL(bias_from_spectra_kernel, dim3(st::ceil_div(np, 32)), dim3(256), 0, st::as_stream(stream), zf, p.rows, 2 * np,
                      dz->channels, np, dbias);
@@ -1106,7 +1120,7 @@ int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, 
                       "conv fft bwd_data: mask tensor mismatch");
   if (below_zf_written) *below_zf_written = 0;
   hipStream_t s = st::as_stream(stream);
-  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
   // X[bin] = Z[bin] (rows x 2 npo) * gfwd[bin]^T (2 npo x 2 cph): the forward spectra read as a transposed operand
   const int kz = 2 * npad_of(dz->channels), cph = half_of(dx->c_pitch), nb = 2 * cph;
   float* const sk = reinterpret_cast<float*>(workspace);
@@ -1125,8 +1139,12 @@ int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, 
     // the layer below's dz spectra ride along when its zf rows are laid out like this call's columns
     const bool below = below_tables && below_zf && width_ok(below_width) && npad_of(dx->channels) % 128 == 0 &&
                        npad_of(dx->channels) == cph && 32 * nchunks == cph;
-    const Plan pb = make_plan(below ? below_width : width, dx->frames, dx->batch);
-    st::trace("idft_ola_dft_rows<%d%s> rows=%d chunks=%d bins=%d", p.bins <= 36 ? 18 : 24, below ? ",dz-spectra" : "", p.rows, nchunks, p.bins);
+    const Plan pb = make_plan(below ? below_width : width, dx->frames, dx->batch, ROWS_F32);
+    // gflop: the whole-window inverse (2 * HP k-steps, three 32-row tiles), then the 32 k-steps of the layer below's zero-padded
+    // forward transform (three tiles); mb: this layer's dx spectra and the ReLU mask in, dx and the layer below's dz spectra out
+    st::trace("idft_ola_dft_rows<%d%s> rows=%d chunks=%d bins=%d gflop=%.3f mb=%.2f", p.bins <= 36 ? 18 : 24, below ? ",dz-spectra" : "", p.rows, nchunks, p.bins,
+              4096e-9 * p.rows * (double)nchunks * (2 * (p.bins <= 36 ? 18 : 24) * 3 + (below ? 32 * 3 : 0)),
+              1e-6 * 4 * ((double)p.bins * p.rows * 2 * cph + (double)p.rows * V * dx->c_pitch * (mask ? 2 : 1) + (below ? (double)pb.bins * p.rows * 2 * cph : 0.0)));
     const dim3 grid(dx->batch * nchunks), block(64 * FUSE_BLOCKS);
     const float* wz = below ? below_tables + T_ZP : nullptr;
     st::LaunchTimer timer(s);
@@ -1328,7 +1346,7 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   ST_REQUIRE(x->batch == dz->batch && x->frames == dz->frames, "conv fft bwd_filter: stride-1 layers only");
   ST_REQUIRE(npad_of(dz->channels) % 128 == 0 && workspace_bytes >= st_conv1d_fft_ws(x, dz, width), "conv fft bwd_filter: workspace / shape");
   hipStream_t s = st::as_stream(stream);
-  const Plan p = make_plan(width, dz->frames, dz->batch);
+  const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
   const f32x2* tw = reinterpret_cast<const f32x2*>(tables + T_FW);
   const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;

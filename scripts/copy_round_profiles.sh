@@ -30,6 +30,11 @@ cp $F/mel_traffic_b512.json ${P}_mel_traffic_b512.json
 cp $F/mel_timing.txt ${P}_mel_timing.txt
 for M in fp32 bf16; do cp $F/host_cost_$M.json ${P}_host_cost_$M.json; cp $F/api_train_$M.json ${P}_api_train_$M.json; done
 cp $F/forced_build.txt ${P}_forced_build.txt
+for f in varlen_train_fp32_b32_m80 varlen_train_fp32_b64_m128_22050hz varlen_train_bf16_b32_m80 step_by_length_fp32 step_by_length_bf16 \
+         api_train_fp32_world2_shared_gpu api_train_bf16_world2_shared_gpu bench_fp32_world2_shared_gpu bench_bf16_world2_shared_gpu \
+         head_bubble_fp32 head_bubble_bf16 ctc_mask_probe; do
+  [ -f $F/$f.json ] && cp $F/$f.json ${P}_$f.json
+done
 python - <<'PY'
 import json
 from speecht_amd import build

@@ -34,5 +34,19 @@ bash scripts/gpu_pmc_shapes.sh r${R}_bf16 --conv-mode bf16 > $F/pmc_shapes_bf16.
 bash scripts/gpu_pmc_shapes.sh r${R}_fp32 > $F/pmc_shapes_fp32.txt 2>&1
 # the bf16 step's own kernels (filter gradients through transposing reads, the 7-tap panel kernel): same counters
 KERNEL_FILTER='((?:conv_taps_bf16_kernel|wgrad_tr_bf16_kernel<[^>]*>))' bash scripts/gpu_pmc_shapes.sh r${R}_bf16_new --conv-mode bf16 > $F/pmc_shapes_bf16_round5_kernels.txt 2>&1
+# round 6: training in the reference's real regime (a new (B, max_T) per step), the per-length step sweep, the data-parallel API
+# loop on a shared GPU, the step-head and CU-masked-CTC probes
+timeout 600 python scripts/bench_varlen_train.py --batch 32 --mels 80 --out $F/varlen_train_fp32_b32_m80.json > /dev/null 2>&1
+timeout 600 python scripts/bench_varlen_train.py --batch 64 --mels 128 --rate 22050 --steps 40 --out $F/varlen_train_fp32_b64_m128_22050hz.json > /dev/null 2>&1
+timeout 600 python scripts/bench_varlen_train.py --batch 32 --mels 80 --conv-mode bf16 --out $F/varlen_train_bf16_b32_m80.json > /dev/null 2>&1
+timeout 600 python scripts/bench_varlen_train.py --sweep --out $F/step_by_length_fp32.json > /dev/null 2>&1
+timeout 600 python scripts/bench_varlen_train.py --sweep --conv-mode bf16 --out $F/step_by_length_bf16.json > /dev/null 2>&1
+for M in fp32 bf16; do
+  timeout 300 python scripts/bench_api_train.py --conv-mode $M --world 2 2>/dev/null | grep '^{' > $F/api_train_${M}_world2_shared_gpu.json
+  ST_SHARE_GPU=1 ST_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --steps-only --conv-mode $M 2>/dev/null | grep '^{' > $F/bench_${M}_world2_shared_gpu.json
+  python scripts/exp/head_bubble.py --conv-mode $M 2>/dev/null | grep '^{' > $F/head_bubble_$M.json
+done
+python scripts/exp/ctc_mask_probe.py 2>/dev/null | grep '^{' > $F/ctc_mask_probe.json
+cat $F/varlen_train_fp32_b32_m80.json | cut -c1-1200
 find gpurun_out -name '*.csv' -size +4M -delete
 du -sh gpurun_out | tail -1

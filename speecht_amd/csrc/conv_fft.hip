@@ -793,6 +793,103 @@ __global__ __launch_bounds__(256) void filters_idft_kernel(const float* __restri
   for (int w = 0; w < width; ++w) dpacked[((long)w * cpi + c) * npo + o] = acc[w];
 }
 
+// ---- the same inverse transform on the matrix pipe (round 6) -------------------------------------------------------
+// dF[w][(c, o)] = sum over (bin, part) of T[w][(bin, part)] * q[(bin, part)][(c, o)] is a product with a CONSTANT 32 x K matrix
+// (K = 2 or 4 values per bin, <= 192): as one thread per (c, o) it cost 2 * W fmas per value on the vector ALU -- the 32-tap layer
+// 3.2 GFLOP there, 78 us for 201 MB on the compute stream's critical path -- and with few (c, o) pairs it was a chain of dependent
+// loads on a fraction of the chip (the 25-tap first layer: 160 workgroups, 45 bins, 60 us at the very end of the backward pass).
+// Here a wavefront owns 32 * VW consecutive output channels o of one input channel c: T sits in LDS pair-interleaved (an A
+// fragment is one ds_read_b32, as in the transforms above), a lane loads VW consecutive floats of a part's row per k-step (the
+// half-waves read the two parts of a k-step: 128 * VW-byte runs), VW accumulator tiles, loads one stage ahead of the MFMAs.
+// Rows w >= W of T are zero; the taps come out as accumulator rows and leave as VW-float stores.
+constexpr int FI_CH = 12;                    // k-steps per stage
+constexpr int FI_SMAX = 96;                  // k-steps: 4 parts x 48 bins / 2
+struct IdftParts { long off[4]; };           // float offsets of a bin's parts inside its plane (c = 0, o = 0)
+template <int VW>
+__global__ __launch_bounds__(256, 2) void filters_idft_mfma_kernel(const float* __restrict__ q, int width, int cin, int cout, int cpi,
+                                                                   int npo, int n, int bins, const f32x2* __restrict__ tw,
+                                                                   float* __restrict__ dpacked, int pshift, long plane, IdftParts parts,
+                                                                   int ld, int ochunks, int items) {
+  typedef float vec __attribute__((ext_vector_type(VW)));
+  __shared__ float tl[FI_SMAX * 32 * 2];                                      // [k-step][tap w][h]
+  const int nparts = 1 << pshift, S = (nparts * bins) >> 1, stages = (S + FI_CH - 1) / FI_CH;
+  {
+    // split form: parts {Re, Im} -> {+cos, -sin};  block form: {P00, P11, P10, P01} (Re = P00 + P11, Im = P10 - P01) -> {+cos, +cos, -sin, +sin}
+    const float inv_n = 1.f / (float)n;
+    for (int i = threadIdx.x; i < stages * FI_CH * 64; i += 256) {
+      const int hh = i & 1, m = (i >> 1) & 31, sidx = i >> 6;
+      float v = 0.f;
+      if (sidx < S && m < width) {
+        const int kk = 2 * sidx + hh, k = kk >> pshift, part = kk & (nparts - 1);
+        const float wk = (k == 0 || 2 * k == n) ? inv_n : 2.f * inv_n;         // DC (and the Nyquist bin of an even N) count once
+        const f32x2 t = tw[k * width + m];
+        if (nparts == 2) v = part == 0 ? wk * t[0] : -wk * t[1];
+        else v = part < 2 ? wk * t[0] : (part == 2 ? -wk * t[1] : wk * t[1]);
+      }
+      tl[i] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
+  const float* afrag = tl + 2 * l31 + h;
+  for (int item = gw; item < items; item += total) {
+    const int c = item / ochunks, o0 = (item - c * ochunks) * (32 * VW) + l31 * VW;
+    f32x16 acc[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    if (c < cin) {                                                            // (wave-uniform; pad channels get zeros)
+      const float* base = q + (long)c * ld + o0;
+      auto load = [&](vec (&bf)[FI_CH], int st) {
+#pragma unroll
+        for (int j = 0; j < FI_CH; ++j) {
+          const int kk = 2 * min(st * FI_CH + j, S - 1) + h;                   // (k-steps past the end re-read the last one against zero rows of T)
+          bf[j] = *reinterpret_cast<const vec*>(base + (long)(kk >> pshift) * plane + parts.off[kk & (nparts - 1)]);
+        }
+      };
+      auto mac = [&](const vec (&bf)[FI_CH], int st) {
+        const float* a = afrag + st * (FI_CH * 64);
+#pragma unroll
+        for (int j = 0; j < FI_CH; ++j)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j * 64], bf[j][e], acc[e], 0, 0, 0);
+          }
+      };
+      vec bfr[2][FI_CH];
+      load(bfr[0], 0);
+      for (int st = 0; st < stages; st += 2) {                                // (two stages per trip: the buffers keep compile-time names)
+        if (st + 1 < stages) load(bfr[1], st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bfr[0], st);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < stages) {
+          if (st + 2 < stages) load(bfr[0], st + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mac(bfr[1], st + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (c < cpi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int w = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (w < width) {
+          vec v;
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            v[e] = o0 + e < cout ? acc[e][r] : 0.f;
+          }
+          *reinterpret_cast<vec*>(dpacked + ((long)w * cpi + c) * npo + o0) = v;
+        }
+      }
+    }
+  }
+}
+
 // ---- bias gradient from the spectra of dz: bin 0 of a block is the plain sum of its 64 frames, so
 // dbias[o] = sum_rows Z[0][row][o] -- 256 x n floats instead of a pass over the whole gradient tensor.
 // 32 columns x 8 row-lanes per block, fixed summation order.
@@ -918,6 +1015,41 @@ bool can_fuse_next(const Plan& p, const st_tensor3& y, int next_width, int next_
 }
 
 
+// the filter gradient's inverse transform: the matrix-pipe kernel (widths up to 32, output channels packing to whole 32 * VW
+// chunks), else -- or with st_set_tuning("filters_idft_valu", 1), for A/B runs and the parity test of the two -- one thread per (c, o)
+void launch_filters_idft(const float* qf, int width, int cin, int cout, int cpi, int cph, int npo, int n, int bins, const f32x2* tw,
+                         float* dpacked, int split, hipStream_t s) {
+  if (width <= 32 && npo % 128 == 0 && (split ? 2 : 4) * bins <= 2 * FI_SMAX && st::tuning(st::TUNE_FILTERS_IDFT_VALU) == 0) {
+    IdftParts parts;
+    long plane;
+    int ld;
+    if (split) {                       // q [bins][2][cph][npo]
+      plane = 2L * cph * npo; ld = npo;
+      parts.off[0] = 0; parts.off[1] = (long)cph * npo; parts.off[2] = parts.off[3] = 0;
+    } else {                           // q [bins][2 cph][2 npo]: P00 (c, o), P11 (cph + c, npo + o), P10 (cph + c, o), P01 (c, npo + o)
+      plane = 2L * cph * 2 * npo; ld = 2 * npo;
+      parts.off[0] = 0; parts.off[1] = (long)cph * 2 * npo + npo; parts.off[2] = (long)cph * 2 * npo; parts.off[3] = npo;
+    }
+    // the widest loads that still leave the chip a few thousand wavefront items
+    const int vw = (long)cpi * (npo / 128) >= 2048 ? 4 : ((long)cpi * (npo / 64) >= 2048 ? 2 : 1);
+    const int ochunks = npo / (32 * vw), items = cpi * ochunks;
+    const dim3 grid(std::min(1024, st::ceil_div(items, 4)));
+    st::trace("filters_idft_mfma<%d> taps=%d bins=%d parts=%d items=%d gflop=%.3f mb=%.2f", vw, width, bins, split ? 2 : 4, items,
+              4096e-9 * items * (double)vw * st::ceil_div((split ? 2 : 4) * bins / 2, FI_CH) * FI_CH,
+              1e-6 * 4 * ((double)(split ? 2 : 4) * bins * cin * npo + (double)width * cpi * npo));
+    st::LaunchTimer timer(s);
+#define ST_FI(VWV) st::launch_timed(timer, filters_idft_mfma_kernel<VWV>, grid, dim3(256), s, qf, width, cin, cout, cpi, npo, n, bins, tw, dpacked, \
+                                    split ? 1 : 2, plane, parts, ld, ochunks, items)
+    if (vw == 4) ST_FI(4); else if (vw == 2) ST_FI(2); else ST_FI(1);
+#undef ST_FI
+    return;
+  }
+  const dim3 grid(st::ceil_div(npo, 256), cpi);
+  if (width == 32) hipLaunchKernelGGL(filters_idft_kernel<32>, grid, dim3(256), 0, s, qf, width, cin, cout, cpi, cph, npo, n, bins, tw, dpacked, split);
+  else if (width == 25) hipLaunchKernelGGL(filters_idft_kernel<25>, grid, dim3(256), 0, s, qf, width, cin, cout, cpi, cph, npo, n, bins, tw, dpacked, split);
+  else if (width == 7) hipLaunchKernelGGL(filters_idft_kernel<7>, grid, dim3(256), 0, s, qf, width, cin, cout, cpi, cph, npo, n, bins, tw, dpacked, split);
+  else hipLaunchKernelGGL(filters_idft_kernel<0>, grid, dim3(256), 0, s, qf, width, cin, cout, cpi, cph, npo, n, bins, tw, dpacked, split);
+}
 
 }  // namespace
 
@@ -1304,14 +1436,13 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
   unsigned short* zt_planes = st_planes + (size_t)planes * 2 * ka * red;                   // [planes][nf][red] (split: [npo][2 red])
   const unsigned short* sfp = reinterpret_cast<const unsigned short*>(sf_planes);
   const unsigned short* zfp = reinterpret_cast<const unsigned short*>(zf_planes);
-  const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
   if (split_lag_products(half) && planes == 1 && npo % 128 == 0 && (2 * p.rows_pad) % 32 == 0 && st::tuning(st::TUNE_BF16_LAG_COPIES) == 0) {
     // round 5: the same two products per bin straight from the spectra planes -- both operands are reduction-major as they lie,
     // and ds_read_b64_tr_b16 hands the matrix pipe its reduction-minor fragments (wgrad_tr_bf16.hip); the rotated operand is a
     // register shuffle there.  No transposing copies (2 launches, 52 us per step at config 2); st_set_tuning("bf16_lag_copies", 1)
     // keeps the round-4 form for A/B runs and for the parity test that holds the two against each other.
     if (int e = st::lag_products_tr_bf16(sfp, zfp, p.bins, p.rows_pad, half, npo, qf, s)) return e;
-    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+    launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1, s);
     return st::check_launch("conv fft planes bwd_filter");
   }
   if (split_lag_products(half)) {
@@ -1325,7 +1456,7 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
     if (int e = st::gemm_bf16_bins(planes, st_planes, (size_t)2 * ka * red, 4 * red, 2L * p.rows_pad, zt_planes, (size_t)nf * red, 2 * red,
                                    2L * p.rows_pad, qf, npo, half, 2 * p.rows_pad, npo, 2 * p.bins, s, 1))
       return e;
-    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+    launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1, s);
     return st::check_launch("conv fft planes bwd_filter");
   }
   for (int pl = 0; pl < planes; ++pl) {
@@ -1336,7 +1467,7 @@ int st_conv1d_nwc_bwd_filter_fft_planes(const st_tensor3* x, const st_tensor3* d
   if (int e = st::gemm_bf16_bins(planes, st_planes, (size_t)ka * red, red, p.rows_pad, zt_planes, (size_t)nf * red, red, p.rows_pad, qf, nf, ka,
                                  p.rows_pad, nf, p.bins, s))
     return e;
-  ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0);
+  launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0, s);
   return st::check_launch("conv fft planes bwd_filter");
 }
 
@@ -1351,7 +1482,6 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
   const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin (st_conv1d_fft_sf_floats)
-  const dim3 grid(st::ceil_div(npo, 256), x->c_pitch);
   if (split_lag_products(half)) {
     // The lag products Q = S^H-like sums over the rows of a bin:  Re Q = S_r^T Z_r + S_i^T Z_i,  Im Q = S_i^T Z_r - S_r^T Z_i.
     // A spectra row [re | im] read as TWO rows of half length turns each into ONE plain product over 2 * rows_pad rows:
@@ -1363,13 +1493,13 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
     if (int e = st::gemm_tn_batched(sf, half, (long)p.rows_pad * ka, zf, npo, (long)p.rows_pad * nf, qf, (long)half * npo, 2 * p.rows_pad,
                                     half, npo, 2 * p.bins, s, 1))
       return e;
-    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1);
+    launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1, s);
   } else {
     // (spectra halves that do not tile the kernel -- the polyphase first layer: 192 columns): Q[bin] = [S_r | S_i]^T [Z_r | Z_i],
     // 2 half x 2 npo, combined by filters_idft
     if (int e = st::gemm_tn_batched(sf, ka, s_bin, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf, p.bins, s))
       return e;
-    ST_FFT_WIDTH_DISPATCH(filters_idft_kernel, qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0);
+    launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0, s);
   }
   return st::check_launch("conv fft bwd_filter");
 }

@@ -31,7 +31,20 @@ def dev_tensor(dev, batch, frames, channels, halo_l, halo_r, data=None):
 
 @pytest.mark.parametrize('W,B,T,cin,cout,relu', [(32, 3, 77, 130, 200, True), (32, 2, 200, 250, 300, False), (32, 5, 63, 250, 129, True),
                                                  (7, 4, 150, 250, 250, True), (7, 2, 64, 130, 129, False), (12, 3, 100, 200, 250, True)])
-def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
+@pytest.mark.parametrize('idft_valu', [0, 1])
+def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu, idft_valu):
+  # idft_valu: the filter gradient's inverse transform on the matrix pipe (filters_idft_mfma_kernel, round 6) or as one thread
+  # per (c, o) on the vector ALU (st_set_tuning("filters_idft_valu", 1)); both the split and the 2 x 2 block form of the lag
+  # products occur in the shapes above (spectra halves of 256 / 192 columns)
+  from speecht_amd._lib import set_tuning
+  set_tuning('filters_idft_valu', idft_valu)
+  try:
+    _fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu)
+  finally:
+    set_tuning('filters_idft_valu', 0)
+
+
+def _fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu):
   from speecht_amd import _lib
   from speecht_amd._lib import call
   from speecht_amd.engine import channel_pitch

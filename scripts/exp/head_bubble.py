@@ -23,11 +23,12 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--conv-mode', default='fp32')
   ap.add_argument('--steps', type=int, default=40)
+  ap.add_argument('--frames', type=int, default=1001)
   args = ap.parse_args()
   layers = WL.w2l_layers(80)
   eng = Wav2LetterEngine(layers, device='cuda:0', conv_mode=args.conv_mode)
   eng.init_xavier(seed=1)
-  x, seq, labels = WL.make_batch([1001] * 32, 80, seed=100)
+  x, seq, labels = WL.make_batch([args.frames] * 32, 80, seed=100)
   feed = bench.HostFeed(eng, x, seq, labels)
   import speecht_amd.modes.bf16 as mb
   import speecht_amd.modes.fp32 as mf
@@ -68,7 +69,7 @@ def main():
   torch.cuda.synchronize()
   h = sorted(a.elapsed_time(b) * 1e3 for a, b in heads)
   s = sorted(a.elapsed_time(b) for a, b in steps)
-  print(json.dumps(dict(conv_mode=args.conv_mode, steps=len(h), head_us_median=round(h[len(h) // 2], 1), head_us_min=round(h[0], 1),
+  print(json.dumps(dict(conv_mode=args.conv_mode, frames=args.frames, steps=len(h), head_us_median=round(h[len(h) // 2], 1), head_us_min=round(h[0], 1),
                         head_us_max=round(h[-1], 1), step_ms_median=round(s[len(s) // 2], 3),
                         note='head = compute stream from behind the update (+ the bottom layer\'s operand refresh) to in front of the '
                              'first convolution launch of the next step: input hand-over copy, cast / forward transform inputs')))

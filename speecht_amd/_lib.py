@@ -191,6 +191,10 @@ def load():
       fn.restype = res
       fn.argtypes = args
     _lib = lib
+    # ST_TUNE="knob=value,knob=value": st_set_tuning overrides for A/B runs of scripts that have no --tune option (experiments only)
+    for item in filter(None, os.environ.get('ST_TUNE', '').split(',')):
+      name, _, value = item.partition('=')
+      check(lib.st_set_tuning(name.strip().encode(), int(value)), 'ST_TUNE ' + item)
   return _lib
 
 

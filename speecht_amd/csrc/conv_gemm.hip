@@ -1195,7 +1195,13 @@ int fwd_splits(int M, int Np, int nk) {
   // The 29-class output layer at full batch (L10: 16032 x 2016 x 32) is an HBM stream of the activations with
   // one 128-row tile per workgroup: 126 workgroups leave half the CUs without any and every workgroup walks 1 MB
   // alone (72 us for 130 MB).  Four slices of the reduction put ~2 workgroups on every CU.
-  if (Np == 32 && !forced) return (M >= 4096 && nk >= 32) ? 4 : 1;
+  // (round 6: shorter batches too -- 32 x 2 s is 3 232 rows = 26 workgroups, 58 us unsplit; about two workgroups per CU, at most
+  // eight slices of at least four k-tiles)
+  if (Np == 32 && !forced) {
+    if (M < 1024 || nk < 32) return 1;
+    const int tiles_m = st::ceil_div(M, 128);
+    return std::max(1, std::min(std::min(8, nk / 4), (512 + tiles_m / 2) / tiles_m));
+  }
   if (Np % 128) return 1;
   const long tiles128 = (long)st::ceil_div(M, 128) * (Np / 128);
   if (forced) return std::max(1, std::min(forced, nk));
@@ -1258,7 +1264,7 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
       return ST_EINVAL;
     }
     const long tiles128 = (long)st::ceil_div(p.M, 128) * (p.Np / 128) * std::max(1, p.batches);
-    if ((p.batches > 0 && tiles128 < 512) || (p.batches <= 0 && tiles128 < 192 && p.splits <= 1)) launch_nn<64, 128, 2, 2, true, true>(p, epi, s);
+    if ((p.batches > 0 && (tiles128 < 512 || p.M <= 64)) || (p.batches <= 0 && tiles128 < 192 && p.splits <= 1)) launch_nn<64, 128, 2, 2, true, true>(p, epi, s);
     else launch_nn<128, 128, 2, 2, true, true>(p, epi, s);
     return st::check_launch("gemm_nn (bt)");
   }
@@ -1267,7 +1273,7 @@ int run_nn(NNParams& p, int epi, hipStream_t s) {
     if (force == 1) launch_nn<64, 128, 2, 2>(p, epi, s);
     else if (force == 2) launch_nn<128, 128, 2, 2>(p, epi, s);
     else if (force == 3) launch_nn<128, 64, 2, 2>(p, epi, s);
-    else if (p.batches > 0 && tiles128 < 512) {                                        // per-bin products with few column tiles
+    else if (p.batches > 0 && (tiles128 < 512 || p.M <= 64)) {                         // per-bin products with few column tiles (or one half tile of rows)
       if (p.cp % 32 == 0 && p.Kvalid % 32 == 0) launch_nn<64, 128, 2, 2, true>(p, epi, s);    // (back-prop: 8 per bin): twice the
       else launch_nn<64, 128, 2, 2>(p, epi, s);                                               // workgroups, +10 %
     }
@@ -1342,6 +1348,19 @@ int st::gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, 
       }
       return st::check_launch("gemm_nn_bins");
     }
+  }
+  // Rows that fill whole 128-row tiles but for a last HALF tile (the planes of a bin are padded to 64 rows: 32 utterances of 9
+  // blocks are 288 -> 320 rows): the 128-row kernel would walk 384.  The whole tiles go to it, the last 64 rows to the 64-row
+  // kernel as a launch of their own (same streams of operands, plain row-major matrices: only the row offset differs).
+  // Measured on the 32-tap layer at 32 x 11 s (rows 320): forward 625 us / back-prop 762 us in one launch of three row tiles.
+  // Only the wide layer's products (K x N of 512 x 4096 or 4096 x 512 per bin: 100+ us of matrix work in the 64 rows saved); the
+  // narrow layers' launches are short and would pay a second launch each.  Same box, no_row_split 1 -> 0: the step at 32 x 6 s
+  // 5.26 -> 5.18 ms, 11 s 8.72 -> 8.52, 12 s 9.13 -> 8.92; bucketed training +0.7 % (profiles/r6_row_split_ab.txt).
+  if (M % 128 == 64 && M > 128 && (long)K * N >= (1L << 21) && (long)st::ceil_div(M, 128) * (N / 128) * batches >= 512 &&
+      st::tuning(st::TUNE_GEMM_TILE) == 0 && st::tuning(st::TUNE_NO_ROW_SPLIT) == 0) {
+    if (int e = st::gemm_nn_batched(A, lda, a_batch, B, b_batch, C, ldc, c_batch, M - 64, K, N, batches, s, nullptr, b_transposed)) return e;
+    return st::gemm_nn_batched(A + (long)(M - 64) * lda, lda, a_batch, B, b_batch, C + (long)(M - 64) * ldc, ldc, c_batch, 64, K, N, batches, s,
+                               nullptr, b_transposed);
   }
   NNParams p{};
   p.A = A;

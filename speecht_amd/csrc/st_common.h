@@ -40,7 +40,7 @@ inline void launch_timed(const LaunchTimer& t, void (*kernel)(KArgs...), const d
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
        TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_STREAMK_SLOTS, TUNE_NO_FUSED_TRANSFORMS,
-       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_BF16_WGRAD_RING, TUNE_BF16_TAPS_PANEL, TUNE_BF16_WGRAD_BIAS_PASS, TUNE_BF16_WGRAD_PLAIN_ORDER, TUNE_FILTERS_IDFT_VALU, TUNE_COUNT };
+       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_BF16_WGRAD_RING, TUNE_BF16_TAPS_PANEL, TUNE_BF16_WGRAD_BIAS_PASS, TUNE_BF16_WGRAD_PLAIN_ORDER, TUNE_FILTERS_IDFT_VALU, TUNE_NO_ROW_SPLIT, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)

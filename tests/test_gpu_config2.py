@@ -73,7 +73,11 @@ def test_config2_bucketed_inference_at_full_size_matches_oracle():
     rows = len(idx) * t_out
     batched = lambda bins: sum(1 for l in tr.lines if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=%d ' % bins in l)
     # the policy of engine._use_fft: the 32-tap layer from 1 000 output rows, the 7-tap layers and the first layer from 3 000
-    assert batched(48) == (1 if rows >= 1000 else 0), trace
+    # (the wide layer's product runs as TWO launches when a bin's rows -- utterances x 64-frame blocks, padded to 64 -- end in a
+    #  half 128-row tile: the whole tiles, then the last 64 rows on the 64-row kernel, st::gemm_nn_batched)
+    rows_pad = -(-(len(idx) * -(-t_out // 64)) // 64) * 64
+    wide_launches = 2 if (rows_pad % 128 == 64 and rows_pad > 128) else 1
+    assert batched(48) == (wide_launches if rows >= 1000 else 0), trace
     assert batched(36) == (7 if rows >= 3000 else 0), trace
     assert batched(45) == (1 if rows >= 3000 else 0), trace
     wtap = [l for l in tr.lines if l.startswith('gemm_nn<') and 'batched' not in l]

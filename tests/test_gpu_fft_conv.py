@@ -29,8 +29,11 @@ def dev_tensor(dev, batch, frames, channels, halo_l, halo_r, data=None):
   return t
 
 
+# (the last case: 5 x 32 blocks = 160 rows, padded to 192 per bin -- the per-bin products run as a launch of whole 128-row tiles
+#  and one of the last 64 rows, st::gemm_nn_batched)
 @pytest.mark.parametrize('W,B,T,cin,cout,relu', [(32, 3, 77, 130, 200, True), (32, 2, 200, 250, 300, False), (32, 5, 63, 250, 129, True),
-                                                 (7, 4, 150, 250, 250, True), (7, 2, 64, 130, 129, False), (12, 3, 100, 200, 250, True)])
+                                                 (7, 4, 150, 250, 250, True), (7, 2, 64, 130, 129, False), (12, 3, 100, 200, 250, True),
+                                                 (32, 5, 2000, 130, 1000, True)])
 @pytest.mark.parametrize('idft_valu', [0, 1])
 def test_fft_conv_matches_oracle(dev, W, B, T, cin, cout, relu, idft_valu):
   # idft_valu: the filter gradient's inverse transform on the matrix pipe (filters_idft_mfma_kernel, round 6) or as one thread

@@ -41,6 +41,7 @@ CONV_CASES = [
     (1, 33, 32, 1, 250, 2000, True),   # L8 real channels, n_pad 2048 > pitch 2000
     (2, 29, 1, 1, 2000, 2000, True),   # L9 real, K=2000 -> k_pad 2016
     (3, 21, 1, 1, 2000, 29, False),    # L10 real, n_pad 32
+    (8, 150, 1, 1, 2000, 29, False),   # L10 on 1 200 rows: the reduction in slices (round 6: short batches too; 10 tiles -> 8 slices)
     (5, 131, 7, 1, 40, 40, True),      # several 128-row tiles, n_pad 64
     (1, 3, 7, 1, 16, 16, True),        # fewer frames than the filter width
 ]

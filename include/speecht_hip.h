@@ -438,6 +438,11 @@ int st_mfcc_f32(const float* audio, const int64_t* sample_offsets, int n_utts, i
 int st_fill_f32(float* dst, float value, size_t n, void* stream);
 /* zero the halo rows of a padded NWC tensor (needed when a buffer is re-described for a new shape) */
 int st_zero_halos_f32(const st_tensor3* t, void* stream);
+/* ... and the same for every buffer of a shape in ONE launch: `regions_device` is a DEVICE table of n_regions pairs
+ * {uint64 address, uint64 bytes} (addresses and sizes multiples of 16; one workgroup zeroes one range, so long ranges are best cut
+ * into pieces of ~1 MB).  The engine keeps one table per (batch, frames) shape it has seen: re-entering a shape -- the reference pads
+ * every batch to its own longest member (speech_input.py:37-45), so that is nearly every step -- costs one launch, not one per tensor. */
+int st_zero_regions(const void* regions_device, int n_regions, void* stream);
 
 #ifdef __cplusplus
 }

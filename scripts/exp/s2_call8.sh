@@ -1,0 +1,10 @@
+# session 2, call 8: one-launch re-zeroing on shape re-entry -- tests + host cost of a shape change
+mkdir -p gpurun_out/s2c8
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fft_conv.py tests/test_gpu_api.py tests/test_gpu_bf16.py tests/test_gpu_config2.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | grep -v "^HIP\|^ROCm\|^Hostname\|^Librccl\|^RCCL" | tail -12 > gpurun_out/s2c8/pytest.log
+cat gpurun_out/s2c8/pytest.log
+for M in bf16 fp32; do
+  for V in 1 0 1 0; do
+    echo "mode $M shape_cache=$V" | tee -a gpurun_out/s2c8/ab.txt
+    ST_SHAPE_CACHE=$V python scripts/bench_varlen_train.py --batch 32 --mels 80 --orders bucketed --conv-mode $M --out gpurun_out/s2c8/varlen_${M}_$V.json 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('ms_per_step','audio_seconds_per_s','ensure_shape_ms_per_change','step_call_ms_median')})" | tee -a gpurun_out/s2c8/ab.txt
+  done
+done

@@ -152,6 +152,7 @@ _SIGNATURES = {
                             c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'st_fill_f32': (c_int, [c_void_p, c_float, c_size_t, c_void_p]),
     'st_zero_halos_f32': (c_int, [_T3P, c_void_p]),
+    'st_zero_regions': (c_int, [c_void_p, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -237,6 +238,10 @@ class launch_trace:
     return False
 
 
+TUNING_EPOCH = [0]        # bumped by set_tuning: policies size workspaces, so an engine's cached shape descriptions are keyed by it
+
+
 def set_tuning(name, value):
   """Performance-experiment override (0 = library policy); see include/speecht_hip.h."""
+  TUNING_EPOCH[0] += 1
   call('st_set_tuning', name.encode(), int(value))

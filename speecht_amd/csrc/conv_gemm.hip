@@ -1129,6 +1129,15 @@ __global__ __launch_bounds__(256) void zero_halos_kernel(float* base, int frames
   }
 }
 
+// zero a table of byte ranges, one workgroup per range (st_zero_regions): addresses and sizes are multiples of 16
+struct ZeroRegion { unsigned long long address, bytes; };
+__global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegion* __restrict__ regions) {
+  const ZeroRegion r = regions[blockIdx.x];
+  f32x4* p = reinterpret_cast<f32x4*>(r.address);
+  const unsigned long long n16 = r.bytes / 16;
+  for (unsigned long long i = threadIdx.x; i < n16; i += 256) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 __global__ void fill_kernel(float* dst, float v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1476,6 +1485,14 @@ int st_fill_f32(float* dst, float value, size_t n, void* stream) {
   int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, st::as_stream(stream), dst, value, n);
   return st::check_launch("fill");
+}
+
+int st_zero_regions(const void* regions_device, int n_regions, void* stream) {
+  ST_REQUIRE(regions_device && n_regions >= 0 && ((uintptr_t)regions_device & 15) == 0, "st_zero_regions: bad table");
+  if (n_regions == 0) return ST_OK;
+  hipLaunchKernelGGL(zero_regions_kernel, dim3(n_regions), dim3(256), 0, st::as_stream(stream),
+                     reinterpret_cast<const ZeroRegion*>(regions_device));
+  return st::check_launch("zero_regions");
 }
 
 int st_zero_halos_f32(const st_tensor3* t, void* stream) {

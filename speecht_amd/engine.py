@@ -199,16 +199,89 @@ class Wav2LetterEngine(DecodeMixin):
   def _tensor(self, name, batch, frames, channels, halo_l, halo_r, clear=False):
     storage, fresh = self._storage.view(name, DevTensor3.numel(batch, frames, channels, halo_l, halo_r))
     t = DevTensor3(storage, batch, frames, channels, halo_l, halo_r)
+    # what has to happen whenever the shape is (re-)entered on storage another shape has written: the other shape's interiors
+    # lie where this shape's halo rows are
     if not fresh:
       if clear:
         t.buf.zero_()
       else:
         call('st_zero_halos_f32', t.ref, self.stream_ptr)
+    log = self.__dict__.get('_describe_log')
+    if log is not None:
+      # (byte ranges: the whole view, or the halo rows -- the rows behind utterance b and in front of b + 1 are one range)
+      base, row = t.buf.data_ptr(), t.c_pitch * 4
+      if clear:
+        log.append((base, t.buf.numel() * 4))
+      else:
+        tail = t.t_pitch - t.halo - t.frames
+        for b in range(t.batch + 1):
+          lo = b * t.t_pitch - (tail if b > 0 else 0)
+          hi = b * t.t_pitch + (t.halo if b < t.batch else 0)
+          if hi > lo:
+            log.append((base + lo * row, (hi - lo) * row))
     return t
+
+  # ---- shapes seen before -----------------------------------------------------------------------------------------
+  # The reference pads every batch to its own longest member (speech_input.py:37-45): (B, max_T) changes nearly every step, and a
+  # training run walks the same few hundred shapes over and over.  Describing a shape is ~60 C calls (geometry, workspace sizes,
+  # plans) and as many Python objects -- 0.55 ms of host time in fp32, 1.0 ms with bf16 activations, where it is what bounds the
+  # step (2.4 ms of kernels, enqueued in 1.0 ms).  A description is therefore kept per (B, T): re-entering a shape puts the cached
+  # descriptors back, re-zeroes what another shape's interiors may have overwritten (halo rows, the input tensor, the bf16
+  # planes: ONE launch over a device table of byte ranges, st_zero_regions) and re-evaluates only what depends on the shape left behind (the modes' `reenter`: stale filter spectra when the set
+  # of frequency-domain layers changed, transform tables).  Entries die with the storage generation they were described on.
+  _SHAPE_ATTRS = ('X', 'dZ', 'geo', 't_out', 'loss_pair', 'loss', 'loss_lo', 'ctc_status', 'dec_ids', 'dec_lens', 'dec_score')
+
+  def _shape_knobs(self):
+    env = os.environ.get
+    return (self.fft_conv, self.fft_min_width, self.fft_min_rows, self.fft_min_rows_narrow, self.fft_first_layer,
+            self.side_filter_gradient, self.split_small_batches, _lib.TUNING_EPOCH[0], env('ST_WGRAD_SIDE_TOP'), env('ST_FFT_BF16'),
+            env('ST_BF16_WGRAD_TR'))
+
+  def _reenter_shape(self, batch, frames):
+    """Put a cached description of (batch, frames) back; False when there is none (or it is stale)."""
+    cache = self.__dict__.get('_shape_cache')
+    entry = cache.get((batch, frames)) if cache else None
+    if entry is None or entry['generation'] != self._storage.generation or entry['knobs'] != self._shape_knobs():
+      return False
+    self.__dict__.update(entry['state'])
+    table, count = entry['zero']
+    if count:
+      call('st_zero_regions', self._ptr(table), count, self.stream_ptr)
+    self.mode.reenter(entry['mode'])
+    self._shape = (batch, frames)
+    return True
+
+  def _remember_shape(self, batch, frames, ranges):
+    if not self.mode.shape_attrs or os.environ.get('ST_SHAPE_CACHE', '1') == '0':
+      return
+    cache = self.__dict__.setdefault('_shape_cache', {})
+    generation = self._storage.generation
+    if any(e['generation'] != generation for e in cache.values()) or len(cache) >= 4096:
+      cache.clear()                                  # (their views may point into buffers that have been replaced since)
+    state = {k: self.__dict__[k] for k in self._SHAPE_ATTRS + tuple(self.mode.shape_attrs) if k in self.__dict__}
+    # the byte ranges to zero on re-entry as a device table, long ranges in pieces of 1 MB (one workgroup each: st_zero_regions)
+    pieces = []
+    for address, nbytes in ranges:
+      assert address % 16 == 0 and nbytes % 16 == 0, (address, nbytes)
+      for off in range(0, nbytes, 1 << 20):
+        pieces.append((address + off, min(1 << 20, nbytes - off)))
+    table = torch.from_numpy(np.asarray(pieces, dtype=np.uint64).reshape(-1, 2).view(np.int64)).to(self.device) if pieces else None
+    cache[(batch, frames)] = dict(state=state, zero=(table, len(pieces)), generation=generation, knobs=self._shape_knobs(),
+                                  mode=self.mode.shape_token())
 
   def _ensure_shape(self, batch, frames):
     if self._shape == (batch, frames):
       return
+    if self._reenter_shape(batch, frames):
+      return
+    self._describe_log = ranges = []
+    try:
+      self._describe_shape(batch, frames)
+    finally:
+      self._describe_log = None
+    self._remember_shape(batch, frames, ranges)
+
+  def _describe_shape(self, batch, frames):
     dev = self.device
     self.X, self.dZ = [], []
     t = frames
@@ -264,6 +337,9 @@ class Wav2LetterEngine(DecodeMixin):
     v = buf[:n * numel + slack]
     if not fresh:
       v.zero_()
+    log = self.__dict__.get('_describe_log')
+    if log is not None:
+      log.append((v.data_ptr(), -(-v.numel() * 2 // 16) * 16))      # (whole 16-byte units: the storage is allocated in larger ones)
     return v[:n * numel]
 
   # ---- the path ----------------------------------------------------------------------------

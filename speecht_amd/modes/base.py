@@ -11,6 +11,17 @@ class ModeBase:
     self.e = engine
 
   # ---- the interface -------------------------------------------------------------------------------------------
+  # Engine attributes `alloc` assigns that are functions of the shape alone: the engine keeps them per (B, T) and puts them back
+  # when a shape comes round again (`Wav2LetterEngine._reenter_shape`) instead of calling `alloc`.  Empty: never cached.
+  shape_attrs = ()
+
+  def shape_token(self):
+    """What `reenter` needs to know about the shape just described (kept with the cached description)."""
+    return None
+
+  def reenter(self, token):
+    """A cached shape is current again: redo what `alloc` does that depends on the shape LEFT BEHIND (freshness flags)."""
+
   def alloc(self, batch):
     """Buffers of this mode for the shape `_ensure_shape` has just described (X, dZ, geo exist)."""
     raise NotImplementedError

@@ -76,6 +76,24 @@ class Bf16Mode(ModeBase):
       if fresh_g:
         self.e._wplanes_fresh = False
       self.e.fftb[i] = f
+    self._fftb_transition(None)
+
+  # ---- shapes seen before (Wav2LetterEngine._reenter_shape) --------------------------------------------------------------
+  shape_attrs = ('_fftb_layers', 'fftb', 'Xb', 'dZb', '_wgrad_tr', 'wgrad_ws_b', '_side_wgrad_bf16', 'wgrad_ws_b2', 'wgrad_ws_b3')
+
+  def shape_token(self):
+    return {i: (self.e.layers[i].width, f['pl']) for i, f in self.e.fftb.items()}
+
+  def reenter(self, token):
+    self._fftb_transition(token)
+
+  def _fftb_transition(self, table_keys):
+    """What entering a shape does that depends on the shape left behind (see SpectralLayers._fft_transition)."""
+    for i, key in (table_keys or {}).items():
+      if self.e._fftb_table_key.get(i) != key:
+        f = self.e.fftb[i]
+        call('st_conv1d_fft_tables_f32', key[0], key[1], self.e._ptr(f['tables']), f['tables'].numel(), self.e.stream_ptr)
+        self.e._fftb_table_key[i] = key
     if set(self.e.fftb) != getattr(self.e, '_fftb_prev', None):
       self.e._wplanes_fresh = False
       self.e._wtplanes_fresh = False

@@ -12,6 +12,7 @@ class Bf16x6Mode(Fp32Mode):
   _one_tap_in_place = False
   _flip_every_layer = True
   _top_gradient_beside = False
+  shape_attrs = ()                  # (its weight planes are re-chosen per shape in `_alloc_planes`: described anew every time)
 
   def _workspace_bytes(self, lib):
     ws = super()._workspace_bytes(lib)

@@ -37,6 +37,15 @@ class Fp32Mode(SpectralLayers, ModeBase):
 
   _top_gradient_beside = True
 
+  # ---- shapes seen before (Wav2LetterEngine._reenter_shape) --------------------------------------------------------------
+  shape_attrs = ('wgrad_ws', '_side_wgrad_top', 'wgrad_ws_top', '_fft_layers', 'fft')
+
+  def shape_token(self):
+    return {i: (f['width'], f['pl']) for i, f in self.e.fft.items()}
+
+  def reenter(self, token):
+    self._fft_transition(token)
+
   def _workspace_bytes(self, lib):
     ws = max(lib.st_conv1d_bwd_filter_ws(self.e.X[i].ref, self.e.dZ[i].ref, l.width) for i, l in enumerate(self.e.layers))
     ws = max([ws] + [lib.st_conv1d_bwd_data_bias_ws(self.e.dZ[i].ref, self.e.dZ[i - 1].ref, l.width)

@@ -86,6 +86,17 @@ class SpectralLayers:
       if fresh_f:
         self.e._gfwd_fresh = False
       self.e.fft[i] = f
+    self._fft_transition(None)
+
+  def _fft_transition(self, table_keys):
+    """What entering a shape does that depends on the shape left behind.  ``table_keys``: {layer: (taps, left padding)} of a
+    cached description being put back -- its tables are rebuilt if another shape has left different ones in the layer's buffer
+    (a fresh description has just done that itself)."""
+    for i, key in (table_keys or {}).items():
+      if self.e._fft_table_key.get(i) != key:
+        f = self.e.fft[i]
+        call('st_conv1d_fft_tables_f32', f['width'], f['pl'], self.e._ptr(f['tables']), f['tables'].numel(), self.e.stream_ptr)
+        self.e._fft_table_key[i] = key
     if set(self.e.fft) != getattr(self.e, '_fft_prev', None):     # a layer (re)joined the path: its spectra may be stale
       self.e._gfwd_fresh = False
       self.e._packed_t_fresh = False                             # (and a layer that left it needs its flipped copy again)

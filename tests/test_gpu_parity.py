@@ -592,7 +592,10 @@ def test_fifty_shapes_of_training_stay_bit_identical_to_fresh_engines_and_alloca
   layers = WL.w2l_layers(16, width=40, fc=72)
   params = WL.xavier_params(layers, seed=9)
   rng = np.random.default_rng(50)
-  shapes = [sorted(rng.integers(24, 200, int(rng.integers(2, 6))).tolist(), reverse=True) for _ in range(50)]
+  shapes = [sorted(rng.integers(24, 200, int(rng.integers(2, 6))).tolist(), reverse=True) for _ in range(32)]
+  # ... eighteen of them come round again, in another order: a shape seen before is re-entered from the engine's cached description
+  # (descriptors put back, halos / planes re-zeroed, freshness re-evaluated against the shape left behind) -- same bit-for-bit bar
+  shapes += [shapes[k] for k in rng.permutation(32)[:18]]
   eng = make_engine(layers, dev, conv_mode=mode)
   eng.set_weights(params)
   eng.reserve(5, 200, min_frames=24, step=16)
@@ -609,7 +612,10 @@ def test_fifty_shapes_of_training_stay_bit_identical_to_fresh_engines_and_alloca
     torch.cuda.synchronize()
     return logits, grads, loss, e.params.clone()
 
+  reentered = 0
   for k, frames in enumerate(shapes):
+    seen = (len(frames), max(frames)) in (eng.__dict__.get('_shape_cache') or {})
+    reentered += int(seen and eng._shape != (len(frames), max(frames)))
     fresh = make_engine(layers, dev, conv_mode=mode)
     for name in ('params', 'adam_m', 'adam_v'):
       getattr(fresh, name).copy_(getattr(eng, name))
@@ -619,6 +625,7 @@ def test_fifty_shapes_of_training_stay_bit_identical_to_fresh_engines_and_alloca
     for what, u, v in zip(('logits', 'gradients', 'losses', 'weights'), a, b):
       assert torch.equal(u, v), (k, frames, what, float((u - v).abs().max()))
     del fresh
+  assert reentered >= 10, reentered
   torch.cuda.synchronize()
   torch.cuda.empty_cache()
   generation = eng._storage.generation

@@ -140,6 +140,25 @@ def measure_dominant_kernel(eng, batch, step_fn, step_ms, reps=3, profiled_steps
       # the layer's workspace as its own entry points lay it out: [stream-K area of the per-bin products | output spectra]
       tail_bytes = _lib_handle().st_gemm_nn_batched_ws_bytes()
       tail, outp = P(f['ws']), ctypes.c_void_p(f['ws'].data_ptr() + tail_bytes)
+      form = _lib_handle().st_conv1d_fft_three_products(f['width'], f['cin_pitch'], l.cout)
+      if form == 2:
+        # the three-product form (conv_fft.hip g3_form): rows [S_r + S_i | S_i | S_r | S_i - S_r] / [Z_r + Z_i | Z_r | Z_i], filter planes
+        # G_r, G_i - G_r, -(G_r + G_i) -- the calls below are the library's own (st_conv1d_nwc_*_fft_f32).  Algorithmic FLOPs: three
+        # real products per complex one, what the form executes
+        fl *= 0.75
+        half, npo = ka // 2, nf // 2
+        i3 = lambda *v: (ctypes.c_int64 * 3)(*v)
+        launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, half=half, npo=npo, rp=rp, nb=nb, outp=outp: call(
+            'st_gemm_nn_g3_batched_f32', P(f['sf']), 4 * half, rp * 4 * half, i3(0, half, 2 * half), P(f['gfwd']), npo, 3 * half * npo,
+            i3(0, half * npo, 2 * half * npo), 0, outp, nf, rp * nf, npo, rp, half, npo, nb, s)))
+        launches.append(('L%d bwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, half=half, npo=npo, rp=rp, nb=nb, outp=outp: call(
+            'st_gemm_nn_g3_batched_f32', P(f['zf']), 3 * npo, rp * 3 * npo, i3(0, 2 * npo, npo), P(f['gfwd']), npo, 3 * half * npo,
+            i3(0, 2 * half * npo, half * npo), 1, outp, ka, rp * ka, half, rp, npo, half, nb, s)))
+        launches.append(('L%d wgrad x%d bins' % (i, nb), fl, nbytes, lambda f=f, half=half, npo=npo, rp=rp, nb=nb, outp=outp: call(
+            'st_gemm_tn_g3_batched_f32', P(f['sf']), 4 * half, rp * 4 * half, i3(2 * half, 3 * half, 0), P(f['zf']), 3 * npo, rp * 3 * npo,
+            i3(0, 2 * npo, npo), outp, 2 * half * npo, half * npo, rp, half, npo, nb, s)))
+        continue
+      assert form == 0, 'bench: isolated launches of a layer with three-part gradient spectra rows are not described here'
       launches.append(('L%d fwd x%d bins' % (i, nb), fl, nbytes, lambda f=f, ka=ka, nf=nf, rp=rp, nb=nb, tail=tail, outp=outp: call(
           'st_gemm_nn_batched_ws_f32', P(f['sf']), ka, 2 * rp * ka, P(f['gfwd']), ka * nf, outp, nf, rp * nf, rp, ka, nf, nb, tail, tail_bytes, s)))
       if i > 0:

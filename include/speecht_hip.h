@@ -159,6 +159,26 @@ int st_gemm_tn_batched_f32(const float* a, int64_t lda, int64_t a_batch, const f
  * rows read at half length -- both against that bin's gradient spectra */
 int st_gemm_tn_batched_shared_f32(const float* a, int64_t lda, int64_t a_batch, const float* z, int64_t ldz, int64_t z_batch,
                                   float* out, int64_t out_batch, int m, int k, int n, int batches, int z_batch_shift, void* stream);
+/* A bin's COMPLEX product in three real products instead of four (Gauss: (a + ib)(c + id) = (k1 - k3) + i (k1 + k2), k1 = c (a + b),
+ * k2 = a (d - c), k3 = b (c + d)), the shared product computed once per output tile (round 6; the 32-tap layer's per-bin products,
+ * 25 % fewer multiplications).  Operand planes A_p = a + a_off[p], B_p = b + b_off[p] (p = 0, 1, 2; offsets in floats; b rows ldb
+ * apart, or with b_transposed != 0 the planes hold B_p^T, [n][ldb]):
+ *     c[i][row][col]          = A_0 B_0 + A_1 B_1          c[i][row][c_off2 + col] = A_0 B_0 + A_2 B_2
+ * k = reduction length of ONE product (a multiple of 64), n a multiple of 128.  The sums and signs live in the planes: the
+ * transforms write [S_r + S_i | S_i | S_r | S_i - S_r] / [Z_r + Z_i | Z_r | Z_i] rows, the filter spectra are the planes
+ * G_r, G_i - G_r, -(G_r + G_i) (st_conv1d_fft_three_products says which layers: conv_fft.hip g3_form). */
+int st_gemm_nn_g3_batched_f32(const float* a, int64_t lda, int64_t a_batch, const int64_t* a_off, const float* b, int64_t ldb,
+                              int64_t b_batch, const int64_t* b_off, int b_transposed, float* c, int64_t ldc, int64_t c_batch,
+                              int64_t c_off2, int m, int k, int n, int batches, void* stream);
+/* ... and the lag products of the filter gradient: out[i] = A_0^T Z_0 + A_1^T Z_1 and, out_part floats behind it,
+ * A_2^T Z_2 - A_0^T Z_0 ([k][n] each), the reduction over the m rows (m a multiple of 32, k and n of 128) */
+int st_gemm_tn_g3_batched_f32(const float* a, int64_t lda, int64_t a_batch, const int64_t* a_off, const float* z, int64_t ldz,
+                              int64_t z_batch, const int64_t* z_off, float* out, int64_t out_batch, int64_t out_part, int m, int k,
+                              int n, int batches, void* stream);
+/* which form a frequency-domain layer's per-bin products take: 0 four real products; 2 three (its sf / zf / gfwd buffers then
+ * hold the layouts above -- same sizes from the st_conv1d_fft_*_floats functions); 1 three-part gradient spectra rows read by the
+ * four-product kernels (an input whose spectra do not tile the three-product kernels).  st_set_tuning("no_g3", 1): always 0. */
+int st_conv1d_fft_three_products(int width, int cin_pitch, int cout);
 size_t st_conv1d_fft_table_floats(void);
 int st_conv1d_fft_tables_f32(int width, int pad_left, float* tables, size_t table_floats, void* stream);
 size_t st_conv1d_fft_filter_floats(int width, int cin_pitch, int cout);

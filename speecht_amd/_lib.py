@@ -54,6 +54,11 @@ _SIGNATURES = {
                                        c_int, c_int, c_void_p]),
     'st_gemm_tn_batched_shared_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int,
                                               c_int, c_int, c_int, c_void_p]),
+    'st_gemm_nn_g3_batched_f32': (c_int, [c_void_p, c_int64, c_int64, POINTER(c_int64), c_void_p, c_int64, c_int64, POINTER(c_int64), c_int,
+                                          c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'st_gemm_tn_g3_batched_f32': (c_int, [c_void_p, c_int64, c_int64, POINTER(c_int64), c_void_p, c_int64, c_int64, POINTER(c_int64),
+                                          c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'st_conv1d_fft_three_products': (c_int, [c_int, c_int, c_int]),
     'st_conv1d_fft_table_floats': (c_size_t, []),
     'st_conv1d_fft_tables_f32': (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'st_conv1d_fft_filter_floats': (c_size_t, [c_int, c_int, c_int]),

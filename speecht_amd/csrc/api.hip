@@ -69,7 +69,7 @@ LaunchTimer::LaunchTimer(hipStream_t) : start_(nullptr), stop_(nullptr) {
 // the launch path reads plain ints (no environment look-ups).
 static const char* const kTuneNames[TUNE_COUNT] = {"gemm_tile", "gemm_splits", "fwd_splits", "xcd_gm", "no_fast",
                                                    "bf16_tile", "bf16_wgrad_splits", "bf16_sched", "streamk", "transform_wgs", "bf16_wgrad_target", "streamk_slots", "no_fused_transforms",
-                                                   "streamk_test_drop", "bf16_lag_copies", "bf16_wgrad_ring", "bf16_taps_panel", "bf16_wgrad_bias_pass", "bf16_wgrad_plain_order", "filters_idft_valu", "no_row_split"};
+                                                   "streamk_test_drop", "bf16_lag_copies", "bf16_wgrad_ring", "bf16_taps_panel", "bf16_wgrad_bias_pass", "bf16_wgrad_plain_order", "filters_idft_valu", "no_row_split", "no_g3", "g3_tile"};
 static std::atomic<int> g_tune[TUNE_COUNT];
 int tuning(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 }  // namespace st

@@ -194,7 +194,9 @@ __device__ inline void stage_matrix(float* __restrict__ dst, const float* __rest
   }
 }
 
-// IN_BF: the tensor is read in its bf16 form.  OUTP: 0 -> fp32 spectra `out`; 1 -> ONE bf16 plane `outb` (bf16 activations:
+// IN_BF: the tensor is read in its bf16 form.  OUTP: 0 -> fp32 spectra `out`; 4 / 5 -> fp32 spectra in the three-product layouts, a row
+// [S_r + S_i | S_i | S_r | S_i - S_r] (input spectra) or [Z_r + Z_i | Z_r | Z_i] (gradient spectra) of `half` columns each;
+// 1 -> ONE bf16 plane `outb` (bf16 activations:
 // the per-bin products run on the bf16 matrix pipe); 3 -> the exact 3-way bf16 split of the fp32 value in three planes
 // `out_plane` elements apart (fp32-accurate products from six bf16 terms, conv_bf16.hip).  `dc` (optional): the fp32 value of
 // spectrum row 0 -- bin 0's real part, the plain sum of the block's frames -- [rows_pad][half]: the bias gradient is a sum of
@@ -271,7 +273,28 @@ __global__ __launch_bounds__(256, 2) void dft_rows_kernel(RowsIn x, const float*
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (c < half) {
+    if constexpr (OUTP == 4 || OUTP == 5) {
+      // the three-product layouts (conv_gemm.hip gemm_nn_g3_kernel): the real part of bin m (accumulator row m < HB) and its
+      // imaginary part (row m + HB = m + 32 + 16: the next tile's register r + 8, or the one after's r - 8) sit in the SAME lane,
+      // so the sums the three products need cost one VALU add per value here, nothing elsewhere
+      constexpr int NP = OUTP == 4 ? 4 : 3;
+      if (c < half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (i == 1 && (r >> 2) >= 2) continue;                      // rows >= HB hold imaginary parts
+            const int bin = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float re = acc[i][r];
+            const float im = (r >> 2) < 2 ? acc[i + 1][(r + 8) & 15] : acc[(i + 2) % 3][(r - 8) & 15];
+            if (bin < bins) {
+              float* o = out + (long)bin * plane + (long)row * NP * half + c;
+              if (OUTP == 4) { o[0] = re + im; o[half] = im; o[2 * half] = re; o[3 * half] = im - re; }
+              else { o[0] = re + im; o[half] = re; o[2 * half] = im; }
+            }
+          }
+      }
+    } else if (c < half) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -709,7 +732,8 @@ __global__ __launch_bounds__(64 * FUSE_BLOCKS, 1) void idft_ola_dft_rows_kernel(
 //  (the 32-tap layer: 403 MB written and read again, plus the 128 MB of the flip).
 //  from packed [w * cpi + c][npo]; one thread per (c, o), o fastest (coalesced reads and writes); rows c >= cin zero.
 // (WT = compile-time width: the taps stay in registers; WT = 0: run-time width, taps in scratch)
-// OUTP 0: fp32 `gfwd`; 1 / 3: the same matrix as one bf16 plane / the exact 3-way bf16 split in three planes at `gb`
+// OUTP 0: fp32 `gfwd`; 4: fp32 `gfwd` as [bins][3][cph][npo] (the three-product form, see g3_form);
+// 1 / 3: the matrix as one bf16 plane / the exact 3-way bf16 split in three planes at `gb`
 template <int WT, int OUTP = 0>
 __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __restrict__ packed, int width_rt, int cin, int cout,
                                                               int cpi, int cph, int npo, int n, int bins,
@@ -743,6 +767,15 @@ __global__ __launch_bounds__(256) void filters_dft_fwd_kernel(const float* __res
         gb[o_] = sh; gb[g_plane + o_] = sm; gb[2 * g_plane + o_] = sl;
       }
     };
+    if constexpr (OUTP == 4) {
+      // the three-product form: planes [c][o] of G_r, G_i - G_r and -(G_r + G_i) -- the forward product (S conj(G)) and back-prop
+      // to the input (Z G, the planes read transposed) take their second and third factor from the same two, signs included
+      const long g3 = (long)k * 3 * cph * npo + (long)c * npo + o;
+      gfwd[g3] = gr;
+      gfwd[g3 + (long)cph * npo] = gi - gr;
+      gfwd[g3 + 2L * cph * npo] = -(gr + gi);
+      continue;
+    }
     const long g0 = (long)k * plane;
     put(g0 + (long)c * 2 * npo + o, gr);
     put(g0 + (long)c * 2 * npo + npo + o, -gi);
@@ -943,17 +976,21 @@ constexpr int TRANSFORM_WGS_DEFAULT = 512;       // persistent: two workgroups p
 inline int transform_wgs() { const int t = st::tuning(st::TUNE_TRANSFORM_WGS); return t > 0 ? t : TRANSFORM_WGS_DEFAULT; }
 
 // tb: the tensor's bf16 form (null: read the fp32 tensor); planes: 0 -> fp32 spectra `out`, 1 / 3 -> bf16 plane(s) `outb`
+// form: 0, or 4 / 5 -- the fp32 spectra in the three-product layouts (rows of 4 / 3 parts, dft_rows_kernel OUTP)
 void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float* wm, int start, int frames_used, int half, float* out,
-                void* outb, int planes, size_t out_plane, float* dc, hipStream_t s, long bin_stride = 0, float* out2 = nullptr) {
-  if (bin_stride == 0) bin_stride = (long)pl.rows_pad * 2 * half;
+                void* outb, int planes, size_t out_plane, float* dc, hipStream_t s, long bin_stride = 0, float* out2 = nullptr,
+                int form = 0) {
+  if (bin_stride == 0) bin_stride = (long)pl.rows_pad * (form == 4 ? 4 : form == 5 ? 3 : 2) * half;
   const int nchunks = st::ceil_div(half, 32);
   const int wgs = std::min(transform_wgs(), st::ceil_div(pl.rows_pad * nchunks, 4));
   const int nst = frames_used <= 6 * CH ? 3 : 4;                           // the matrix has no columns past frames_used
   // mb = the bytes the transform has to move: every frame of the tensor once, every spectrum value (and its rotated copy) once
   const double esz_in = tb ? 2.0 : 4.0, esz_out = planes == 0 ? 4.0 : 2.0 * planes;
-  st::trace("dft_rows<%d%s%s> rows=%d chunks=%d bins=%d gflop=%.3f mb=%.2f", nst, tb ? ",bf16-in" : "", planes == 1 ? ",bf16-out" : planes == 3 ? ",x3-out" : "",
+  st::trace("dft_rows<%d%s%s> rows=%d chunks=%d bins=%d gflop=%.3f mb=%.2f", nst, tb ? ",bf16-in" : "",
+            planes == 1 ? ",bf16-out" : planes == 3 ? ",x3-out" : form == 4 ? ",4-part" : form == 5 ? ",3-part" : "",
             pl.rows, nchunks, pl.bins, 4096e-9 * pl.rows * (double)nchunks * nst * CH * 3,
-            1e-6 * ((double)t.batch * t.frames * t.c_pitch * esz_in + (double)pl.bins * pl.rows * 2 * half * esz_out * (out2 ? 2 : 1)));
+            1e-6 * ((double)t.batch * t.frames * t.c_pitch * esz_in +
+                    (double)pl.bins * pl.rows * half * esz_out * (form == 4 ? 4 : form == 5 ? 3 : out2 ? 4 : 2)));
   RowsIn x = rows_in(t);
   if (tb) x.base_b = reinterpret_cast<const unsigned short*>(tb) + (long)t.halo * t.c_pitch;
   unsigned short* ob = reinterpret_cast<unsigned short*>(outb);
@@ -962,7 +999,9 @@ void launch_dft(const st_tensor3& t, const void* tb, const Plan& pl, const float
   st::launch_timed(timer, dft_rows_kernel<NSTV, INB, OUTPV>, dim3(wgs), dim3(256), s, x, wm, pl.blocks, pl.rows, pl.rows_pad, start, \
                    pl.bins, half, nchunks, out, ob, out_plane, dc, bin_stride, out2)
 #define ST_DFT_N(INB, OUTPV) do { if (nst == 3) ST_DFT(3, INB, OUTPV); else ST_DFT(4, INB, OUTPV); } while (0)
-  if (!tb && planes == 0) ST_DFT_N(false, 0);
+  if (!tb && planes == 0 && form == 4) ST_DFT_N(false, 4);
+  else if (!tb && planes == 0 && form == 5) ST_DFT_N(false, 5);
+  else if (!tb && planes == 0) ST_DFT_N(false, 0);
   else if (!tb && planes == 3) ST_DFT_N(false, 3);
   else if (tb && planes == 1) ST_DFT_N(true, 1);
   else st::set_error("dft: unsupported operand form (bf16 in: %d, planes %d)", tb ? 1 : 0, planes);
@@ -990,6 +1029,17 @@ void launch_idft(const float* in, const float* winv, const Plan& p, int half_in,
 }
 
 bool width_ok(int width) { return width >= 2 && V + width - 1 <= KP; }
+// The three-product form of a layer's per-bin complex products (Gauss; conv_gemm.hip gemm_nn_g3_kernel / gemm_tn_g3_kernel): wide
+// layers only -- many output channels (the narrow layers' products run on the persistent per-bin kernel, and their launches are
+// too short for another split of the work) and more than 9 taps (the fused transforms of a chain write a neighbour layer's
+// spectra in the four-product layout: they stop at 9 taps, so the two never meet on the input side).  The GRADIENT spectra's
+// layout [Z_r + Z_i | Z_r | Z_i] is a function of (taps, output channels) alone -- st_conv1d_fft_dz_spectra_f32 does not know
+// the layer's input -- and a layer whose input spectra do not tile the kernels (half % 128 != 0) reads its [Z_r | Z_i] out of
+// the same rows with the four-product kernels.  st_set_tuning("no_g3", 1): the four-product form everywhere (A/B runs, parity
+// of the two forms) -- set before the filter spectra are built.
+constexpr int G3_MIN_WIDTH = 2 * FUSE_HALO + 2;
+bool zf3_form(int width, int cout) { return width >= G3_MIN_WIDTH && npad_of(cout) >= 512 && st::tuning(st::TUNE_NO_G3) == 0; }
+bool g3_form(int width, int cin_pitch, int cout) { return zf3_form(width, cout) && half_of(cin_pitch) % 128 == 0; }
 // the filter gradient's lag products as separate real / imaginary products over half-length rows (see bwd_filter): needs the
 // spectra halves to tile the filter-gradient kernel (128 columns)
 bool split_lag_products(int half) { return half % 128 == 0; }
@@ -1088,6 +1138,29 @@ int st_gemm_tn_batched_shared_f32(const float* a, int64_t lda, int64_t a_batch, 
   return st::gemm_tn_batched(a, lda, a_batch, z, ldz, z_batch, out, out_batch, m, k, n, batches, st::as_stream(stream), z_batch_shift);
 }
 
+int st_gemm_nn_g3_batched_f32(const float* a, int64_t lda, int64_t a_batch, const int64_t* a_off, const float* b, int64_t ldb, int64_t b_batch,
+                              const int64_t* b_off, int b_transposed, float* c, int64_t ldc, int64_t c_batch, int64_t c_off2, int m, int k, int n,
+                              int batches, void* stream) {
+  ST_REQUIRE(a_off && b_off, "gemm_nn_g3_batched: null offsets");
+  const long ao[3] = {(long)a_off[0], (long)a_off[1], (long)a_off[2]}, bo[3] = {(long)b_off[0], (long)b_off[1], (long)b_off[2]};
+  return st::gemm_nn_g3_batched(a, lda, a_batch, ao, b, ldb, b_batch, bo, c, ldc, c_batch, c_off2, m, k, n, batches, st::as_stream(stream),
+                                b_transposed != 0);
+}
+
+int st_gemm_tn_g3_batched_f32(const float* a, int64_t lda, int64_t a_batch, const int64_t* a_off, const float* z, int64_t ldz, int64_t z_batch,
+                              const int64_t* z_off, float* out, int64_t out_batch, int64_t out_part, int m, int k, int n, int batches,
+                              void* stream) {
+  ST_REQUIRE(a_off && z_off, "gemm_tn_g3_batched: null offsets");
+  const long ao[3] = {(long)a_off[0], (long)a_off[1], (long)a_off[2]}, zo[3] = {(long)z_off[0], (long)z_off[1], (long)z_off[2]};
+  return st::gemm_tn_g3_batched(a, lda, a_batch, ao, z, ldz, z_batch, zo, out, out_batch, out_part, m, k, n, batches, st::as_stream(stream));
+}
+
+// 0: the layer's per-bin products run in the four-product form; 1: its gradient spectra take three-part rows but its input does
+// not tile the three-product kernels; 2: the three-product form (g3_form)
+int st_conv1d_fft_three_products(int width, int cin_pitch, int cout) {
+  return g3_form(width, cin_pitch, cout) ? 2 : (zf3_form(width, cout) ? 1 : 0);
+}
+
 int st_conv1d_fft_plan(int width, int frames, int batch, int* n, int* valid, int* blocks, int* bins, int* rows_pad) {
   ST_REQUIRE(width_ok(width) && frames > 0 && batch > 0, "fft plan: filter width must be in [2, 33]");
   const Plan p = make_plan(width, frames, batch);
@@ -1133,6 +1206,11 @@ int st_conv1d_fft_filters_f32(const float* packed, int width, int cin, int cout,
   // rows of pad channels (c in [cin, half)) are written as zeros by the kernel's `live` test
   const int gx = st::ceil_div(npo, 256), gy = half_of(cin_pitch);
   const dim3 grid(gx, gy, gx * gy < 1024 ? 4 : 1);
+  if (g3_form(width, cin_pitch, cout)) {               // three planes per bin instead of the 2 x 2 block matrix (g3_form)
+    if (width == 32) hipLaunchKernelGGL((filters_dft_fwd_kernel<32, 4>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd, (unsigned short*)nullptr, (size_t)0);
+    else hipLaunchKernelGGL((filters_dft_fwd_kernel<0, 4>), grid, dim3(256), 0, s, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd, (unsigned short*)nullptr, (size_t)0);
+    return st::check_launch("fft filters (three planes)");
+  }
   ST_FFT_WIDTH_DISPATCH(filters_dft_fwd_kernel, packed, width, cin, cout, cin_pitch, half_of(cin_pitch), npo, n, bins, tw, gfwd,
                         (unsigned short*)nullptr, (size_t)0);
   return st::check_launch("fft filters");
@@ -1150,7 +1228,10 @@ size_t st_conv1d_fft_sf_floats(const st_tensor3* x, const st_tensor3* y, int wid
 size_t st_conv1d_fft_zf_floats(const st_tensor3* dz, int width) {
   if (!dz || !width_ok(width)) return 0;
   const Plan p = make_plan(width, dz->frames, dz->batch);
-  return (size_t)p.bins * p.rows_pad * 2 * npad_of(dz->channels);
+  // (three parts per row, [Z_r + Z_i | Z_r | Z_i], where the layer's gradient spectra take the three-product layout: zf3_form --
+  // sized for it whatever the tuning knob says)
+  const bool three = width >= G3_MIN_WIDTH && npad_of(dz->channels) >= 512;
+  return (size_t)p.bins * p.rows_pad * (three ? 3 : 2) * npad_of(dz->channels);
 }
 
 size_t st_conv1d_fft_ws(const st_tensor3* x, const st_tensor3* y, int width) {
@@ -1181,11 +1262,23 @@ int st_conv1d_nwc_fwd_fft_chain_f32(const st_tensor3* x, const float* gfwd, cons
   float* yf = sk + st::SK_WS_FLOATS;
   const int half = half_of(x->c_pitch);
   const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin
+  if (g3_form(width, x->c_pitch, y->channels)) {
+    // three real products per bin: rows [S_r + S_i | S_i | S_r | S_i - S_r] (the same floats per bin as [S | rotated copy]) against
+    // the planes G_r, G_i - G_r, -(G_r + G_i):  Re Y = (S_r + S_i) G_r + S_i (G_i - G_r),  Im Y = (S_r + S_i) G_r - S_r (G_r + G_i)
+    ST_REQUIRE(!sf_ready, "conv fft fwd: a layer in the three-product form transforms its own input");
+    launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half, sf, nullptr, 0, 0, nullptr, s, 0, nullptr, 4);
+    const long plane = (long)half * npo;
+    const long a_off[3] = {0, half, 2L * half}, b_off[3] = {0, plane, 2 * plane};
+    if (int e = st::gemm_nn_g3_batched(sf, 4L * half, s_bin, a_off, gfwd, npo, 3 * plane, b_off, yf, nf, (long)p.rows_pad * nf, npo,
+                                       p.rows_pad, half, npo, p.bins, s))
+      return e;
+  } else {
   if (!sf_ready)
     launch_dft(*x, nullptr, p, tables + T_FS, -pad_left, p.n, half, sf, nullptr, 0, 0, nullptr, s, s_bin,
                split_lag_products(half) ? sf + (long)p.rows_pad * ka : nullptr);
   if (int e = st::gemm_nn_batched(sf, ka, s_bin, gfwd, (long)ka * nf, yf, nf, (long)p.rows_pad * nf, p.rows_pad, ka, nf, p.bins, s, sk))
     return e;
+  }
   RowsOut out{y->base + (long)y->halo * y->c_pitch, (long)y->t_pitch * y->c_pitch, y->c_pitch, y->channels, y->frames, nullptr};
   const int nchunks = st::ceil_div(y->c_pitch, 32);
   if (next_tables && next_sf && can_fuse_next(p, *y, next_width, next_pad_left)) {
@@ -1223,7 +1316,8 @@ int st_conv1d_nwc_fwd_fft_f32(const st_tensor3* x, const float* gfwd, const floa
 int st_conv1d_fft_dz_spectra_f32(const st_tensor3* dz, int width, const float* tables, float* zf, void* stream) {
   ST_REQUIRE(tensor_ok(dz) && tables && zf && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft dz spectra: bad argument");
   const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
-  launch_dft(*dz, nullptr, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, nullptr, 0, 0, nullptr, st::as_stream(stream));
+  launch_dft(*dz, nullptr, p, tables + T_FZ, 0, V, npad_of(dz->channels), zf, nullptr, 0, 0, nullptr, st::as_stream(stream), 0, nullptr,
+             zf3_form(width, dz->channels) ? 5 : 0);
   return st::check_launch("conv fft dz spectra");
 }
 
@@ -1231,8 +1325,9 @@ int st_conv1d_fft_bias_grad_f32(const st_tensor3* dz, int width, const float* zf
   ST_REQUIRE(tensor_ok(dz) && zf && dbias && width_ok(width) && npad_of(dz->channels) % 128 == 0, "conv fft bias grad: bad argument");
   const Plan p = make_plan(width, dz->frames, dz->batch, ROWS_F32);
   const int np = npad_of(dz->channels);
-  hipLaunchKernelGGL(bias_from_spectra_kernel, dim3(st::ceil_div(np, 32)), dim3(256), 0, st::as_stream(stream), zf, p.rows, 2 * np,
-                     dz->channels, np, dbias);
+  const bool zf3 = zf3_form(width, dz->channels);              // rows [Z_r + Z_i | Z_r | Z_i]: bin 0's real parts one part in
+  hipLaunchKernelGGL(bias_from_spectra_kernel, dim3(st::ceil_div(np, 32)), dim3(256), 0, st::as_stream(stream), zf + (zf3 ? np : 0), p.rows,
+                     (zf3 ? 3 : 2) * np, dz->channels, np, dbias);
   return st::check_launch("conv fft bias grad");
 }
 
@@ -1257,8 +1352,18 @@ int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, 
   const int kz = 2 * npad_of(dz->channels), cph = half_of(dx->c_pitch), nb = 2 * cph;
   float* const sk = reinterpret_cast<float*>(workspace);
   float* xf = sk + st::SK_WS_FLOATS;
-  if (int e = st::gemm_nn_batched(zf, kz, (long)p.rows_pad * kz, gfwd, (long)nb * kz, xf, nb, (long)p.rows_pad * nb, p.rows_pad, kz,
-                                  nb, p.bins, s, sk, true))
+  const int npz = npad_of(dz->channels);
+  const bool zf3 = zf3_form(width, dz->channels);
+  if (g3_form(width, dx->c_pitch, dz->channels)) {
+    // X = Z G in three products, the filter planes read transposed in place:
+    // Re X = (Z_r + Z_i) G_r - Z_i (G_r + G_i),  Im X = (Z_r + Z_i) G_r + Z_r (G_i - G_r)
+    const long plane = (long)cph * npz;
+    const long a_off[3] = {0, 2L * npz, npz}, b_off[3] = {0, 2 * plane, plane};
+    if (int e = st::gemm_nn_g3_batched(zf, 3L * npz, (long)p.rows_pad * 3 * npz, a_off, gfwd, npz, 3 * plane, b_off, xf, nb, (long)p.rows_pad * nb,
+                                       cph, p.rows_pad, npz, cph, p.bins, s, true))
+      return e;
+  } else if (int e = st::gemm_nn_batched(zf + (zf3 ? npz : 0), zf3 ? 3L * npz : kz, (long)p.rows_pad * (zf3 ? 3 * npz : kz), gfwd, (long)nb * kz, xf, nb,
+                                         (long)p.rows_pad * nb, p.rows_pad, kz, nb, p.bins, s, sk, true))
     return e;
   RowsOut out{dx->base + (long)dx->halo * dx->c_pitch, (long)dx->t_pitch * dx->c_pitch, dx->c_pitch, dx->channels, dx->frames, nullptr};
   const int nchunks = st::ceil_div(dx->c_pitch, 32);
@@ -1270,7 +1375,7 @@ int st_conv1d_nwc_bwd_data_fft_chain_f32(const st_tensor3* dz, const float* zf, 
   if (window_form) {
     // the layer below's dz spectra ride along when its zf rows are laid out like this call's columns
     const bool below = below_tables && below_zf && width_ok(below_width) && npad_of(dx->channels) % 128 == 0 &&
-                       npad_of(dx->channels) == cph && 32 * nchunks == cph;
+                       npad_of(dx->channels) == cph && 32 * nchunks == cph && !zf3_form(below_width, dx->channels);
     const Plan pb = make_plan(below ? below_width : width, dx->frames, dx->batch, ROWS_F32);
     // gflop: the whole-window inverse (2 * HP k-steps, three 32-row tiles), then the 32 k-steps of the layer below's zero-padded
     // forward transform (three tiles); mb: this layer's dx spectra and the ReLU mask in, dx and the layer below's dz spectra out
@@ -1482,7 +1587,16 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   const int half = half_of(x->c_pitch), ka = 2 * half, npo = npad_of(dz->channels), nf = 2 * npo;
   float* qf = reinterpret_cast<float*>(workspace) + st::SK_WS_FLOATS;
   const long s_bin = 2L * p.rows_pad * ka;                      // [S | rotated copy] per bin (st_conv1d_fft_sf_floats)
-  if (split_lag_products(half)) {
+  const bool zf3 = zf3_form(width, dz->channels);
+  if (g3_form(width, x->c_pitch, dz->channels)) {
+    // the lag products in three products per bin (gemm_tn_g3_kernel):  Re Q = S_r^T (Z_r + Z_i) + (S_i - S_r)^T Z_i,
+    // Im Q = (S_r + S_i)^T Z_r - S_r^T (Z_r + Z_i);  q comes out as the split form's [bins][2][half][npo]
+    const long a_off[3] = {2L * half, 3L * half, 0}, z_off[3] = {0, 2L * npo, npo};
+    if (int e = st::gemm_tn_g3_batched(sf, 4L * half, s_bin, a_off, zf, 3L * npo, (long)p.rows_pad * 3 * npo, z_off, qf, 2L * half * npo,
+                                       (long)half * npo, p.rows_pad, half, npo, p.bins, s))
+      return e;
+    launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 1, s);
+  } else if (split_lag_products(half)) {
     // The lag products Q = S^H-like sums over the rows of a bin:  Re Q = S_r^T Z_r + S_i^T Z_i,  Im Q = S_i^T Z_r - S_r^T Z_i.
     // A spectra row [re | im] read as TWO rows of half length turns each into ONE plain product over 2 * rows_pad rows:
     // Re Q = S2^T Z2 with S2 = S as [2 rows][half], Z2 = Z as [2 rows][npo]; Im Q the same with the rotated copy [S_i | -S_r]
@@ -1497,7 +1611,9 @@ int st_conv1d_nwc_bwd_filter_fft_f32(const st_tensor3* x, const st_tensor3* dz, 
   } else {
     // (spectra halves that do not tile the kernel -- the polyphase first layer: 192 columns): Q[bin] = [S_r | S_i]^T [Z_r | Z_i],
     // 2 half x 2 npo, combined by filters_idft
-    if (int e = st::gemm_tn_batched(sf, ka, s_bin, zf, nf, (long)p.rows_pad * nf, qf, (long)ka * nf, p.rows_pad, ka, nf, p.bins, s))
+    // (gradient spectra in three-part rows -- zf3_form -- are read from their [Z_r | Z_i] columns)
+    if (int e = st::gemm_tn_batched(sf, ka, s_bin, zf + (zf3 ? npo : 0), zf3 ? 3L * npo : nf, (long)p.rows_pad * (zf3 ? 3 * npo : nf), qf, (long)ka * nf,
+                                    p.rows_pad, ka, nf, p.bins, s))
       return e;
     launch_filters_idft(qf, width, x->channels, dz->channels, x->c_pitch, half, npo, p.n, p.bins, tw, dpacked, 0, s);
   }

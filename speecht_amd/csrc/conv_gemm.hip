@@ -791,6 +791,231 @@ __global__ __launch_bounds__(NTHREADS, MINW) void gemm_nn_bins_kernel(BinsParams
 }
 
 // ------------------------------------------------------------------------------------
+// A bin's COMPLEX product in three real products (Gauss), one launch, one pass over the operands (round 6).
+// (a + ib)(c + id) = (k1 - k3) + i (k1 + k2) with k1 = c (a + b), k2 = a (d - c), k3 = b (c + d): as the real embedding
+// [re | im] x [[Gr, -Gi], [Gi, Gr]] the 32-tap layer's per-bin products execute four real products of the half-size operands
+// (51.5 GFLOP per pass at config 2); with the sums formed where the spectra are produced (transforms: a + b; filter spectra:
+// d - c and -(c + d), signs included) they are three (38.7 GFLOP).  The shared product k1 is computed ONCE per output tile:
+//     phase 0:  acc  = A0 . B0                 (k1)           acc2 = acc
+//     phase 1:  acc  += A1 . B1                (-> real part)
+//     phase 2:  acc2 += A2 . B2                (-> imaginary part)
+// one K-loop of 3 K / 32 stages over two accumulator sets (128 of the wave's registers), the tile's real and imaginary parts
+// stored `c_off2` columns apart -- the [re | im] rows the inverse transforms read.  A_p = A + a_off[p] (column offsets inside a
+// spectra row), B_p = B + b_off[p] (element offsets of a bin's three filter planes).  Stage, swizzle and scheduling are the FAST
+// stage of gemm_nn_kernel; BT reads the planes transposed in place (back-prop to the input).  Whole k-tiles, K / 32 even.
+// ksplit = 2 (blockIdx.y): a product with few output tiles and a long reduction -- back-prop to the input of the 32-tap layer:
+// 256 x 256 outputs per bin over 3 x 2048 -- gives every workgroup half of each phase's reduction and ADDS its tile into a
+// zeroed C with float atomics: exactly two addends per element onto +0, so the sum is the same whichever arrives first
+// (a + b == b + a) and the result stays bit-reproducible.
+struct G3Params {
+  const float* A; long lda, a_batch; long a_off[3];
+  const float* B; long ldb, b_batch; long b_off[3];   // ldb: floats between rows of B (BT: between rows of B^T)
+  float* C; long ldc, c_batch, c_off2;
+  int M, K, N;                                        // K: reduction length of ONE phase (of one split of it)
+  int tiles_m, tiles_n, batches, ksplit;
+};
+
+// rows [0, M) of every bin, columns [0, N) and [c_off2, c_off2 + N): zero (four rows per workgroup, N a multiple of 128)
+__global__ __launch_bounds__(256) void g3_zero_out_kernel(float* __restrict__ C, long ldc, long c_batch, long c_off2, int M, int N) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float* row = C + (long)blockIdx.y * c_batch + (long)m * ldc;
+  for (int c = (threadIdx.x & 63) * 4; c < N; c += 256) {
+    *reinterpret_cast<f32x4*>(row + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(row + c_off2 + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int BM, bool BT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nn_g3_kernel(G3Params p) {
+  constexpr int BN = 128, WMW = 2, WNW = 2;
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_DMA = BM / 32, B_DMA = BN / 32, B_LPR = BN / 4;
+  constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
+  constexpr int N_DMA = A_DMA + B_DMA;
+  static_assert(MT >= 1 && NT == 2, "tile config");
+  typedef typename FVec<NT>::type bvec;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_SZ;
+
+  // one bin per XCD at a time (its operands stay in that L2), row tiles fastest (see gemm_nn_kernel's batched mode)
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per_bin = p.tiles_m * p.tiles_n;
+  const int set = local / per_bin, t = local - set * per_bin;
+  const int bin = set * 8 + xcd;
+  if (bin >= p.batches) return;
+  const int tile_n = t / p.tiles_m, tile_m = t - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  // (a split of the reduction: this workgroup's share of every phase starts blockIdx.y * K further in)
+  const float* __restrict__ Ab = p.A + (long)bin * p.a_batch + (long)blockIdx.y * p.K;
+  const float* __restrict__ Bb = p.B + (long)bin * p.b_batch + (long)blockIdx.y * p.K * (BT ? 1L : p.ldb);
+  const float* aptr[A_DMA];
+  const float* bptr[B_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) {
+    const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
+    aptr[i] = Ab + (long)min(m0 + row, p.M - 1) * p.lda + (((lane & 7) ^ ((row >> 1) & 7))) * 4;   // rows past M: re-read, never stored
+  }
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i) {
+    if (BT) {
+      const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
+      bptr[i] = Bb + (long)(n0 + row) * p.ldb + (((lane & 7) ^ ((row >> 1) & 7))) * 4;
+    } else {
+      bptr[i] = Bb + (long)((wave * B_DMA + i) * (64 / B_LPR) + lane / B_LPR) * p.ldb + n0 + (lane % B_LPR) * 4;
+    }
+  }
+  // (ao, bo): element offsets of a stage -- phase offset + position inside the phase
+  auto dma_piece = [&](int pcx, long ao, long bo, int buf) {
+    if (pcx < A_DMA) {
+      const int i = pcx < A_DMA ? pcx : 0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + ao), (lptr_t)(As + buf * A_SZ + (wave * A_DMA + i) * 256), 16, 0, 0);
+    } else {
+      const int i = pcx - A_DMA < B_DMA ? pcx - A_DMA : 0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(bptr[i] + bo), (lptr_t)(Bs + buf * B_SZ + (wave * B_DMA + i) * 256), 16, 0, 0);
+    }
+  };
+  const long bstep = BT ? (long)BK : (long)BK * p.ldb;         // a k-tile further inside a plane
+
+  int a_frag[4], bt_frag[4];
+  {
+    const int row = wm * WTM + l31, sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
+  {
+    const int row = wn * WTN + l31, sw = (row >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bt_frag[q] = row * BK + (((2 * q + h) ^ sw) * 4);
+  }
+  const int b_frag = (4 * h) * BN + wn * WTN + NT * l31;
+
+  f32x16 acc[MT][NT], acc2[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int pcx = 0; pcx < N_DMA; ++pcx) dma_piece(pcx, p.a_off[0], p.b_off[0], 0);
+  __syncthreads();
+
+  // one k-tile into `tgt`; (nao, nbo): offsets of the tile to stage meanwhile
+  auto stage = [&](auto cur_c, auto more_c, f32x16 (&tgt)[MT][NT], long nao, long nbo) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr bool MORE = decltype(more_c)::value;
+    const float* as = As + CUR * A_SZ;
+    const float* bs = Bs + CUR * B_SZ + (BT ? 0 : b_frag);
+    f32x4 af[4][MT];
+    bvec bf[4][4];
+    f32x4 bft[4][NT];
+    auto read_frags = [&](int q) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const f32x4*>(as + a_frag[q] + i * 32 * BK);
+      if (BT) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bft[q][n] = *reinterpret_cast<const f32x4*>(bs + bt_frag[q] + n * 32 * BK);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[q][j] = *reinterpret_cast<const bvec*>(bs + (8 * q + j) * BN);
+      }
+    };
+    read_frags(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (MORE) {
+#pragma unroll
+        for (int pcx = q; pcx < N_DMA; pcx += 4) dma_piece(pcx, nao, nbo, CUR ^ 1);
+      }
+      if (q < 3) read_frags(q + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            tgt[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i][j], BT ? bft[q][n][j] : vget<NT>(bf[q][j], n), tgt[i][n], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                         // also drains this wave's DMA (vmcnt) before anyone reads it
+  };
+  using std::integral_constant;
+  using std::true_type;
+  using std::false_type;
+  const int spp = p.K / BK;                  // stages per phase (even)
+  // a phase: pairs of stages; the tile staged under the last stage of phases 0 and 1 is the first of the next phase
+  auto phase = [&](f32x16 (&tgt)[MT][NT], long ao, long bo, long next_ao, long next_bo, auto last_c) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    for (int kt = 0; kt + 2 < spp; kt += 2) {
+      stage(integral_constant<int, 0>{}, true_type{}, tgt, ao + (kt + 1) * BK, bo + (kt + 1) * bstep);
+      stage(integral_constant<int, 1>{}, true_type{}, tgt, ao + (kt + 2) * BK, bo + (kt + 2) * bstep);
+    }
+    stage(integral_constant<int, 0>{}, true_type{}, tgt, ao + (spp - 1) * BK, bo + (spp - 1) * bstep);
+    if (LAST) stage(integral_constant<int, 1>{}, false_type{}, tgt, 0L, 0L);
+    else stage(integral_constant<int, 1>{}, true_type{}, tgt, next_ao, next_bo);
+  };
+  phase(acc, p.a_off[0], p.b_off[0], p.a_off[1], p.b_off[1], false_type{});
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc2[i][j] = acc[i][j];
+  phase(acc, p.a_off[1], p.b_off[1], p.a_off[2], p.b_off[2], false_type{});
+  phase(acc2, p.a_off[2], p.b_off[2], 0L, 0L, true_type{});
+
+  float* __restrict__ Cb = p.C + (long)bin * p.c_batch + n0 + wn * WTN + (BT ? l31 : NT * l31);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < p.M) {
+        float* row = Cb + (long)m * p.ldc;
+        if (p.ksplit > 1) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int cn = BT ? n * 32 : n;
+            __hip_atomic_fetch_add(row + cn, acc[i][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(row + p.c_off2 + cn, acc2[i][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else if (BT) {                     // this lane's columns are 32 apart
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { row[n * 32] = acc[i][n][r]; row[p.c_off2 + n * 32] = acc2[i][n][r]; }
+        } else {
+          bvec o1, o2;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { vset<NT>(o1, n, acc[i][n][r]); vset<NT>(o2, n, acc2[i][n][r]); }
+          *reinterpret_cast<bvec*>(row) = o1;
+          *reinterpret_cast<bvec*>(row + p.c_off2) = o2;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Filter gradient: out[split][k][n] = sum over the split's rows m of A[m][k] * Z[m][n].
 // Both operands are reduction-major in memory (a row of A / Z is one value of the reduction
 // index m) and are staged as they are, linear [m][cols], by LDS-DMA.  A lane fetches MT (NT)
@@ -997,6 +1222,158 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TNParams p) {
           vset<NT>(o, n, (k < p.Kvalid && col0 + n < p.z_cols) ? acc[i][n][r] : 0.f);
         *reinterpret_cast<zvec*>(out + (long)k * p.Np + col0) = o;
       }
+    }
+}
+
+// The lag products of a bin in three real products (see gemm_nn_g3_kernel): Re Q = S_r^T Z_r + S_i^T Z_i and
+// Im Q = S_i^T Z_r - S_r^T Z_i from  k1 = S_r^T (Z_r + Z_i),  k2 = (S_i - S_r)^T Z_i,  k3 = (S_r + S_i)^T Z_r:  Re = k1 + k2,
+// Im = k3 - k1.  One workgroup per 128 x 128 output tile of a bin walks the bin's M rows three times with other column
+// offsets (A_p = A + a_off[p], Z_p = Z + z_off[p]):
+//     phase 0: acc = A0^T Z0 (k1), acc2 = -acc;   phase 1: acc += A1^T Z1;   phase 2: acc2 += A2^T Z2
+// and stores acc to out[bin][0], acc2 to out[bin][1] ([K][N] each).  Plain row-major operands (row m at m * ld), M a multiple
+// of 32, M / 32 stages per phase; the stage is gemm_tn_kernel's (linear LDS-DMA images, scalar base + per-lane offset).
+struct TN3Params {
+  const float* A; long lda, a_batch; long a_off[3];
+  const float* Z; long ldz, z_batch; long z_off[3];
+  float* out; long o_batch, o_part;                  // o_part: floats between the real and the imaginary product of a bin
+  int M, K, N, tiles_k, tiles_n, batches;
+};
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_g3_kernel(TN3Params p) {
+  constexpr int BKO = 128, BN = 128, BMR = 32, WKW = 2, WNW = 2;
+  constexpr int WTK = BKO / WKW, WTN = BN / WNW;
+  constexpr int MT = WTK / 32, NT = WTN / 32;
+  constexpr int A_LPR = BKO / 4, Z_LPR = BN / 4;
+  constexpr int A_SZ = BMR * BKO, Z_SZ = BMR * BN;
+  constexpr int A_PIECES = BMR * A_LPR / 64, Z_PIECES = BMR * Z_LPR / 64;   // 16 + 16 one-KiB pieces per stage
+  constexpr int A_PW = A_PIECES / 4, Z_PW = Z_PIECES / 4;                   // pieces per wave
+  typedef typename FVec<MT>::type avec;
+  typedef typename FVec<NT>::type zvec;
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * Z_SZ];
+  float* const As = smem;
+  float* const Zs = smem + 2 * A_SZ;
+
+  // all tiles of a bin on one XCD (blockIdx.x = 8 * (set * tiles + tile) + xcd, bin = 8 * set + xcd): the bin's two operands
+  // are read by its 32 tiles out of that L2
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per_bin = p.tiles_k * p.tiles_n;
+  const int set = local / per_bin, t = local - set * per_bin;
+  const int bin = set * 8 + xcd;
+  if (bin >= p.batches) return;
+  const int tile_n = t / p.tiles_k, tile_k = t - tile_n * p.tiles_k;
+  const int k0 = tile_k * BKO, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wk = wave / WNW, wn = wave % WNW;
+
+  const char* Ab = reinterpret_cast<const char*>(p.A + (long)bin * p.a_batch + k0);
+  const char* Zb = reinterpret_cast<const char*>(p.Z + (long)bin * p.z_batch + n0);
+  const unsigned a_voff = (unsigned)(((lane / A_LPR) * p.lda + (lane % A_LPR) * 4) * 4);
+  const unsigned z_voff = (unsigned)(((lane / Z_LPR) * p.ldz + (lane % Z_LPR) * 4) * 4);
+  const unsigned lds_a = lds_addr(As), lds_z = lds_addr(Zs);
+  const long a_step = (long)(64 / A_LPR) * p.lda * 4, z_step = (long)(64 / Z_LPR) * p.ldz * 4;   // bytes between pieces
+  const long a_stage = (long)BMR * p.lda * 4, z_stage = (long)BMR * p.ldz * 4;                     // bytes between stages
+
+  // slice `sl` (0..3) of the stage whose first row lies at (sa, sz) -> LDS buffer buf
+  auto issue_slice = [&](int sl, const char* sa, const char* sz, int buf) {
+#pragma unroll
+    for (int i = sl; i < A_PW; i += 4) {
+      const int pc = wave * A_PW + i;
+      dma16_sv(lds_a + (buf * A_SZ + pc * 256) * 4, sa + pc * a_step, a_voff);
+    }
+#pragma unroll
+    for (int i = sl; i < Z_PW; i += 4) {
+      const int pc = wave * Z_PW + i;
+      dma16_sv(lds_z + (buf * Z_SZ + pc * 256) * 4, sz + pc * z_step, z_voff);
+    }
+  };
+
+  f32x16 acc[MT][NT], acc2[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int spp = p.M / BMR;                         // stages per phase
+  const int a_frag = (4 * h) * BKO + wk * WTK + MT * l31;
+  const int z_frag = (4 * h) * BN + wn * WTN + NT * l31;
+  int gst = 0;                                       // stages done so far, over the three phases (LDS buffer = gst & 1)
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) issue_slice(sl, Ab + p.a_off[0] * 4, Zb + p.z_off[0] * 4, 0);
+  dma_wait_all();
+  __syncthreads();
+
+  auto phase = [&](f32x16 (&tgt)[MT][NT], int ph) __attribute__((always_inline)) {
+    const char* sa = Ab + p.a_off[ph] * 4;
+    const char* sz = Zb + p.z_off[ph] * 4;
+    const char* na = ph < 2 ? Ab + p.a_off[ph < 2 ? ph + 1 : 2] * 4 : nullptr;     // first stage of the next phase
+    const char* nz = ph < 2 ? Zb + p.z_off[ph < 2 ? ph + 1 : 2] * 4 : nullptr;
+    for (int st = 0; st < spp; ++st, ++gst) {
+      const int cur = gst & 1;
+      const bool last = st + 1 == spp;
+      const bool more = !last || ph < 2;
+      const char* nsa = last ? na : sa + (long)(st + 1) * a_stage;
+      const char* nsz = last ? nz : sz + (long)(st + 1) * z_stage;
+      const float* as = As + cur * A_SZ + a_frag;
+      const float* zs = Zs + cur * Z_SZ + z_frag;
+      avec af[4][4];
+      zvec zf[4][4];
+      auto read_frags = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          af[q][j] = *reinterpret_cast<const avec*>(as + (8 * q + j) * BKO);
+          zf[q][j] = *reinterpret_cast<const zvec*>(zs + (8 * q + j) * BN);
+        }
+      };
+      read_frags(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (more) issue_slice(q, nsa, nsz, cur ^ 1);
+        if (q < 3) read_frags(q + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              tgt[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<MT>(af[q][j], i), vget<NT>(zf[q][j], n), tgt[i][n], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      dma_wait_all();
+      __syncthreads();
+    }
+  };
+  phase(acc, 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc2[i][j] = -acc[i][j];
+  phase(acc, 1);
+  phase(acc2, 2);
+
+  float* out = p.out + (long)bin * p.o_batch;
+  const int col0 = n0 + wn * WTN + NT * l31;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + wk * WTK + MT * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+      zvec o1, o2;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { vset<NT>(o1, n, acc[i][n][r]); vset<NT>(o2, n, acc2[i][n][r]); }
+      *reinterpret_cast<zvec*>(out + (long)k * p.N + col0) = o1;
+      *reinterpret_cast<zvec*>(out + p.o_part + (long)k * p.N + col0) = o2;
     }
 }
 
@@ -1423,6 +1800,77 @@ int st::gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, 
     st::launch_timed(timer, gemm_tn_kernel<128, 2, 2>, dim3(p.tiles_k * p.tiles_n, 1, batches), dim3(TN_THREADS), s, p);
   }
   return st::check_launch("gemm_tn_batched");
+}
+
+// A bin's complex product in three real products (gemm_nn_g3_kernel): C[bin][m][n] = sum_k A0 B0 + A1 B1, C[bin][m][c_off2 + n] =
+// sum_k A0 B0 + A2 B2 with A_p = A + a_off[p] (K readable floats of row m from there), B_p = B + b_off[p] -- [K][ldb] row-major, or
+// with b_transposed [N][ldb] holding B_p^T.  K a multiple of 64, N of 128.  A last half tile of rows (M % 128 == 64) runs on 64-row
+// tiles as a launch of its own, like gemm_nn_batched's.
+int st::gemm_nn_g3_batched(const float* A, long lda, long a_batch, const long a_off[3], const float* B, long ldb, long b_batch,
+                           const long b_off[3], float* C, long ldc, long c_batch, long c_off2, int M, int K, int N, int batches,
+                           hipStream_t s, bool b_transposed) {
+  if (!(A && B && C && M > 0 && K > 0 && K % 64 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+        c_off2 % 4 == 0 && a_off[0] % 4 == 0 && a_off[1] % 4 == 0 && a_off[2] % 4 == 0 && b_off[0] % 4 == 0 && b_off[1] % 4 == 0 && b_off[2] % 4 == 0)) {
+    st::set_error("gemm_nn_g3_batched: bad shape M=%d K=%d N=%d", M, K, N);
+    return ST_EINVAL;
+  }
+  if (M % 128 == 64 && M > 128 && st::tuning(st::TUNE_NO_ROW_SPLIT) == 0) {
+    if (int e = st::gemm_nn_g3_batched(A, lda, a_batch, a_off, B, ldb, b_batch, b_off, C, ldc, c_batch, c_off2, M - 64, K, N, batches, s, b_transposed)) return e;
+    return st::gemm_nn_g3_batched(A + (long)(M - 64) * lda, lda, a_batch, a_off, B, ldb, b_batch, b_off, C + (long)(M - 64) * ldc, ldc, c_batch, c_off2,
+                                  64, K, N, batches, s, b_transposed);
+  }
+  G3Params p{};
+  p.A = A; p.lda = lda; p.a_batch = a_batch;
+  p.B = B; p.ldb = ldb; p.b_batch = b_batch;
+  for (int i = 0; i < 3; ++i) { p.a_off[i] = a_off[i]; p.b_off[i] = b_off[i]; }
+  p.C = C; p.ldc = ldc; p.c_batch = c_batch; p.c_off2 = c_off2;
+  p.M = M; p.N = N; p.batches = batches;
+  // 128-row tiles while they give every CU its two workgroups; else 64-row tiles (three resident per CU), and if those are still
+  // fewer than two per CU the reduction is split in two (the 32-tap layer's back-prop at config 2: 4 x 48 = 192 tiles of 128 rows
+  // -> 768 workgroups of 64 rows x half the reduction, three per CU; measured 423 -> see DESIGN)
+  const long wgs128 = (long)batches * st::ceil_div(M, 128) * (N / 128), wgs64 = (long)batches * st::ceil_div(M, 64) * (N / 128);
+  const int tile = st::tuning(st::TUNE_G3_TILE);                    // 1: 64-row tiles, 2: 128-row tiles, 4: 64 rows + split reduction
+  const bool half_rows = tile == 2 ? false : (tile == 1 || tile == 4 || M <= 64 || wgs128 < 512);
+  p.ksplit = (half_rows && K % 128 == 0 && (tile == 4 || (tile == 0 && wgs64 < 512))) ? 2 : 1;
+  p.K = K / p.ksplit;
+  p.tiles_m = st::ceil_div(M, half_rows ? 64 : 128);
+  p.tiles_n = N / 128;
+  if (p.ksplit > 1)          // the tiles are ADDED into C: both column ranges of the M rows of every bin zeroed first
+    hipLaunchKernelGGL(g3_zero_out_kernel, dim3(st::ceil_div(M, 4), batches), dim3(256), 0, s, C, ldc, c_batch, c_off2, M, N);
+  const dim3 grid(st::ceil_div(batches, 8) * p.tiles_m * p.tiles_n * 8, p.ksplit), block(NTHREADS);
+  st::trace("gemm_nn_g3<%d%s> batched bins=%d M=%d Np=%d Kp=%d ksplit=%d gflop=%.3f", half_rows ? 64 : 128, b_transposed ? ",bt" : "", batches, M, N, K,
+            p.ksplit, 2e-9 * p.tiles_m * (half_rows ? 64 : 128) * (double)N * 3 * K * batches);
+  st::LaunchTimer timer(s);
+  if (half_rows) {
+    if (b_transposed) st::launch_timed(timer, gemm_nn_g3_kernel<64, true>, grid, block, s, p);
+    else st::launch_timed(timer, gemm_nn_g3_kernel<64, false>, grid, block, s, p);
+  } else {
+    if (b_transposed) st::launch_timed(timer, gemm_nn_g3_kernel<128, true>, grid, block, s, p);
+    else st::launch_timed(timer, gemm_nn_g3_kernel<128, false>, grid, block, s, p);
+  }
+  return st::check_launch("gemm_nn_g3");
+}
+
+// The lag products of a bin in three real products (gemm_tn_g3_kernel): out[bin][0] = A0^T Z0 + A1^T Z1, out[bin][1] = A2^T Z2 - A0^T Z0
+// ([K][N] each, o_part floats apart), the reduction over the M rows; A_p = A + a_off[p], Z_p = Z + z_off[p].  M a multiple of 32,
+// K and N of 128.
+int st::gemm_tn_g3_batched(const float* A, long lda, long a_batch, const long a_off[3], const float* Z, long ldz, long z_batch,
+                           const long z_off[3], float* out, long o_batch, long o_part, int M, int K, int N, int batches, hipStream_t s) {
+  if (!(A && Z && out && M > 0 && M % 32 == 0 && K % 128 == 0 && N % 128 == 0 && batches > 0 && lda % 4 == 0 && ldz % 4 == 0 &&
+        (long)32 * lda < (1L << 29) && (long)32 * ldz < (1L << 29))) {
+    st::set_error("gemm_tn_g3_batched: bad shape M=%d K=%d N=%d", M, K, N);
+    return ST_EINVAL;
+  }
+  TN3Params p{};
+  p.A = A; p.lda = lda; p.a_batch = a_batch;
+  p.Z = Z; p.ldz = ldz; p.z_batch = z_batch;
+  for (int i = 0; i < 3; ++i) { p.a_off[i] = a_off[i]; p.z_off[i] = z_off[i]; }
+  p.out = out; p.o_batch = o_batch; p.o_part = o_part;
+  p.M = M; p.K = K; p.N = N; p.tiles_k = K / 128; p.tiles_n = N / 128; p.batches = batches;
+  st::trace("gemm_tn_g3<128> batched bins=%d M=%d Kp=%d Np=%d gflop=%.3f", batches, M, K, N, 2e-9 * 3 * M * (double)K * N * batches);
+  st::LaunchTimer timer(s);
+  st::launch_timed(timer, gemm_tn_g3_kernel, dim3(st::ceil_div(batches, 8) * p.tiles_k * p.tiles_n * 8), dim3(TN_THREADS), s, p);
+  return st::check_launch("gemm_tn_g3_batched");
 }
 
 namespace {

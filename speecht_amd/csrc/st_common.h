@@ -40,7 +40,7 @@ inline void launch_timed(const LaunchTimer& t, void (*kernel)(KArgs...), const d
 }
 enum { TUNE_GEMM_TILE, TUNE_GEMM_SPLITS, TUNE_FWD_SPLITS, TUNE_XCD_GM, TUNE_NO_FAST, TUNE_BF16_TILE,
        TUNE_BF16_WGRAD_SPLITS, TUNE_BF16_SCHED, TUNE_STREAMK, TUNE_TRANSFORM_WGS, TUNE_BF16_WGRAD_TARGET, TUNE_STREAMK_SLOTS, TUNE_NO_FUSED_TRANSFORMS,
-       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_BF16_WGRAD_RING, TUNE_BF16_TAPS_PANEL, TUNE_BF16_WGRAD_BIAS_PASS, TUNE_BF16_WGRAD_PLAIN_ORDER, TUNE_FILTERS_IDFT_VALU, TUNE_NO_ROW_SPLIT, TUNE_COUNT };
+       TUNE_STREAMK_TEST_DROP, TUNE_BF16_LAG_COPIES, TUNE_BF16_WGRAD_RING, TUNE_BF16_TAPS_PANEL, TUNE_BF16_WGRAD_BIAS_PASS, TUNE_BF16_WGRAD_PLAIN_ORDER, TUNE_FILTERS_IDFT_VALU, TUNE_NO_ROW_SPLIT, TUNE_NO_G3, TUNE_G3_TILE, TUNE_COUNT };
 int tuning(int key);
 
 // conv_gemm.hip: batched plain GEMM on the fp32 MFMA convolution kernel (used by conv_fft.hip)
@@ -53,6 +53,13 @@ int gemm_nn_batched(const float* A, long lda, long a_batch, const float* B, long
                     int M, int K, int N, int batches, hipStream_t s, float* sk_ws = nullptr, bool b_transposed = false);
 int gemm_tn_batched(const float* A, long lda, long a_batch, const float* Z, long ldz, long z_batch, float* out, long o_batch,
                     int M, int K, int N, int batches, hipStream_t s, int z_batch_shift = 0);
+// the same products of COMPLEX operands as three real products per bin instead of four (Gauss; conv_gemm.hip gemm_nn_g3_kernel /
+// gemm_tn_g3_kernel): operand planes A_p = A + a_off[p] etc., the real and the imaginary result c_off2 columns / o_part floats apart
+int gemm_nn_g3_batched(const float* A, long lda, long a_batch, const long a_off[3], const float* B, long ldb, long b_batch,
+                       const long b_off[3], float* C, long ldc, long c_batch, long c_off2, int M, int K, int N, int batches,
+                       hipStream_t s, bool b_transposed = false);
+int gemm_tn_g3_batched(const float* A, long lda, long a_batch, const long a_off[3], const float* Z, long ldz, long z_batch,
+                       const long z_off[3], float* out, long o_batch, long o_part, int M, int K, int N, int batches, hipStream_t s);
 
 // conv_bf16.hip: the same per-bin products on the bf16 matrix pipe (planes = 1: bf16 operands; 3: the exact 3-way split of fp32
 // operands, six product terms -- fp32-accurate), and the reduction-major copies of spectra the lag products read

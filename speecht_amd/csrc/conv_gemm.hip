@@ -1814,7 +1814,8 @@ int st::gemm_nn_g3_batched(const float* A, long lda, long a_batch, const long a_
     st::set_error("gemm_nn_g3_batched: bad shape M=%d K=%d N=%d", M, K, N);
     return ST_EINVAL;
   }
-  if (M % 128 == 64 && M > 128 && st::tuning(st::TUNE_NO_ROW_SPLIT) == 0) {
+  if (M % 128 == 64 && M > 128 && (long)batches * st::ceil_div(M, 128) * (N / 128) >= 512 && st::tuning(st::TUNE_G3_TILE) == 0 &&
+      st::tuning(st::TUNE_NO_ROW_SPLIT) == 0) {                    // (a launch that takes 64-row tiles anyway stays whole)
     if (int e = st::gemm_nn_g3_batched(A, lda, a_batch, a_off, B, ldb, b_batch, b_off, C, ldc, c_batch, c_off2, M - 64, K, N, batches, s, b_transposed)) return e;
     return st::gemm_nn_g3_batched(A + (long)(M - 64) * lda, lda, a_batch, a_off, B, ldb, b_batch, b_off, C + (long)(M - 64) * ldc, ldc, c_batch, c_off2,
                                   64, K, N, batches, s, b_transposed);

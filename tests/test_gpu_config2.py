@@ -71,7 +71,7 @@ def test_config2_bucketed_inference_at_full_size_matches_oracle():
     trace = '\n'.join(tr.lines)
     t_out = (max_t + 1) // 2
     rows = len(idx) * t_out
-    batched = lambda bins: sum(1 for l in tr.lines if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=%d ' % bins in l)
+    batched = lambda bins: sum(1 for l in tr.lines if l.startswith(('gemm_nn<', 'gemm_nn_bins<', 'gemm_nn_g3<')) and ' batched bins=%d ' % bins in l)
     # the policy of engine._use_fft: the 32-tap layer from 1 000 output rows, the 7-tap layers and the first layer from 3 000
     # (the wide layer's product runs as TWO launches when a bin's rows -- utterances x 64-frame blocks, padded to 64 -- end in a
     #  half 128-row tile: the whole tiles, then the last 64 rows on the 64-row kernel, st::gemm_nn_batched)

@@ -141,8 +141,9 @@ def test_fullsize_fp32_frequency_domain_l8_gradients_match_float64_reference(cas
   text = '\n'.join(trace)
   # L8 (48 bins): forward and back-prop products on the batched convolution kernel, lag products on the batched
   # filter-gradient kernel; the seven 7-tap layers (36 bins) likewise
-  assert sum(1 for l in trace if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=48 ' in l) == 2, text
-  assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=96 M=512 ' in l) == 1, text      # real + imaginary lag products of the 48 bins
+  # (round 6: the 32-tap layer's complex products in three real products -- gemm_nn_g3 / gemm_tn_g3, conv_fft.hip g3_form)
+  assert sum(1 for l in trace if l.startswith('gemm_nn_g3<') and ' batched bins=48 ' in l) == 2, text
+  assert sum(1 for l in trace if l.startswith('gemm_tn_g3<') and ' batched bins=48 M=256 ' in l) == 1, text   # the lag products of the 48 bins
   assert sum(1 for l in trace if l.startswith(('gemm_nn<', 'gemm_nn_bins<')) and ' batched bins=36 ' in l) == 14, text
   assert sum(1 for l in trace if l.startswith('gemm_tn<') and ' batched bins=72 M=512 ' in l) == 7, text
   assert not any('Kp=8192' in l or 'Kp=64512' in l or 'Kp=1792' in l for l in trace if 'batched' not in l), text   # no W-tap launch of L1..L8
@@ -163,7 +164,8 @@ def test_fullsize_bf16x6_with_frequency_domain_l8(case):
   """bf16x6 mode as it runs by default: the frequency-domain (fp32) L8 between bf16x6 layers -- the planes of its
   neighbours are split from its fp32 outputs."""
   eng, trace = run_step(case, 'bf16x6', fft_conv=True)
-  assert sum(1 for l in trace if ' batched bins=48 ' in l) == 2 and sum(1 for l in trace if ' batched bins=96 M=512 ' in l) == 1 and \
+  assert sum(1 for l in trace if l.startswith('gemm_nn_g3<') and ' batched bins=48 ' in l) == 2 and \
+      sum(1 for l in trace if l.startswith('gemm_tn_g3<') and ' batched bins=48 ' in l) == 1 and \
       any(l.startswith('gemm_nn_bf16<256,NP=3>') for l in trace)
   compare(eng, case['ref'], case)
 

@@ -93,13 +93,14 @@ def run(order, batch, mels, rate, steps, warmup, pool_size, conv_mode, seed=0):
     gen0 = eng._storage.generation
     mem0 = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
     shapes = set()
-    host = []
+    host, seen = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
       h0 = time.perf_counter()
       model.step(sess)
       host.append(time.perf_counter() - h0)
       shapes.add(eng._shape)
+      seen.append(eng._shape)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     coord.request_stop()
@@ -113,7 +114,9 @@ def run(order, batch, mels, rate, steps, warmup, pool_size, conv_mode, seed=0):
                ensure_shape_ms_per_step=round(acc['seconds'] / steps * 1e3, 3),
                storage_reallocations_after_warmup=eng._storage.generation - gen0,
                torch_allocations_after_warmup=torch.cuda.memory_stats().get('allocation.all.allocated', 0) - mem0,
-               step_call_ms_median=round(float(np.median(host)) * 1e3, 3))
+               step_call_ms_median=round(float(np.median(host)) * 1e3, 3),
+               # the five longest step() calls and the (batch, frames) they ran at: a mean far above the median is a few of these
+               slowest_step_calls=[dict(ms=round(host[k] * 1e3, 2), step=int(k), shape=[int(v) for v in seen[k]]) for k in np.argsort(host)[::-1][:5]])
   return out
 
 

@@ -65,6 +65,40 @@ def test_gemm_nn_g3_against_float64(dev, bins, M, K, N, bt):
   assert float(np.abs(C[:, :, N:c_off2] - 7.0).max()) == 0.0 and float(np.abs(C[:, :, c_off2 + N:] - 7.0).max()) == 0.0
 
 
+def test_split_reduction_adds_two_halves_and_is_bit_reproducible(dev):
+  # the 32-tap layer's back-prop shape in small: few output tiles, a long reduction -> 64-row tiles, each phase's reduction in two
+  # halves ADDED into a zeroed output by float atomics.  Two addends onto +0: a + b == b + a, so whichever workgroup arrives first
+  # the bits are the same -- twenty launches over a dirty output, all identical, and equal to the unsplit launch to rounding
+  from speecht_amd._lib import call, launch_trace, set_tuning
+  bins, M, K, N = 48, 256, 512, 256
+  rng = np.random.default_rng(7)
+  A = torch.as_tensor(rng.standard_normal((bins, M, 3 * K)).astype(np.float32)).to(dev)
+  Bt = torch.as_tensor(rng.standard_normal((bins, 3, N, K)).astype(np.float32)).to(dev)
+  C = torch.empty((bins, M, 2 * N), device=dev)
+
+  def run():
+    C.fill_(float('nan'))
+    with launch_trace() as tr:
+      call('st_gemm_nn_g3_batched_f32', P(A), 3 * K, M * 3 * K, i64x3([0, 2 * K, K]), P(Bt), K, 3 * N * K, i64x3([0, 2 * N * K, N * K]), 1,
+           P(C), 2 * N, M * 2 * N, N, M, K, N, bins, None)
+    torch.cuda.synchronize()
+    return C.clone(), tr.lines[0]
+
+  first, line = run()
+  assert 'gemm_nn_g3<64,bt>' in line and 'ksplit=2' in line, line
+  assert bool(torch.isfinite(first).all())
+  for _ in range(20):
+    again, _ = run()
+    assert torch.equal(first, again)
+  try:
+    set_tuning('g3_tile', 2)                       # 128-row tiles, the whole reduction in one workgroup
+    whole, line = run()
+    assert 'ksplit=1' in line, line
+  finally:
+    set_tuning('g3_tile', 0)
+  assert float((first - whole).abs().max()) < 2e-6 * float(whole.abs().max())
+
+
 @pytest.mark.parametrize('bins,M,K,N', [(9, 256, 128, 256), (3, 64, 256, 128), (17, 96, 128, 128)])
 def test_gemm_tn_g3_against_float64(dev, bins, M, K, N):
   # out[bin][0] = A0^T Z0 + A1^T Z1, out[bin][1] = A2^T Z2 - A0^T Z0
